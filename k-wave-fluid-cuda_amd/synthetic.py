@@ -1,0 +1,247 @@
+"""Synthetic k-Wave input generator (file format 1.1 datasets).
+
+Produces, as a dict of NumPy arrays keyed by the reference's HDF5 dataset names
+(/root/reference/Utils/MatrixNames.h:48-275, main.cpp:446-563), exactly what the reference would
+read from an input file: grid scalars, medium, k-space derivative/shift operators, PML vectors,
+sources and the sensor mask.  Index datasets are 1-based like in the file
+(/root/reference/MatrixClasses/IndexMatrix.cpp:161-168 converts them at load time).
+
+The operator / PML formulas are the standard k-Wave MATLAB conventions; they are *data* for the
+solver (the reference reads them from the file and never computes them).
+
+Arrays are stored [z][y][x] (x fastest), i.e. HDF5 dims (Nz, Ny, Nx).
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, Optional
+
+import numpy as np
+
+F32 = np.float32
+U64 = np.uint64
+
+
+def _kvec(n: int, d: float) -> np.ndarray:
+    """k-Wave wavenumber vector in FFT order (float64)."""
+    if n == 1:
+        return np.zeros(1)
+    if n % 2 == 0:
+        idx = np.arange(-n // 2, n // 2)
+    else:
+        idx = np.arange(-(n - 1) // 2, (n - 1) // 2 + 1)
+    k = (2.0 * math.pi / (n * d)) * idx
+    return np.fft.ifftshift(k)
+
+
+def _cplx_to_f32_pairs(c: np.ndarray) -> np.ndarray:
+    out = np.empty(c.shape + (2,), dtype=F32)
+    out[..., 0] = c.real
+    out[..., 1] = c.imag
+    return out
+
+
+def kspace_operators(nx: int, ny: int, nz: int, dx: float, dy: float, dz: float) -> Dict[str, np.ndarray]:
+    """ddx/ddy/ddz_k_shift_{pos,neg}[_r] and {x,y,z}_shift_neg_r (interleaved complex float32)."""
+    ops: Dict[str, np.ndarray] = {}
+    for ax, n, d in (("x", nx, dx), ("y", ny, dy), ("z", nz, dz)):
+        k = _kvec(n, d)
+        pos = 1j * k * np.exp(1j * k * d / 2.0)
+        neg = 1j * k * np.exp(-1j * k * d / 2.0)
+        shift = np.exp(-1j * k * d / 2.0)
+        nr = n // 2 + 1
+        if ax == "x":
+            ops["ddx_k_shift_pos_r"] = _cplx_to_f32_pairs(pos[:nr])
+            ops["ddx_k_shift_neg_r"] = _cplx_to_f32_pairs(neg[:nr])
+        else:
+            ops[f"dd{ax}_k_shift_pos"] = _cplx_to_f32_pairs(pos)
+            ops[f"dd{ax}_k_shift_neg"] = _cplx_to_f32_pairs(neg)
+        ops[f"{ax}_shift_neg_r"] = _cplx_to_f32_pairs(shift[:nr])
+    return ops
+
+
+def pml_vectors(n: int, d: float, dt: float, c_ref: float, size: int, alpha: float, staggered: bool) -> np.ndarray:
+    """k-Wave getPML (PML inside the grid); returns float32 [n]."""
+    pml = np.ones(n, dtype=np.float64)
+    if size <= 0:
+        return pml.astype(F32)
+    x = np.arange(1, size + 1, dtype=np.float64)
+    if staggered:
+        left = alpha * (c_ref / d) * (((x + 0.5) - size - 1.0) / (0.0 - size)) ** 4
+        right = alpha * (c_ref / d) * ((x + 0.5) / size) ** 4
+    else:
+        left = alpha * (c_ref / d) * ((x - size - 1.0) / (0.0 - size)) ** 4
+        right = alpha * (c_ref / d) * (x / size) ** 4
+    pml[:size] = np.exp(-left * dt / 2.0)
+    pml[n - size:] = np.exp(-right * dt / 2.0)
+    return pml.astype(F32)
+
+
+def _grid(nx, ny, nz):
+    z, y, x = np.meshgrid(np.arange(nz, dtype=np.float64), np.arange(ny, dtype=np.float64),
+                          np.arange(nx, dtype=np.float64), indexing="ij")
+    return x, y, z
+
+
+def _sg_mean(a: np.ndarray, axis: int) -> np.ndarray:
+    """staggered-grid value = mean of the two neighbours along axis (edge replicated)."""
+    nxt = np.concatenate([np.take(a, range(1, a.shape[axis]), axis=axis),
+                          np.take(a, [a.shape[axis] - 1], axis=axis)], axis=axis)
+    return 0.5 * (a + nxt)
+
+
+def make_problem(nx: int, ny: Optional[int] = None, nz: Optional[int] = None, *,
+                 heterogeneous: bool = True, nonlinear: bool = True, absorbing: bool = True,
+                 source: str = "p0", nt: int = 110, pml_size: int = 10, pml_alpha: float = 2.0,
+                 pml_off: bool = False, dx: float = 2.0e-4, cfl: float = 0.3,
+                 source_mode: int = 0, source_many: int = 0, sensor: str = "plane",
+                 hetero_subset: Optional[dict] = None, seed: int = 0x5EED1234) -> Dict[str, np.ndarray]:
+    """Build one synthetic problem.
+
+    source: "p0" (1 MPa Gaussian ball), "p_source" (1 MHz tone burst on plane x=12),
+            "u_source" (velocity source on the same plane, ux only), "transducer", or "none".
+    hetero_subset: optionally {"c0": bool, "rho0": bool, "BonA": bool, "alpha_coeff": bool} to mix
+            scalar / array medium parameters (detected per dataset by shape in the reference:
+            /root/reference/Parameters/Parameters.cpp:426-459).
+    """
+    ny = nx if ny is None else ny
+    nz = nx if nz is None else nz
+    dy = dz = dx
+    n = max(nx, ny, nz)
+    x, y, z = _grid(nx, ny, nz)
+    two_pi = 2.0 * math.pi
+    het = {"c0": heterogeneous, "rho0": heterogeneous, "BonA": heterogeneous, "alpha_coeff": heterogeneous}
+    if hetero_subset:
+        het.update(hetero_subset)
+
+    pr: Dict[str, np.ndarray] = {}
+
+    def scalar_f(v):
+        return np.array([[[v]]], dtype=F32)
+
+    def scalar_u(v):
+        return np.array([[[v]]], dtype=U64)
+
+    # ---- medium -------------------------------------------------------------------------------
+    if het["c0"]:
+        c0 = 1500.0 * (1.0 + 0.05 * np.sin(two_pi * 3 * x / nx) * np.cos(two_pi * 2 * y / ny) * np.cos(two_pi * z / nz))
+        r2 = (x - nx // 2) ** 2 + (y - ny // 2) ** 2 + (z - nz // 2) ** 2
+        c0 = np.where(r2 <= (n / 6.0) ** 2, 1600.0, c0)
+        pr["c0"] = c0.astype(F32)
+    else:
+        pr["c0"] = scalar_f(1500.0)
+    c_ref = float(pr["c0"].max())
+    if het["rho0"]:
+        rho0 = 1000.0 * (1.0 + 0.04 * np.cos(two_pi * 2 * x / nx) * np.sin(two_pi * 3 * z / nz))
+        pr["rho0"] = rho0.astype(F32)
+        pr["rho0_sgx"] = _sg_mean(rho0, 2).astype(F32)
+        pr["rho0_sgy"] = _sg_mean(rho0, 1).astype(F32)
+        pr["rho0_sgz"] = _sg_mean(rho0, 0).astype(F32)
+    else:
+        for nm in ("rho0", "rho0_sgx", "rho0_sgy", "rho0_sgz"):
+            pr[nm] = scalar_f(1000.0)
+    if nonlinear:
+        pr["BonA"] = (6.0 + 2.0 * np.sin(two_pi * y / ny)).astype(F32) if het["BonA"] else scalar_f(6.0)
+    if absorbing:
+        pr["alpha_coeff"] = ((0.75 + 0.25 * np.cos(two_pi * x / nx)).astype(F32)
+                             if het["alpha_coeff"] else scalar_f(0.75))
+        pr["alpha_power"] = scalar_f(1.5)
+
+    dt = float(F32(cfl * dx / c_ref))
+
+    # ---- grid scalars / flags -----------------------------------------------------------------
+    pr["Nx"], pr["Ny"], pr["Nz"], pr["Nt"] = scalar_u(nx), scalar_u(ny), scalar_u(nz), scalar_u(nt)
+    pr["dt"], pr["dx"], pr["dy"], pr["dz"] = scalar_f(dt), scalar_f(dx), scalar_f(dy), scalar_f(dz)
+    pr["c_ref"] = scalar_f(c_ref)
+    for ax in "xyz":
+        pr[f"pml_{ax}_size"] = scalar_u(0 if pml_off else pml_size)
+        pr[f"pml_{ax}_alpha"] = scalar_f(pml_alpha)
+    pr["nonuniform_grid_flag"] = scalar_u(0)
+    pr["nonlinear_flag"] = scalar_u(int(nonlinear))
+    pr["absorbing_flag"] = scalar_u(int(absorbing))
+
+    # ---- operators + PML ----------------------------------------------------------------------
+    pr.update(kspace_operators(nx, ny, nz, dx, dy, dz))
+    eff = 0 if pml_off else pml_size
+    for ax, nn, dd in (("x", nx, dx), ("y", ny, dy), ("z", nz, dz)):
+        pr[f"pml_{ax}"] = pml_vectors(nn, dd, dt, c_ref, eff, pml_alpha, False)
+        pr[f"pml_{ax}_sg{ax}"] = pml_vectors(nn, dd, dt, c_ref, eff, pml_alpha, True)
+
+    # ---- sources ------------------------------------------------------------------------------
+    for nm in ("ux_source_flag", "uy_source_flag", "uz_source_flag", "p_source_flag", "p0_source_flag",
+               "transducer_source_flag"):
+        pr[nm] = scalar_u(0)
+    rng = np.random.default_rng(seed)
+    if source == "p0":
+        sigma = 4.0
+        r2 = (x - nx // 2) ** 2 + (y - ny // 2) ** 2 + (z - nz // 2) ** 2
+        pr["p0_source_input"] = (1.0e6 * np.exp(-r2 / (2.0 * sigma * sigma))).astype(F32)
+        pr["p0_source_flag"] = scalar_u(1)
+    elif source in ("p_source", "u_source", "transducer"):
+        xs = min(12, nx - 1)
+        yy, zz = np.meshgrid(np.arange(ny), np.arange(nz), indexing="xy")
+        # linear (MATLAB, 1-based) indices of plane x = xs, restricted to a centred patch
+        y0, y1 = ny // 4, ny - ny // 4
+        z0, z1 = nz // 4, nz - nz // 4
+        sel = (yy >= y0) & (yy < y1) & (zz >= z0) & (zz < z1)
+        lin = (zz[sel].astype(np.int64) * ny + yy[sel].astype(np.int64)) * nx + xs
+        lin = np.sort(lin).astype(U64) + U64(1)
+        nsrc = lin.size
+        nt_src = nt
+        t = np.arange(nt_src, dtype=np.float64) * dt
+        f0 = 1.0e6
+        env = np.minimum(1.0, t * f0 / 3.0)  # 3-cycle ramp
+        sig = np.sin(two_pi * f0 * t) * env
+        if source == "p_source":
+            amp = 1.0e5 / (3.0 * c_ref * c_ref) if source_mode != 0 else 1.0e5 / (3.0 * c_ref * c_ref)
+            base = (amp * sig).astype(F32)
+            if source_many:
+                w = (1.0 + 0.1 * rng.standard_normal(nsrc)).astype(F32)
+                pr["p_source_input"] = (base[:, None] * w[None, :]).reshape(1, nt_src, nsrc)
+            else:
+                pr["p_source_input"] = base.reshape(1, nt_src, 1)
+            pr["p_source_index"] = lin.reshape(1, 1, nsrc)
+            pr["p_source_flag"] = scalar_u(nt_src)
+            pr["p_source_mode"] = scalar_u(source_mode)
+            pr["p_source_many"] = scalar_u(source_many)
+        elif source == "u_source":
+            base = (0.05 * sig).astype(F32)
+            if source_many:
+                w = (1.0 + 0.1 * rng.standard_normal(nsrc)).astype(F32)
+                pr["ux_source_input"] = (base[:, None] * w[None, :]).reshape(1, nt_src, nsrc)
+            else:
+                pr["ux_source_input"] = base.reshape(1, nt_src, 1)
+            pr["u_source_index"] = lin.reshape(1, 1, nsrc)
+            pr["ux_source_flag"] = scalar_u(nt_src)
+            pr["u_source_mode"] = scalar_u(source_mode)
+            pr["u_source_many"] = scalar_u(source_many)
+        else:  # transducer
+            delays = (np.abs(np.arange(nsrc) % 16 - 8)).astype(U64)  # focusing-like delay pattern
+            nsig = nt_src + int(delays.max()) + 1
+            tt = np.arange(nsig, dtype=np.float64) * dt
+            sig_t = np.sin(two_pi * f0 * tt) * np.minimum(1.0, tt * f0 / 3.0)
+            pr["transducer_source_input"] = (0.05 * sig_t).astype(F32).reshape(1, 1, nsig)
+            pr["delay_mask"] = (delays + U64(1)).reshape(1, 1, nsrc)
+            pr["u_source_index"] = lin.reshape(1, 1, nsrc)
+            pr["transducer_source_flag"] = scalar_u(nt_src)
+            pr["u_source_mode"] = scalar_u(0)
+            pr["u_source_many"] = scalar_u(0)
+    elif source != "none":
+        raise ValueError(source)
+
+    # ---- sensor -------------------------------------------------------------------------------
+    pr["sensor_mask_type"] = scalar_u(0)
+    if sensor == "plane":
+        zs = nz // 2
+        yy, xx = np.meshgrid(np.arange(ny), np.arange(nx), indexing="ij")
+        lin = (zs * ny + yy.ravel().astype(np.int64)) * nx + xx.ravel().astype(np.int64)
+    elif sensor == "random":
+        lin = np.sort(rng.choice(nx * ny * nz, size=min(4096, nx * ny * nz // 4), replace=False))
+    else:
+        raise ValueError(sensor)
+    pr["sensor_mask_index"] = (lin.astype(U64) + U64(1)).reshape(1, 1, -1)
+    return pr
+
+
+def is_scalar(a: np.ndarray) -> bool:
+    return a.size == 1
