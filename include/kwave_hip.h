@@ -1,0 +1,259 @@
+/*
+ * kwave_hip.h — C-ABI of the MI355X (gfx950) device layer for the k-space first-order acoustic step.
+ *
+ * This is the drop-in boundary for the per-time-step hot path of klepo/k-Wave-Fluid-CUDA.  The reference
+ * has no FFI layer; its device-operator boundary is four C++ surfaces:
+ *   (1) namespace SolverCudaKernels            KSpaceSolver/SolverCudaKernels.cuh:52-500
+ *   (2) class CufftComplexMatrix (plans+exec)   MatrixClasses/CufftComplexMatrix.h:73-238
+ *   (3) namespace OutputStreamsCudaKernels     OutputStreams/OutputStreamsCudaKernels.cuh:47-106
+ *   (4) CudaParameters / CudaDeviceConstants   Parameters/CudaParameters.h:140-146, CudaDeviceConstants.cuh:44-116
+ * plus the memory verbs of the matrix classes   MatrixClasses/BaseFloatMatrix.h:85-131.
+ * Every entry point below names the reference interface (file:line, relative to the reference root) it replaces.
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes; device pointers are raw HIP device addresses.
+ *   - every function returns kw_status (0 = OK).  The reference's convention (void + C++ exception,
+ *     Logger/Logger.h:194-216) is restored by the C++ host shims in k-wave-fluid-cuda_amd/host/, which turn
+ *     a non-zero status into std::runtime_error(kw_last_error()).
+ *   - all launches are asynchronous on the context's stream (reference: default stream, in order).
+ *   - data layout: fp32, row-major with x fastest; complex = interleaved (re,im); indices = uint64, 0-based
+ *     (KSpaceFirstOrderSolver.cpp:2916-2920, ComplexMatrix.cpp:124-135, IndexMatrix.cpp:161-168).
+ *   - a NULL pointer for an optional per-voxel medium array selects the scalar from kw_constants, exactly
+ *     like the reference's boolean template flags (e.g. SolverCudaKernels.cu:1401-1440).
+ */
+#ifndef KWAVE_HIP_H
+#define KWAVE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define KW_API __attribute__((visibility("default")))
+
+typedef struct kw_ctx kw_ctx;
+
+typedef enum kw_status
+{
+  KW_OK            = 0,
+  KW_ERR_INVALID   = 1, /* bad argument (NULL pointer, zero size, unsupported flag) */
+  KW_ERR_HIP       = 2, /* HIP runtime error ("GPU error: ..." of Logger/ErrorMessages.h:331) */
+  KW_ERR_FFT       = 3, /* rocFFT error (CufftComplexMatrix.cpp:63-72,706-720) */
+  KW_ERR_ALLOC     = 4, /* out of memory (std::bad_alloc of BaseFloatMatrix.cpp:140-143) */
+  KW_ERR_STATE     = 5, /* call order violated (constants / plans not set) */
+  KW_ERR_NO_DEVICE = 6  /* no usable gfx950 device (CudaParameters.cpp:81-177) */
+} kw_status;
+
+/* Parameters/Parameters.h:60-94 */
+typedef enum kw_source_mode
+{
+  KW_SRC_DIRICHLET              = 0,
+  KW_SRC_ADDITIVE_NO_CORRECTION = 1,
+  KW_SRC_ADDITIVE               = 2
+} kw_source_mode;
+
+/* OutputStreams/BaseOutputStream.h ReduceOperator (device-side subset used by the samplers) */
+typedef enum kw_reduce_op
+{
+  KW_OP_NONE = 0, /* buf[i]  = src      */
+  KW_OP_RMS  = 1, /* buf[i] += src*src  */
+  KW_OP_MAX  = 2, /* buf[i]  = max(buf[i], src) */
+  KW_OP_MIN  = 3  /* buf[i]  = min(buf[i], src) */
+} kw_reduce_op;
+
+/* Mirror of struct CudaDeviceConstants (Parameters/CudaDeviceConstants.cuh:44-116), filled the way
+ * CudaParameters::setUpDeviceConstants does (Parameters/CudaParameters.cpp:238-288).  Passed to kernels as a
+ * by-value argument (SGPR-resident) instead of a __constant__ symbol. */
+typedef struct kw_constants
+{
+  uint32_t nx, ny, nz, n_elements;
+  uint32_t nx_complex, ny_complex, nz_complex, n_elements_complex;
+  float    fft_divider, fft_divider_x, fft_divider_y, fft_divider_z;
+  float    dt, dt_by_2, c2;
+  float    rho0, dt_rho0, dt_rho0_sgx, dt_rho0_sgy, dt_rho0_sgz;
+  float    b_on_a, absorb_tau, absorb_eta;
+  uint32_t velocity_source_size, velocity_source_mode, velocity_source_many;
+  uint32_t pressure_source_size, pressure_source_mode, pressure_source_many;
+} kw_constants;
+
+typedef struct kw_device_info
+{
+  char     name[128];
+  char     arch[64];
+  int32_t  device_id;
+  int32_t  compute_units;
+  int32_t  wavefront_size;
+  int32_t  clock_mhz;
+  uint64_t total_mem;
+  uint64_t free_mem;
+  uint64_t lds_per_cu;
+  uint64_t l2_bytes;
+} kw_device_info;
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * Context / device  — replaces CudaParameters::selectDevice (CudaParameters.cpp:81-177)
+ * ---------------------------------------------------------------------------------------------------------------- */
+/* device_id < 0: first free device (reference: -g not given).  Creates the context's stream. */
+KW_API kw_status   kw_init(int device_id, kw_ctx** out_ctx);
+KW_API kw_status   kw_destroy(kw_ctx* ctx);
+/* message of the last failing call on this thread (ctx may be NULL) */
+KW_API const char* kw_last_error(void);
+KW_API kw_status   kw_device_info_get(kw_ctx* ctx, kw_device_info* out);
+/* use an externally owned hipStream_t (e.g. torch's current stream); NULL restores the context's own stream */
+KW_API kw_status   kw_set_stream(kw_ctx* ctx, void* hip_stream);
+KW_API void*       kw_get_stream(kw_ctx* ctx);
+KW_API kw_status   kw_sync(kw_ctx* ctx);
+/* HIP events on the context's stream (bench.py times kernels with these) */
+KW_API kw_status   kw_event_create(kw_ctx* ctx, void** out_event);
+KW_API kw_status   kw_event_record(kw_ctx* ctx, void* event);
+KW_API kw_status   kw_event_synchronize(kw_ctx* ctx, void* event);
+KW_API kw_status   kw_event_elapsed_ms(kw_ctx* ctx, void* start, void* stop, float* out_ms);
+KW_API kw_status   kw_event_destroy(kw_ctx* ctx, void* event);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * Memory verbs — replace BaseFloatMatrix/BaseIndexMatrix allocate/copyToDevice/copyFromDevice/zeroDeviceMatrix
+ * (MatrixClasses/BaseFloatMatrix.cpp:77-80,124-168; BaseIndexMatrix.cpp)
+ * ---------------------------------------------------------------------------------------------------------------- */
+KW_API kw_status kw_malloc(kw_ctx* ctx, size_t bytes, void** out_dptr);
+KW_API kw_status kw_free(kw_ctx* ctx, void* dptr);
+KW_API kw_status kw_memcpy_h2d(kw_ctx* ctx, void* dst, const void* src, size_t bytes);
+KW_API kw_status kw_memcpy_d2h(kw_ctx* ctx, void* dst, const void* src, size_t bytes);
+KW_API kw_status kw_memcpy_d2d(kw_ctx* ctx, void* dst, const void* src, size_t bytes);
+KW_API kw_status kw_memcpy_d2h_async(kw_ctx* ctx, void* dst, const void* src, size_t bytes);
+KW_API kw_status kw_memset(kw_ctx* ctx, void* dptr, int value, size_t bytes);
+/* pinned host memory (reference: cudaHostRegister / mapped buffers, BaseOutputStream.cpp:369-388) */
+KW_API kw_status kw_host_alloc(kw_ctx* ctx, size_t bytes, void** out_hptr);
+KW_API kw_status kw_host_free(kw_ctx* ctx, void* hptr);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * Device constants — replaces CudaDeviceConstants::uploadDeviceConstants (CudaDeviceConstants.cu:58-60)
+ * and CudaParameters::setKernelConfiguration (CudaParameters.cpp:195-232; geometry is derived internally
+ * from the CU count instead of SM count x 8).
+ * ---------------------------------------------------------------------------------------------------------------- */
+KW_API kw_status kw_set_constants(kw_ctx* ctx, const kw_constants* constants);
+KW_API kw_status kw_get_constants(kw_ctx* ctx, kw_constants* out);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * FFT — replaces CufftComplexMatrix static plan factory + compute* members
+ * (MatrixClasses/CufftComplexMatrix.cpp:82-130 plans ND, :144-426 plans 1D, :432-502 destroy, :508-534 exec ND,
+ *  :540-692 exec 1D).  Unnormalised, forward sign -i, out-of-place, nx/2+1 bins along x.  Dimensions come from
+ * kw_set_constants.  C2R may overwrite its input (as cuFFT may).
+ * ---------------------------------------------------------------------------------------------------------------- */
+KW_API kw_status kw_fft_create_plans_3d(kw_ctx* ctx);                         /* createR2CFftPlanND + createC2RFftPlanND */
+KW_API kw_status kw_fft_create_plans_1d(kw_ctx* ctx, int axis);               /* create{R2C,C2R}FftPlan1D{X,Y,Z} */
+KW_API kw_status kw_fft_destroy_plans(kw_ctx* ctx);                           /* destroyAllPlansAndStaticData */
+KW_API kw_status kw_fft_r2c_3d(kw_ctx* ctx, const float* in, float* out);     /* computeR2CFftND */
+KW_API kw_status kw_fft_c2r_3d(kw_ctx* ctx, float* in, float* out);           /* computeC2RFftND */
+/* 1-D transforms along axis (0=x,1=y,2=z); the half-spectrum keeps the [z][y][x] order with the transformed
+ * axis shortened to n/2+1 (the reference's transposed/padded layout for Y and Z is an implementation detail) */
+KW_API kw_status kw_fft_r2c_1d(kw_ctx* ctx, int axis, const float* in, float* out);  /* computeR2CFft1D{X,Y,Z} */
+KW_API kw_status kw_fft_c2r_1d(kw_ctx* ctx, int axis, float* in, float* out);        /* computeC2RFft1D{X,Y,Z} */
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * Solver kernels — one entry per SolverCudaKernels wrapper (3-D, uniform grid)
+ * ---------------------------------------------------------------------------------------------------------------- */
+/* computeVelocityHeterogeneous (.cuh:92, .cu:184-243) when dt_rho0_sg* != NULL,
+ * computeVelocityHomogeneousUniform (.cuh:107, .cu:278-335) when all three are NULL */
+KW_API kw_status kw_compute_velocity(kw_ctx* ctx, float* ux_sgx, float* uy_sgy, float* uz_sgz, const float* ifft_x,
+                                     const float* ifft_y, const float* ifft_z, const float* dt_rho0_sgx,
+                                     const float* dt_rho0_sgy, const float* dt_rho0_sgz, const float* pml_x_sgx,
+                                     const float* pml_y_sgy, const float* pml_z_sgz);
+/* addTransducerSource (.cuh:132, .cu:463-497) */
+KW_API kw_status kw_add_transducer_source(kw_ctx* ctx, float* ux_sgx, const uint64_t* velocity_source_index,
+                                          const float* transducer_source_input, const uint64_t* delay_mask,
+                                          uint64_t time_index);
+/* addVelocitySource (.cuh:141-143, .cu:504-555) */
+KW_API kw_status kw_add_velocity_source(kw_ctx* ctx, float* velocity, const float* velocity_source_input,
+                                        const uint64_t* velocity_source_index, uint64_t time_index);
+/* addPressureSource (.cuh:152, .cu:570-660) */
+KW_API kw_status kw_add_pressure_source(kw_ctx* ctx, float* rho_x, float* rho_y, float* rho_z,
+                                        const float* pressure_source_input, const uint64_t* pressure_source_index,
+                                        uint64_t time_index);
+/* insertSourceIntoScalingMatrix (.cuh:163-166, .cu:679-733) */
+KW_API kw_status kw_insert_source_into_scaling_matrix(kw_ctx* ctx, float* scaled_source, const float* source_input,
+                                                      const uint64_t* source_index, uint64_t source_size,
+                                                      int many_flag, uint64_t time_index);
+/* computeSourceGradient (.cuh:173-174, .cu:740-758) */
+KW_API kw_status kw_compute_source_gradient(kw_ctx* ctx, float* source_spectrum, const float* source_kappa);
+/* addVelocityScaledSource (.cuh:181-182, .cu:765-786) */
+KW_API kw_status kw_add_velocity_scaled_source(kw_ctx* ctx, float* velocity, const float* scaled_source);
+/* addPressureScaledSource (.cuh:191-192, .cu:795-826) */
+KW_API kw_status kw_add_pressure_scaled_source(kw_ctx* ctx, float* rho_x, float* rho_y, float* rho_z,
+                                               const float* scaled_source);
+/* addInitialPressureSource (.cuh:208, .cu:864-927); c2 == NULL -> scalar */
+KW_API kw_status kw_add_initial_pressure_source(kw_ctx* ctx, float* p, float* rho_x, float* rho_y, float* rho_z,
+                                                const float* p0_source_input, const float* c2);
+/* computeInitialVelocityHeterogeneous / HomogeneousUniform (.cuh:222,236, .cu:949-1040) */
+KW_API kw_status kw_compute_initial_velocity(kw_ctx* ctx, float* ux_sgx, float* uy_sgy, float* uz_sgz,
+                                             const float* dt_rho0_sgx, const float* dt_rho0_sgy,
+                                             const float* dt_rho0_sgz);
+/* computePressureGradient (.cuh:267, .cu:1139-1185) */
+KW_API kw_status kw_compute_pressure_gradient(kw_ctx* ctx, float* fft_x, float* fft_y, float* fft_z,
+                                              const float* kappa, const float* ddx_k_shift_pos,
+                                              const float* ddy_k_shift_pos, const float* ddz_k_shift_pos);
+/* computeVelocityGradient (.cuh:281, .cu:1210-1268) */
+KW_API kw_status kw_compute_velocity_gradient(kw_ctx* ctx, float* fft_x, float* fft_y, float* fft_z,
+                                              const float* kappa, const float* ddx_k_shift_neg,
+                                              const float* ddy_k_shift_neg, const float* ddz_k_shift_neg);
+/* computeDensityNonlinear (.cuh:306, .cu:1358-1440) / computeDensityLinear (.cuh:320, .cu:1470-1545); rho0 NULL -> scalar */
+KW_API kw_status kw_compute_density_nonlinear(kw_ctx* ctx, float* rho_x, float* rho_y, float* rho_z,
+                                              const float* pml_x, const float* pml_y, const float* pml_z,
+                                              const float* duxdx, const float* duydy, const float* duzdz,
+                                              const float* rho0);
+KW_API kw_status kw_compute_density_linear(kw_ctx* ctx, float* rho_x, float* rho_y, float* rho_z, const float* pml_x,
+                                           const float* pml_y, const float* pml_z, const float* duxdx,
+                                           const float* duydy, const float* duzdz, const float* rho0);
+/* computePressureTermsNonlinear (.cuh:335-338, .cu:1577-1695); b_on_a / rho0 NULL -> scalar */
+KW_API kw_status kw_compute_pressure_terms_nonlinear(kw_ctx* ctx, float* density_sum, float* nonlinear_term,
+                                                     float* velocity_gradient_sum, const float* rho_x,
+                                                     const float* rho_y, const float* rho_z, const float* duxdx,
+                                                     const float* duydy, const float* duzdz, const float* b_on_a,
+                                                     const float* rho0);
+/* computePressureTermsLinear (.cuh:348-350, .cu:1724-1790) */
+KW_API kw_status kw_compute_pressure_terms_linear(kw_ctx* ctx, float* density_sum, float* velocity_gradient_sum,
+                                                  const float* rho_x, const float* rho_y, const float* rho_z,
+                                                  const float* duxdx, const float* duydy, const float* duzdz,
+                                                  const float* rho0);
+/* computeAbsorbtionTerm (.cuh:365-368, .cu:1812-1840) */
+KW_API kw_status kw_compute_absorbtion_term(kw_ctx* ctx, float* fft_part1, float* fft_part2,
+                                            const float* absorb_nabla1, const float* absorb_nabla2);
+/* sumPressureTermsNonlinear (.cuh:388-391, .cu:1865-1945); c2 / absorb_tau+absorb_eta NULL -> scalars */
+KW_API kw_status kw_sum_pressure_terms_nonlinear(kw_ctx* ctx, float* p, const float* nonlinear_term,
+                                                 const float* absorb_tau_term, const float* absorb_eta_term,
+                                                 const float* c2, const float* absorb_tau, const float* absorb_eta);
+/* sumPressureTermsLinear (.cuh:411-414, .cu:1966-2045) */
+KW_API kw_status kw_sum_pressure_terms_linear(kw_ctx* ctx, float* p, const float* absorb_tau_term,
+                                              const float* absorb_eta_term, const float* density_sum, const float* c2,
+                                              const float* absorb_tau, const float* absorb_eta);
+/* sumPressureNonlinearLossless (.cuh:429, .cu:2067-2200) */
+KW_API kw_status kw_sum_pressure_nonlinear_lossless(kw_ctx* ctx, float* p, const float* rho_x, const float* rho_y,
+                                                    const float* rho_z, const float* c2, const float* b_on_a,
+                                                    const float* rho0);
+/* sumPressureLinearLossless (.cuh:444, .cu:2224-2275) */
+KW_API kw_status kw_sum_pressure_linear_lossless(kw_ctx* ctx, float* p, const float* rho_x, const float* rho_y,
+                                                 const float* rho_z, const float* c2);
+/* computeVelocityShiftInX/Y/Z (.cuh:482-499, .cu:2617-2710); spectrum in the layout of kw_fft_r2c_1d(axis) */
+KW_API kw_status kw_compute_velocity_shift(kw_ctx* ctx, int axis, float* spectrum, const float* shift_neg_r);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * Sampling kernels — replace namespace OutputStreamsCudaKernels (OutputStreams/OutputStreamsCudaKernels.cuh:47-106)
+ * ---------------------------------------------------------------------------------------------------------------- */
+/* sampleIndex<op> (.cuh:58-62, .cu:83-126) */
+KW_API kw_status kw_sample_index(kw_ctx* ctx, kw_reduce_op op, float* sampling_buffer, const float* source_data,
+                                 const uint64_t* sensor_data, uint64_t n_samples);
+/* sampleCuboid<op> (.cuh:75-81, .cu:164-252): corners are 0-based inclusive (x,y,z), matrix_size = (nx,ny,nz) */
+KW_API kw_status kw_sample_cuboid(kw_ctx* ctx, kw_reduce_op op, float* sampling_buffer, const float* source_data,
+                                  const uint32_t top_left[3], const uint32_t bottom_right[3],
+                                  const uint32_t matrix_size[3], uint64_t n_samples);
+/* sampleAll<op> (.cuh:91-95, .cu:297-332) */
+KW_API kw_status kw_sample_all(kw_ctx* ctx, kw_reduce_op op, float* sampling_buffer, const float* source_data,
+                               uint64_t n_samples);
+/* postProcessingRms (.cuh:103-105, .cu:359-378) */
+KW_API kw_status kw_post_processing_rms(kw_ctx* ctx, float* sampling_buffer, float scaling_coeff, uint64_t n_samples);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* KWAVE_HIP_H */

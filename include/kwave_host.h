@@ -1,0 +1,71 @@
+/*
+ * kwave_host.h — C entry points of the C++ host layer (libkwave_host.so).
+ *
+ * The host layer is the MI355X build's mirror of the reference's caller side of the hot path:
+ * Parameters / MatrixContainer / KSpaceFirstOrderSolver / OutputStreamContainer (k-wave-fluid-cuda_amd/host/).
+ * These entry points exist so that non-C++ drivers (bench.py, pytest via ctypes) can run the *same* C++ time loop
+ * the command-line program runs — they correspond to main()'s sequence in the reference (main.cpp:840-966):
+ *   kwh_create   = Parameters::init + selectDevice + allocateMemory + loadInputData   (main.cpp:857-917)
+ *   kwh_run      = the body of computeMainLoop for n steps                            (KSpaceFirstOrderSolver.cpp:885-935)
+ *   kwh_finish   = last delayed flush + postProcessing                                (:937-942, :950-1053)
+ * Input datasets are named exactly like the HDF5 input file's datasets (Utils/MatrixNames.h, main.cpp:446-563).
+ */
+#ifndef KWAVE_HOST_H
+#define KWAVE_HOST_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define KWH_API __attribute__((visibility("default")))
+
+typedef struct kwh_solver kwh_solver;
+
+typedef struct kwh_dataset
+{
+  const char* name;     /* HDF5 dataset name, e.g. "c0", "ddx_k_shift_pos_r", "sensor_mask_index" */
+  const void* data;     /* host pointer: float32 or uint64 */
+  int32_t     dtype;    /* 0 = float ("float"), 1 = uint64 ("long") */
+  int32_t     pad_;
+  uint64_t    nx, ny, nz; /* (x,y,z) sizes = HDF5 dims reversed; complex datasets have the doubled x size halved here */
+} kwh_dataset;
+
+/* what the reference takes from the command line for the loop (CommandLineParameters.cpp:264-292) */
+typedef struct kwh_options
+{
+  int32_t  device_idx;                 /* -g ; <0 = first free */
+  int32_t  fused_kernels;              /* 1: MI355X fused step kernels, 0: one launch per reference kernel */
+  uint64_t sampling_start_time_index;  /* -s (0-based) */
+  uint64_t benchmark_time_steps;       /* --benchmark (0 = use Nt) */
+  int32_t  p_raw, p_rms, p_max, p_min, p_max_all, p_min_all, p_final;
+  int32_t  u_raw, u_rms, u_max, u_min, u_max_all, u_min_all, u_final, u_non_staggered_raw;
+  int32_t  p_c, u_non_staggered_c, i_avg_c, no_overlap;
+  float    period;
+  uint64_t mos, harmonics;
+} kwh_options;
+
+KWH_API const char* kwh_last_error(void);
+KWH_API int      kwh_create(const kwh_dataset* datasets, size_t n_datasets, const kwh_options* options, kwh_solver** out);
+KWH_API int      kwh_destroy(kwh_solver* s);
+KWH_API int      kwh_run(kwh_solver* s, uint64_t n_steps);
+KWH_API int      kwh_finish(kwh_solver* s);
+KWH_API int      kwh_sync(kwh_solver* s);
+KWH_API uint64_t kwh_time_index(const kwh_solver* s);
+/* the underlying kw_ctx* (include/kwave_hip.h) — for HIP-event timing on the solver's stream */
+KWH_API void*    kwh_context(kwh_solver* s);
+/* copy a matrix (by reference name: "p","ux_sgx","rhox","kappa_r","absorb_tau", "c0" (= c^2 after pre-processing) ...)
+ * from the device into dst; n = number of floats expected (checked) */
+KWH_API int      kwh_get_matrix(kwh_solver* s, const char* name, float* dst, uint64_t n);
+KWH_API int      kwh_matrix_size(kwh_solver* s, const char* name, uint64_t* n_floats);
+/* scalar parameters computed by pre-processing: "absorb_tau","absorb_eta","c2","dt_rho0_sgx",... */
+KWH_API int      kwh_get_scalar(kwh_solver* s, const char* name, float* out);
+/* output streams by dataset name ("p","p_max","ux",...): size = points per step, steps = stored steps (1 for aggregates) */
+KWH_API int      kwh_stream_info(kwh_solver* s, const char* name, uint64_t* size, uint64_t* steps);
+KWH_API int      kwh_stream_read(kwh_solver* s, const char* name, float* dst, uint64_t n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,265 @@
+// kw_context.hip — context, device selection, memory verbs, constants, events.
+// Replaces CudaParameters::selectDevice / setUpDeviceConstants (Parameters/CudaParameters.cpp:81-177,238-288),
+// CudaDeviceConstants::uploadDeviceConstants (Parameters/CudaDeviceConstants.cu:58-60) and the memory verbs of
+// MatrixClasses/BaseFloatMatrix.cpp:77-80,124-168.
+#include "kw_internal.h"
+
+static thread_local char g_err[1024] = "";
+
+void kw_set_error(const char* fmt, ...)
+{
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+extern "C" {
+
+const char* kw_last_error(void) { return g_err; }
+
+kw_status kw_init(int device_id, kw_ctx** out_ctx)
+{
+  if (out_ctx == nullptr) { kw_set_error("kw_init: out_ctx is NULL"); return KW_ERR_INVALID; }
+  *out_ctx = nullptr;
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
+  {
+    kw_set_error("kw_init: no HIP device found");
+    return KW_ERR_NO_DEVICE;
+  }
+  int dev = device_id;
+  if (dev < 0)
+  {
+    // first device that accepts a context (reference: first free device, CudaParameters.cpp:95-123)
+    dev = -1;
+    for (int i = 0; i < n; i++)
+    {
+      if (hipSetDevice(i) == hipSuccess && hipFree(nullptr) == hipSuccess) { dev = i; break; }
+    }
+    if (dev < 0) { kw_set_error("kw_init: no free HIP device"); return KW_ERR_NO_DEVICE; }
+  }
+  else if (dev >= n)
+  {
+    kw_set_error("kw_init: device %d out of range (have %d)", dev, n);
+    return KW_ERR_NO_DEVICE;
+  }
+  KW_HIP(hipSetDevice(dev));
+  hipDeviceProp_t prop;
+  KW_HIP(hipGetDeviceProperties(&prop, dev));
+  if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+  {
+    // the code objects in this library are gfx950-only; fail loudly instead of at the first launch
+    kw_set_error("kw_init: device %d is %s, this library is built for gfx950 (MI355X) only", dev, prop.gcnArchName);
+    return KW_ERR_NO_DEVICE;
+  }
+  kw_ctx* ctx   = new kw_ctx();
+  ctx->device   = dev;
+  ctx->cu_count = prop.multiProcessorCount;
+  hipError_t e  = hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking);
+  if (e != hipSuccess)
+  {
+    kw_set_error("GPU error: %s routine name: kw_init", hipGetErrorString(e));
+    delete ctx;
+    return KW_ERR_HIP;
+  }
+  ctx->stream = ctx->own_stream;
+  *out_ctx    = ctx;
+  return KW_OK;
+}
+
+kw_status kw_destroy(kw_ctx* ctx)
+{
+  if (ctx == nullptr) return KW_OK;
+  (void)hipSetDevice(ctx->device);
+  (void)hipStreamSynchronize(ctx->stream);
+  kw_fft_destroy_plans(ctx);
+  if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+  delete ctx;
+  return KW_OK;
+}
+
+kw_status kw_device_info_get(kw_ctx* ctx, kw_device_info* out)
+{
+  KW_CHECK_CTX(ctx);
+  KW_REQUIRE(out != nullptr);
+  hipDeviceProp_t prop;
+  KW_HIP(hipGetDeviceProperties(&prop, ctx->device));
+  memset(out, 0, sizeof(*out));
+  snprintf(out->name, sizeof(out->name), "%s", prop.name);
+  snprintf(out->arch, sizeof(out->arch), "%s", prop.gcnArchName);
+  out->device_id      = ctx->device;
+  out->compute_units  = prop.multiProcessorCount;
+  out->wavefront_size = prop.warpSize;
+  out->clock_mhz      = prop.clockRate / 1000;
+  out->total_mem      = prop.totalGlobalMem;
+  size_t fr = 0, tot = 0;
+  KW_HIP(hipMemGetInfo(&fr, &tot));
+  out->free_mem   = fr;
+  out->lds_per_cu = prop.maxSharedMemoryPerMultiProcessor;
+  out->l2_bytes   = (uint64_t)prop.l2CacheSize;
+  return KW_OK;
+}
+
+kw_status kw_set_stream(kw_ctx* ctx, void* hip_stream)
+{
+  KW_CHECK_CTX(ctx);
+  ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+  hipStream_t s = ctx->stream;
+  kw_fft_plan* plans[] = { &ctx->r2c_3d, &ctx->c2r_3d, &ctx->r2c_1d[0], &ctx->r2c_1d[1], &ctx->r2c_1d[2],
+                           &ctx->c2r_1d[0], &ctx->c2r_1d[1], &ctx->c2r_1d[2] };
+  for (kw_fft_plan* p : plans)
+    if (p->info && rocfft_execution_info_set_stream(p->info, s) != rocfft_status_success)
+    {
+      kw_set_error("kw_set_stream: rocfft_execution_info_set_stream failed");
+      return KW_ERR_FFT;
+    }
+  return KW_OK;
+}
+
+void* kw_get_stream(kw_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
+
+kw_status kw_sync(kw_ctx* ctx)
+{
+  KW_CHECK_CTX(ctx);
+  KW_HIP(hipStreamSynchronize(ctx->stream));
+  return KW_OK;
+}
+
+kw_status kw_event_create(kw_ctx* ctx, void** out_event)
+{
+  KW_CHECK_CTX(ctx);
+  KW_REQUIRE(out_event != nullptr);
+  hipEvent_t ev;
+  KW_HIP(hipEventCreate(&ev));
+  *out_event = (void*)ev;
+  return KW_OK;
+}
+kw_status kw_event_record(kw_ctx* ctx, void* event)
+{
+  KW_CHECK_CTX(ctx);
+  KW_HIP(hipEventRecord((hipEvent_t)event, ctx->stream));
+  return KW_OK;
+}
+kw_status kw_event_synchronize(kw_ctx* ctx, void* event)
+{
+  KW_CHECK_CTX(ctx);
+  KW_HIP(hipEventSynchronize((hipEvent_t)event));
+  return KW_OK;
+}
+kw_status kw_event_elapsed_ms(kw_ctx* ctx, void* start, void* stop, float* out_ms)
+{
+  KW_CHECK_CTX(ctx);
+  KW_REQUIRE(out_ms != nullptr);
+  KW_HIP(hipEventElapsedTime(out_ms, (hipEvent_t)start, (hipEvent_t)stop));
+  return KW_OK;
+}
+kw_status kw_event_destroy(kw_ctx* ctx, void* event)
+{
+  KW_CHECK_CTX(ctx);
+  KW_HIP(hipEventDestroy((hipEvent_t)event));
+  return KW_OK;
+}
+
+// ---- memory --------------------------------------------------------------------------------------------------------
+kw_status kw_malloc(kw_ctx* ctx, size_t bytes, void** out_dptr)
+{
+  KW_CHECK_CTX(ctx);
+  KW_REQUIRE(out_dptr != nullptr);
+  *out_dptr = nullptr;
+  if (bytes == 0) return KW_OK;
+  KW_HIP(hipSetDevice(ctx->device));
+  KW_HIP(hipMalloc(out_dptr, bytes));
+  return KW_OK;
+}
+kw_status kw_free(kw_ctx* ctx, void* dptr)
+{
+  KW_CHECK_CTX(ctx);
+  if (dptr == nullptr) return KW_OK;
+  KW_HIP(hipFree(dptr));
+  return KW_OK;
+}
+kw_status kw_memcpy_h2d(kw_ctx* ctx, void* dst, const void* src, size_t bytes)
+{
+  KW_CHECK_CTX(ctx);
+  if (bytes == 0) return KW_OK;
+  KW_REQUIRE(dst != nullptr && src != nullptr);
+  KW_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+  KW_HIP(hipStreamSynchronize(ctx->stream)); // blocking like cudaMemcpy in BaseFloatMatrix::copyToDevice
+  return KW_OK;
+}
+kw_status kw_memcpy_d2h(kw_ctx* ctx, void* dst, const void* src, size_t bytes)
+{
+  KW_CHECK_CTX(ctx);
+  if (bytes == 0) return KW_OK;
+  KW_REQUIRE(dst != nullptr && src != nullptr);
+  KW_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+  KW_HIP(hipStreamSynchronize(ctx->stream));
+  return KW_OK;
+}
+kw_status kw_memcpy_d2h_async(kw_ctx* ctx, void* dst, const void* src, size_t bytes)
+{
+  KW_CHECK_CTX(ctx);
+  if (bytes == 0) return KW_OK;
+  KW_REQUIRE(dst != nullptr && src != nullptr);
+  KW_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+  return KW_OK;
+}
+kw_status kw_memcpy_d2d(kw_ctx* ctx, void* dst, const void* src, size_t bytes)
+{
+  KW_CHECK_CTX(ctx);
+  if (bytes == 0) return KW_OK;
+  KW_REQUIRE(dst != nullptr && src != nullptr);
+  KW_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+  return KW_OK;
+}
+kw_status kw_memset(kw_ctx* ctx, void* dptr, int value, size_t bytes)
+{
+  KW_CHECK_CTX(ctx);
+  if (bytes == 0) return KW_OK;
+  KW_REQUIRE(dptr != nullptr);
+  KW_HIP(hipMemsetAsync(dptr, value, bytes, ctx->stream));
+  return KW_OK;
+}
+kw_status kw_host_alloc(kw_ctx* ctx, size_t bytes, void** out_hptr)
+{
+  KW_CHECK_CTX(ctx);
+  KW_REQUIRE(out_hptr != nullptr);
+  *out_hptr = nullptr;
+  if (bytes == 0) return KW_OK;
+  KW_HIP(hipHostMalloc(out_hptr, bytes, hipHostMallocDefault));
+  return KW_OK;
+}
+kw_status kw_host_free(kw_ctx* ctx, void* hptr)
+{
+  KW_CHECK_CTX(ctx);
+  if (hptr == nullptr) return KW_OK;
+  KW_HIP(hipHostFree(hptr));
+  return KW_OK;
+}
+
+// ---- constants -----------------------------------------------------------------------------------------------------
+kw_status kw_set_constants(kw_ctx* ctx, const kw_constants* k)
+{
+  KW_CHECK_CTX(ctx);
+  KW_REQUIRE(k != nullptr);
+  KW_REQUIRE(k->nx >= 1 && k->ny >= 1 && k->nz >= 1);
+  KW_REQUIRE((uint64_t)k->nx * k->ny * k->nz == (uint64_t)k->n_elements);
+  KW_REQUIRE(k->nx_complex == k->nx / 2 + 1 && k->ny_complex == k->ny && k->nz_complex == k->nz);
+  KW_REQUIRE((uint64_t)k->nx_complex * k->ny * k->nz == (uint64_t)k->n_elements_complex);
+  KW_REQUIRE(k->velocity_source_mode <= 2 && k->pressure_source_mode <= 2);
+  const bool dims_changed = ctx->have_consts && (ctx->c.nx != k->nx || ctx->c.ny != k->ny || ctx->c.nz != k->nz);
+  if (dims_changed) kw_fft_destroy_plans(ctx);
+  ctx->c           = *k;
+  ctx->have_consts = true;
+  return KW_OK;
+}
+kw_status kw_get_constants(kw_ctx* ctx, kw_constants* out)
+{
+  KW_CHECK_CONSTS(ctx);
+  KW_REQUIRE(out != nullptr);
+  *out = ctx->c;
+  return KW_OK;
+}
+
+} // extern "C"

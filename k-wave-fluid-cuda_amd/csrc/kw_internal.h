@@ -1,0 +1,70 @@
+// kw_internal.h — shared internals of libkwave_hip.so (not part of the public C-ABI).
+#ifndef KW_INTERNAL_H
+#define KW_INTERNAL_H
+
+#include <hip/hip_runtime.h>
+#include <rocfft/rocfft.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+
+#include "kwave_hip.h"
+
+struct kw_fft_plan
+{
+  rocfft_plan           plan  = nullptr;
+  rocfft_execution_info info  = nullptr;
+  size_t                work  = 0;
+};
+
+struct kw_ctx
+{
+  int          device      = 0;
+  hipStream_t  own_stream  = nullptr;
+  hipStream_t  stream      = nullptr; // stream every launch goes to
+  bool         have_consts = false;
+  kw_constants c{};
+  int          cu_count    = 256;
+  // rocFFT
+  bool         fft_setup   = false;
+  kw_fft_plan  r2c_3d, c2r_3d;
+  kw_fft_plan  r2c_1d[3], c2r_1d[3];
+  void*        fft_work       = nullptr; // one shared work buffer, sized for the largest plan
+  size_t       fft_work_bytes = 0;
+};
+
+// thread-local error text (kw_last_error)
+void kw_set_error(const char* fmt, ...) __attribute__((format(printf, 1, 2)));
+
+#define KW_CHECK_CTX(ctx)                                                                                              \
+  do {                                                                                                                 \
+    if ((ctx) == nullptr) { kw_set_error("%s: ctx is NULL", __func__); return KW_ERR_INVALID; }                       \
+  } while (0)
+
+#define KW_CHECK_CONSTS(ctx)                                                                                           \
+  do {                                                                                                                 \
+    KW_CHECK_CTX(ctx);                                                                                                 \
+    if (!(ctx)->have_consts) { kw_set_error("%s: kw_set_constants has not been called", __func__); return KW_ERR_STATE; } \
+  } while (0)
+
+#define KW_REQUIRE(cond)                                                                                               \
+  do {                                                                                                                 \
+    if (!(cond)) { kw_set_error("%s: invalid argument: %s", __func__, #cond); return KW_ERR_INVALID; }                \
+  } while (0)
+
+// "GPU error: %s routine name: %s in file %s, line %d." — message shape of the reference (ErrorMessages.h:331)
+#define KW_HIP(call)                                                                                                   \
+  do {                                                                                                                 \
+    hipError_t e_ = (call);                                                                                            \
+    if (e_ != hipSuccess) {                                                                                            \
+      kw_set_error("GPU error: %s routine name: %s in file %s, line %d.", hipGetErrorString(e_), __func__, __FILE__,  \
+                   __LINE__);                                                                                          \
+      return (e_ == hipErrorOutOfMemory) ? KW_ERR_ALLOC : KW_ERR_HIP;                                                  \
+    }                                                                                                                  \
+  } while (0)
+
+// checked right after each launch, without synchronising (reference: cudaCheckErrors(cudaGetLastError()))
+#define KW_LAUNCH_CHECK() KW_HIP(hipGetLastError())
+
+#endif

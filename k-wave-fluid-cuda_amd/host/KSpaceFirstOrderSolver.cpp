@@ -1,0 +1,460 @@
+// KSpaceFirstOrderSolver.cpp — see KSpaceFirstOrderSolver.h.  Sequencing follows
+// KSpaceSolver/KSpaceFirstOrderSolver.cpp:864-943 (loop), :2087-2396 (step pieces), :2404-2703 (generators).
+#include "KSpaceFirstOrderSolver.h"
+
+#include <cmath>
+#include <limits>
+
+#include "HipError.h"
+#include "SolverHipKernels.h"
+
+using SD = Parameters::SimulationDimension;
+using MI = MatrixContainer::MatrixIdx;
+
+KSpaceFirstOrderSolver::KSpaceFirstOrderSolver() : mParameters(Parameters::getInstance()) {}
+KSpaceFirstOrderSolver::~KSpaceFirstOrderSolver() { freeMemory(); }
+
+void KSpaceFirstOrderSolver::allocateMemory()
+{
+  mMatrixContainer.init();
+  mMatrixContainer.createMatrices();
+  mOutputStreamContainer.init(mMatrixContainer);
+}
+
+void KSpaceFirstOrderSolver::freeMemory()
+{
+  mOutputStreamContainer.freeStreams();
+  mMatrixContainer.freeMatrices();
+  HipFftComplexMatrix::destroyAllPlansAndStaticData();
+  mPrepared = false;
+}
+
+void KSpaceFirstOrderSolver::loadInputData(const InputProvider& input)
+{
+  mMatrixContainer.loadDataFromInputFile(input);
+  mOutputStreamContainer.createStreams();
+}
+
+void KSpaceFirstOrderSolver::initializeFftPlans()
+{ // KSpaceFirstOrderSolver.cpp:747-777
+  const DimensionSizes dims = mParameters.getFullDimensionSizes();
+  HipFftComplexMatrix::createR2CFftPlanND(dims);
+  HipFftComplexMatrix::createC2RFftPlanND(dims);
+  if (mParameters.needsShiftedVelocity())
+  {
+    HipFftComplexMatrix::createR2CFftPlan1DX(dims);
+    HipFftComplexMatrix::createR2CFftPlan1DY(dims);
+    HipFftComplexMatrix::createR2CFftPlan1DZ(dims);
+  }
+}
+
+void KSpaceFirstOrderSolver::prepare()
+{
+  if (mPrepared) return;
+  mParameters.getHipParameters().setUpDeviceConstants(); // dims first: plans need them
+  initializeFftPlans();
+  preProcessing<SD::k3D>();
+  mParameters.getHipParameters().setKernelConfiguration();
+  mParameters.getHipParameters().setUpDeviceConstants(); // again: tau/eta scalars exist only after preProcessing
+  mMatrixContainer.copyMatricesToDevice();               // KSpaceFirstOrderSolver.cpp:880
+  // host twins of the big arrays are not needed during the loop
+  for (auto& rec : mMatrixContainer.records())
+    if (rec.second.matrixType != MatrixRecord::MatrixType::kIndex)
+      static_cast<BaseFloatMatrix*>(rec.second.matrixPtr)->freeHostData();
+  mPrepared = true;
+}
+
+void KSpaceFirstOrderSolver::compute()
+{
+  prepare();
+  computeMainLoop<SD::k3D>();
+  postProcessing<SD::k3D>();
+}
+
+void KSpaceFirstOrderSolver::finish()
+{
+  if (mParameters.getTimeIndex() > mParameters.getSamplingStartTimeIndex()) mOutputStreamContainer.flushRawStreams();
+  postProcessing<SD::k3D>();
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+template<SD sd> void KSpaceFirstOrderSolver::preProcessing()
+{ // KSpaceFirstOrderSolver.cpp:784-857
+  if (mMatrixContainer.has(MI::kSensorMaskIndex)) index(MI::kSensorMaskIndex).recomputeIndicesToCPP();
+  if (mMatrixContainer.has(MI::kSensorMaskCorners)) index(MI::kSensorMaskCorners).recomputeIndicesToCPP();
+  if ((mParameters.getTransducerSourceFlag() != 0) || (mParameters.getVelocityXSourceFlag() != 0) ||
+      (mParameters.getVelocityYSourceFlag() != 0) || (mParameters.getVelocityZSourceFlag() != 0))
+    index(MI::kVelocitySourceIndex).recomputeIndicesToCPP();
+  if (mParameters.getTransducerSourceFlag() != 0) index(MI::kDelayMask).recomputeIndicesToCPP();
+  if (mParameters.getPressureSourceFlag() != 0) index(MI::kPressureSourceIndex).recomputeIndicesToCPP();
+
+  if (!mParameters.getRho0ScalarFlag())
+  {
+    real(MI::kDtRho0Sgx).scalarDividedBy(mParameters.getDt());
+    real(MI::kDtRho0Sgy).scalarDividedBy(mParameters.getDt());
+    real(MI::kDtRho0Sgz).scalarDividedBy(mParameters.getDt());
+  }
+  if (mParameters.getAbsorbingFlag() != 0)
+  {
+    generateKappaAndNablas();
+    generateTauAndEta();
+  }
+  else
+  {
+    generateKappa();
+  }
+  if (mMatrixContainer.has(MI::kSourceKappa)) generateSourceKappa();
+  computeC2();
+}
+
+template<SD sd> void KSpaceFirstOrderSolver::computeMainLoop()
+{ // KSpaceFirstOrderSolver.cpp:864-943
+  runTimeSteps(mParameters.getNt() - mParameters.getTimeIndex());
+  if (mParameters.getTimeIndex() > mParameters.getSamplingStartTimeIndex()) mOutputStreamContainer.flushRawStreams();
+}
+
+void KSpaceFirstOrderSolver::runTimeSteps(size_t nSteps)
+{
+  prepare();
+  for (size_t s = 0; s < nSteps && mParameters.getTimeIndex() < mParameters.getNt(); s++)
+  {
+    const size_t timeIndex = mParameters.getTimeIndex();
+    computeVelocity<SD::k3D>();
+    addVelocitySource();
+    if (mParameters.getTransducerSourceFlag() > timeIndex) SolverHipKernels::addTransducerSource(mMatrixContainer);
+    computeVelocityGradient<SD::k3D>();
+    if (mParameters.getNonLinearFlag()) computeDensityNonliner<SD::k3D>();
+    else computeDensityLinear<SD::k3D>();
+    addPressureSource<SD::k3D>();
+    if (mParameters.getNonLinearFlag()) computePressureNonlinear<SD::k3D>();
+    else computePressureLinear<SD::k3D>();
+    if ((timeIndex == 0) && (mParameters.getInitialPressureSourceFlag() == 1)) addInitialPressureSource<SD::k3D>();
+    storeSensorData();
+    mParameters.incrementTimeIndex();
+  }
+}
+
+template<SD sd> void KSpaceFirstOrderSolver::postProcessing()
+{ // KSpaceFirstOrderSolver.cpp:950-1053 (streams part); p_final/u_final stay on the device until asked for
+  mOutputStreamContainer.postProcessStreams();
+  mOutputStreamContainer.closeStreams();
+}
+
+void KSpaceFirstOrderSolver::storeSensorData()
+{ // KSpaceFirstOrderSolver.cpp:1060-1093
+  if (mOutputStreamContainer.empty()) return;
+  if (mParameters.getTimeIndex() >= mParameters.getSamplingStartTimeIndex())
+  {
+    if (mParameters.getTimeIndex() > mParameters.getSamplingStartTimeIndex()) mOutputStreamContainer.flushRawStreams();
+    if (mParameters.needsShiftedVelocity()) computeShiftedVelocity<SD::k3D>();
+    mOutputStreamContainer.sampleStreams();
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+template<SD sd> void KSpaceFirstOrderSolver::computeVelocity()
+{ // :2087-2119
+  getTempHipFftX().computeR2CFftND(getP());
+  SolverHipKernels::computePressureGradient<sd>(mMatrixContainer);
+  getTempHipFftX().computeC2RFftND(getTemp1RealND());
+  getTempHipFftY().computeC2RFftND(getTemp2RealND());
+  getTempHipFftZ().computeC2RFftND(getTemp3RealND());
+  if (mParameters.getRho0ScalarFlag()) SolverHipKernels::computeVelocityHomogeneousUniform<sd>(mMatrixContainer);
+  else SolverHipKernels::computeVelocityHeterogeneous<sd>(mMatrixContainer);
+}
+
+template<SD sd> void KSpaceFirstOrderSolver::computeVelocityGradient()
+{ // :2126-2150
+  getTempHipFftX().computeR2CFftND(real(MI::kUxSgx));
+  getTempHipFftY().computeR2CFftND(real(MI::kUySgy));
+  getTempHipFftZ().computeR2CFftND(real(MI::kUzSgz));
+  SolverHipKernels::computeVelocityGradient<sd>(mMatrixContainer);
+  getTempHipFftX().computeC2RFftND(real(MI::kDuxdx));
+  getTempHipFftY().computeC2RFftND(real(MI::kDuydy));
+  getTempHipFftZ().computeC2RFftND(real(MI::kDuzdz));
+}
+
+template<SD sd> void KSpaceFirstOrderSolver::computeDensityNonliner() { SolverHipKernels::computeDensityNonlinear<sd>(mMatrixContainer); }
+template<SD sd> void KSpaceFirstOrderSolver::computeDensityLinear() { SolverHipKernels::computeDensityLinear<sd>(mMatrixContainer); }
+
+template<SD sd> void KSpaceFirstOrderSolver::computePressureNonlinear()
+{ // :2180-2210
+  if (mParameters.getAbsorbingFlag())
+  {
+    RealMatrix& densitySum          = getTemp1RealND();
+    RealMatrix& nonlinearTerm       = getTemp2RealND();
+    RealMatrix& velocityGradientSum = getTemp3RealND();
+    RealMatrix& absorbTauTerm       = velocityGradientSum;
+    RealMatrix& absorbEtaTerm       = densitySum;
+    SolverHipKernels::computePressureTermsNonlinear<sd>(densitySum, nonlinearTerm, velocityGradientSum, mMatrixContainer);
+    getTempHipFftX().computeR2CFftND(velocityGradientSum);
+    getTempHipFftY().computeR2CFftND(densitySum);
+    SolverHipKernels::computeAbsorbtionTerm(getTempHipFftX(), getTempHipFftY(), real(MI::kAbsorbNabla1), real(MI::kAbsorbNabla2));
+    getTempHipFftX().computeC2RFftND(absorbTauTerm);
+    getTempHipFftY().computeC2RFftND(absorbEtaTerm);
+    SolverHipKernels::sumPressureTermsNonlinear(nonlinearTerm, absorbTauTerm, absorbEtaTerm, mMatrixContainer);
+  }
+  else
+  {
+    SolverHipKernels::sumPressureNonlinearLossless<sd>(mMatrixContainer);
+  }
+}
+
+template<SD sd> void KSpaceFirstOrderSolver::computePressureLinear()
+{ // :2217-2245
+  if (mParameters.getAbsorbingFlag())
+  {
+    RealMatrix& densitySum           = getTemp1RealND();
+    RealMatrix& velocityGradientTerm = getTemp2RealND();
+    RealMatrix& absorbTauTerm        = getTemp2RealND();
+    RealMatrix& absorbEtaTerm        = getTemp3RealND();
+    SolverHipKernels::computePressureTermsLinear<sd>(densitySum, velocityGradientTerm, mMatrixContainer);
+    getTempHipFftX().computeR2CFftND(velocityGradientTerm);
+    getTempHipFftY().computeR2CFftND(densitySum);
+    SolverHipKernels::computeAbsorbtionTerm(getTempHipFftX(), getTempHipFftY(), real(MI::kAbsorbNabla1), real(MI::kAbsorbNabla2));
+    getTempHipFftX().computeC2RFftND(absorbTauTerm);
+    getTempHipFftY().computeC2RFftND(absorbEtaTerm);
+    SolverHipKernels::sumPressureTermsLinear(absorbTauTerm, absorbEtaTerm, densitySum, mMatrixContainer);
+  }
+  else
+  {
+    SolverHipKernels::sumPressureLinearLossless<sd>(mMatrixContainer);
+  }
+}
+
+void KSpaceFirstOrderSolver::addVelocitySource()
+{ // :2252-2303
+  const size_t timeIndex = mParameters.getTimeIndex();
+  struct Comp { size_t flag; MI u; MI input; };
+  const Comp comps[3] = {{mParameters.getVelocityXSourceFlag(), MI::kUxSgx, MI::kVelocityXSourceInput},
+                         {mParameters.getVelocityYSourceFlag(), MI::kUySgy, MI::kVelocityYSourceInput},
+                         {mParameters.getVelocityZSourceFlag(), MI::kUzSgz, MI::kVelocityZSourceInput}};
+  for (const Comp& c : comps)
+  {
+    if (!(c.flag > timeIndex)) continue;
+    if (mParameters.getVelocitySourceMode() != Parameters::SourceMode::kAdditive)
+    {
+      SolverHipKernels::addVelocitySource(real(c.u), real(c.input), index(MI::kVelocitySourceIndex));
+    }
+    else
+    {
+      RealMatrix& scaledSource = getTemp1RealND();
+      scaleSource(scaledSource, real(c.input), index(MI::kVelocitySourceIndex), mParameters.getVelocitySourceMany());
+      SolverHipKernels::addVelocityScaledSource(real(c.u), scaledSource);
+    }
+  }
+}
+
+template<SD sd> void KSpaceFirstOrderSolver::addPressureSource()
+{ // :2310-2332
+  if (mParameters.getPressureSourceFlag() > mParameters.getTimeIndex())
+  {
+    if (mParameters.getPressureSourceMode() != Parameters::SourceMode::kAdditive)
+    {
+      SolverHipKernels::addPressureSource<sd>(mMatrixContainer);
+    }
+    else
+    {
+      RealMatrix& scaledSource = getTemp1RealND();
+      scaleSource(scaledSource, real(MI::kPressureSourceInput), index(MI::kPressureSourceIndex), mParameters.getPressureSourceMany());
+      SolverHipKernels::addPressureScaledSource<sd>(mMatrixContainer, scaledSource);
+    }
+  }
+}
+
+void KSpaceFirstOrderSolver::scaleSource(RealMatrix& scaledSource, const RealMatrix& sourceInput,
+                                         const IndexMatrix& sourceIndex, const size_t manyFlag)
+{ // :2339-2352
+  scaledSource.zeroDeviceMatrix();
+  SolverHipKernels::insertSourceIntoScalingMatrix(scaledSource, sourceInput, sourceIndex, manyFlag);
+  getTempHipFftX().computeR2CFftND(scaledSource);
+  SolverHipKernels::computeSourceGradient(getTempHipFftX(), real(MI::kSourceKappa));
+  getTempHipFftX().computeC2RFftND(scaledSource);
+}
+
+template<SD sd> void KSpaceFirstOrderSolver::addInitialPressureSource()
+{ // :2359-2396
+  SolverHipKernels::addInitialPressureSource<sd>(mMatrixContainer);
+  getTempHipFftX().computeR2CFftND(getP());
+  SolverHipKernels::computePressureGradient<sd>(mMatrixContainer);
+  getTempHipFftX().computeC2RFftND(real(MI::kUxSgx));
+  getTempHipFftY().computeC2RFftND(real(MI::kUySgy));
+  getTempHipFftZ().computeC2RFftND(real(MI::kUzSgz));
+  if (mParameters.getRho0ScalarFlag()) SolverHipKernels::computeInitialVelocityHomogeneousUniform<sd>(mMatrixContainer);
+  else SolverHipKernels::computeInitialVelocityHeterogeneous<sd>(mMatrixContainer);
+}
+
+template<SD sd> void KSpaceFirstOrderSolver::computeShiftedVelocity()
+{ // :2714-2735
+  HipFftComplexMatrix& tempShift = fft(MI::kTempHipFftShift);
+  tempShift.computeR2CFft1DX(real(MI::kUxSgx));
+  SolverHipKernels::computeVelocityShiftInX(tempShift, mMatrixContainer.getMatrix<ComplexMatrix>(MI::kXShiftNegR));
+  tempShift.computeC2RFft1DX(real(MI::kUxShifted));
+  tempShift.computeR2CFft1DY(real(MI::kUySgy));
+  SolverHipKernels::computeVelocityShiftInY(tempShift, mMatrixContainer.getMatrix<ComplexMatrix>(MI::kYShiftNegR));
+  tempShift.computeC2RFft1DY(real(MI::kUyShifted));
+  tempShift.computeR2CFft1DZ(real(MI::kUzSgz));
+  SolverHipKernels::computeVelocityShiftInZ(tempShift, mMatrixContainer.getMatrix<ComplexMatrix>(MI::kZShiftNegR));
+  tempShift.computeC2RFft1DZ(real(MI::kUzShifted));
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Host generators: same fp32 formula order as the reference (the operators are computed, not read from the file)
+// ---------------------------------------------------------------------------------------------------------------------
+void KSpaceFirstOrderSolver::generateKappa()
+{ // :2404-2452
+  const float dx2Rec = 1.0f / (mParameters.getDx() * mParameters.getDx());
+  const float dy2Rec = 1.0f / (mParameters.getDy() * mParameters.getDy());
+  const float dz2Rec = 1.0f / (mParameters.getDz() * mParameters.getDz());
+  const float cRefDtPi = mParameters.getCRef() * mParameters.getDt() * static_cast<float>(M_PI);
+  const DimensionSizes full = mParameters.getFullDimensionSizes(), red = mParameters.getReducedDimensionSizes();
+  const float nxRec = 1.0f / static_cast<float>(full.nx);
+  const float nyRec = 1.0f / static_cast<float>(full.ny);
+  const float nzRec = 1.0f / static_cast<float>(full.nz);
+  float* kappa = real(MI::kKappa).getHostData();
+#pragma omp parallel for schedule(static)
+  for (size_t z = 0; z < red.nz; z++)
+  {
+    const float zf = static_cast<float>(z);
+    float zPart    = 0.5f - std::fabs(0.5f - zf * nzRec);
+    zPart          = (zPart * zPart) * dz2Rec;
+    for (size_t y = 0; y < red.ny; y++)
+    {
+      const float yf = static_cast<float>(y);
+      float yPart    = 0.5f - std::fabs(0.5f - yf * nyRec);
+      yPart          = (yPart * yPart) * dy2Rec;
+      const float yzPart = zPart + yPart;
+      for (size_t x = 0; x < red.nx; x++)
+      {
+        const float xf = static_cast<float>(x);
+        float xPart    = 0.5f - std::fabs(0.5f - xf * nxRec);
+        xPart          = (xPart * xPart) * dx2Rec;
+        const float k  = cRefDtPi * std::sqrt(xPart + yzPart);
+        kappa[(z * red.ny + y) * red.nx + x] = (k == 0.0f) ? 1.0f : std::sin(k) / k;
+      }
+    }
+  }
+}
+
+void KSpaceFirstOrderSolver::generateSourceKappa()
+{ // :2460-2506
+  const float dx2Rec = 1.0f / (mParameters.getDx() * mParameters.getDx());
+  const float dy2Rec = 1.0f / (mParameters.getDy() * mParameters.getDy());
+  const float dz2Rec = 1.0f / (mParameters.getDz() * mParameters.getDz());
+  const float cRefDtPi = mParameters.getCRef() * mParameters.getDt() * static_cast<float>(M_PI);
+  const DimensionSizes full = mParameters.getFullDimensionSizes(), red = mParameters.getReducedDimensionSizes();
+  const float nxRec = 1.0f / static_cast<float>(full.nx);
+  const float nyRec = 1.0f / static_cast<float>(full.ny);
+  const float nzRec = 1.0f / static_cast<float>(full.nz);
+  float* sourceKappa = real(MI::kSourceKappa).getHostData();
+#pragma omp parallel for schedule(static)
+  for (size_t z = 0; z < red.nz; z++)
+  {
+    const float zf = static_cast<float>(z);
+    float zPart    = 0.5f - std::fabs(0.5f - zf * nzRec);
+    zPart          = (zPart * zPart) * dz2Rec;
+    for (size_t y = 0; y < red.ny; y++)
+    {
+      const float yf = static_cast<float>(y);
+      float yPart    = 0.5f - std::fabs(0.5f - yf * nyRec);
+      yPart          = (yPart * yPart) * dy2Rec;
+      const float yzPart = zPart + yPart;
+      for (size_t x = 0; x < red.nx; x++)
+      {
+        const float xf = static_cast<float>(x);
+        float xPart    = 0.5f - std::fabs(0.5f - xf * nxRec);
+        xPart          = (xPart * xPart) * dx2Rec;
+        const float k  = cRefDtPi * std::sqrt(xPart + yzPart);
+        sourceKappa[(z * red.ny + y) * red.nx + x] = std::cos(k);
+      }
+    }
+  }
+}
+
+void KSpaceFirstOrderSolver::generateKappaAndNablas()
+{ // :2514-2577
+  const float dxSqRec = 1.0f / (mParameters.getDx() * mParameters.getDx());
+  const float dySqRec = 1.0f / (mParameters.getDy() * mParameters.getDy());
+  const float dzSqRec = 1.0f / (mParameters.getDz() * mParameters.getDz());
+  const float cRefDt2 = mParameters.getCRef() * mParameters.getDt() * 0.5f;
+  const float pi2     = static_cast<float>(M_PI) * 2.0f;
+  const DimensionSizes full = mParameters.getFullDimensionSizes(), red = mParameters.getReducedDimensionSizes();
+  const float nxRec = 1.0f / static_cast<float>(full.nx);
+  const float nyRec = 1.0f / static_cast<float>(full.ny);
+  const float nzRec = 1.0f / static_cast<float>(full.nz);
+  float* kappa        = real(MI::kKappa).getHostData();
+  float* absorbNabla1 = real(MI::kAbsorbNabla1).getHostData();
+  float* absorbNabla2 = real(MI::kAbsorbNabla2).getHostData();
+  const float alphaPower = mParameters.getAlphaPower();
+#pragma omp parallel for schedule(static)
+  for (size_t z = 0; z < red.nz; z++)
+  {
+    const float zf = static_cast<float>(z);
+    float zPart    = 0.5f - std::fabs(0.5f - zf * nzRec);
+    zPart          = (zPart * zPart) * dzSqRec;
+    for (size_t y = 0; y < red.ny; y++)
+    {
+      const float yf = static_cast<float>(y);
+      float yPart    = 0.5f - std::fabs(0.5f - yf * nyRec);
+      yPart          = (yPart * yPart) * dySqRec;
+      const float yzPart = zPart + yPart;
+      for (size_t x = 0; x < red.nx; x++)
+      {
+        const float xf = static_cast<float>(x);
+        float xPart    = 0.5f - std::fabs(0.5f - xf * nxRec);
+        xPart          = (xPart * xPart) * dxSqRec;
+        const float k     = pi2 * std::sqrt(xPart + yzPart);
+        const float cRefK = cRefDt2 * k;
+        const size_t i    = (z * red.ny + y) * red.nx + x;
+        kappa[i]          = (cRefK == 0.0f) ? 1.0f : std::sin(cRefK) / cRefK;
+        absorbNabla1[i]   = std::pow(k, alphaPower - 2.0f);
+        absorbNabla2[i]   = std::pow(k, alphaPower - 1.0f);
+        if (absorbNabla1[i] == std::numeric_limits<float>::infinity()) absorbNabla1[i] = 0.0f;
+        if (absorbNabla2[i] == std::numeric_limits<float>::infinity()) absorbNabla2[i] = 0.0f;
+      }
+    }
+  }
+}
+
+void KSpaceFirstOrderSolver::generateTauAndEta()
+{ // :2584-2643
+  const float alphaPower       = mParameters.getAlphaPower();
+  const float tanPi2AlphaPower = std::tan(static_cast<float>(M_PI_2) * alphaPower);
+  const float alphaNeperCoeff =
+    (100.0f * std::pow(1.0e-6f / (2.0f * static_cast<float>(M_PI)), alphaPower)) / (20.0f * static_cast<float>(M_LOG10E));
+  if ((mParameters.getAlphaCoeffScalarFlag()) && (mParameters.getC0ScalarFlag()))
+  {
+    const float alphaCoeff2 = 2.0f * mParameters.getAlphaCoeffScalar() * alphaNeperCoeff;
+    mParameters.setAbsorbTauScalar((-alphaCoeff2) * std::pow(mParameters.getC0Scalar(), alphaPower - 1));
+    mParameters.setAbsorbEtaScalar(alphaCoeff2 * std::pow(mParameters.getC0Scalar(), alphaPower) * tanPi2AlphaPower);
+    return;
+  }
+  float* absorbTau = real(MI::kAbsorbTau).getHostData();
+  float* absorbEta = real(MI::kAbsorbEta).getHostData();
+  const bool   alphaCoeffScalarFlag = mParameters.getAlphaCoeffScalarFlag();
+  const float  alphaCoeffScalar     = alphaCoeffScalarFlag ? mParameters.getAlphaCoeffScalar() : 0.0f;
+  const float* alphaCoeffMatrix     = alphaCoeffScalarFlag ? nullptr : getTemp1RealND().getHostData();
+  const bool   c0ScalarFlag         = mParameters.getC0ScalarFlag();
+  const float  c0Scalar             = c0ScalarFlag ? mParameters.getC0Scalar() : 0.0f;
+  const float* c0Matrix             = c0ScalarFlag ? nullptr : real(MI::kC2).getHostData(); // still holds c0 (:2612)
+  const size_t n = mParameters.getFullDimensionSizes().nElements();
+#pragma omp parallel for schedule(static)
+  for (size_t i = 0; i < n; i++)
+  {
+    const float alphaCoeff2 = 2.0f * alphaNeperCoeff * (alphaCoeffScalarFlag ? alphaCoeffScalar : alphaCoeffMatrix[i]);
+    const float c0          = c0ScalarFlag ? c0Scalar : c0Matrix[i];
+    absorbTau[i] = (-alphaCoeff2) * std::pow(c0, alphaPower - 1.0f);
+    absorbEta[i] = alphaCoeff2 * std::pow(c0, alphaPower) * tanPi2AlphaPower;
+  }
+}
+
+void KSpaceFirstOrderSolver::computeC2()
+{ // :2690-2703
+  if (!mParameters.getC0ScalarFlag())
+  {
+    float*       c2   = real(MI::kC2).getHostData();
+    const size_t size = real(MI::kC2).size();
+#pragma omp parallel for schedule(static)
+    for (size_t i = 0; i < size; i++) c2[i] = c2[i] * c2[i];
+  }
+}

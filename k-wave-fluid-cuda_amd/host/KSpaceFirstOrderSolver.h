@@ -1,0 +1,82 @@
+// KSpaceFirstOrderSolver.h — orchestrator of the k-space first-order time loop on MI355X.
+// Mirror of KSpaceSolver/KSpaceFirstOrderSolver.{h,cpp} for the per-step path and the generators it needs
+// (SURVEY.md §8 a1-a9, a12): allocateMemory (:124-141), loadInputData (:159-261), compute (:268-439) =
+// initializeFftPlans (:747-777) + preProcessing (:784-857) + computeMainLoop (:864-943) + postProcessing (:950-1053),
+// the step pieces (:2087-2396, :2714-2735) and the host generators (:2404-2703).
+// Same method names; the device work goes through namespace SolverHipKernels / HipFftComplexMatrix /
+// OutputStreamsHipKernels.  Options::fusedKernels selects the MI355X-fused step (fewer, wider kernels, identical
+// arithmetic order) instead of one launch per reference kernel.
+#ifndef KW_HOST_KSPACE_FIRST_ORDER_SOLVER_H
+#define KW_HOST_KSPACE_FIRST_ORDER_SOLVER_H
+#include "MatrixContainer.h"
+#include "OutputStreams.h"
+#include "Parameters.h"
+
+class KSpaceFirstOrderSolver
+{
+ public:
+  using SD = Parameters::SimulationDimension;
+  KSpaceFirstOrderSolver();
+  virtual ~KSpaceFirstOrderSolver();
+
+  virtual void allocateMemory();
+  virtual void freeMemory();
+  virtual void loadInputData(const InputProvider& input);
+  /// whole simulation: plans, pre-processing, main loop to Nt, post-processing
+  virtual void compute();
+
+  // ---- the same pipeline in pieces, so that bench.py / tests can time or inspect the loop alone ----
+  void prepare();                       // initializeFftPlans + preProcessing + constants + copyMatricesToDevice
+  void runTimeSteps(size_t nSteps);     // body of computeMainLoop for nSteps (stops at Nt)
+  void finish();                        // last delayed flush + postProcessing
+
+  MatrixContainer&       getMatrixContainer() { return mMatrixContainer; }
+  OutputStreamContainer& getOutputStreamContainer() { return mOutputStreamContainer; }
+  /// "kspaceFirstOrder-HIP" code name (reference: getCodeName, KSpaceFirstOrderSolver.h)
+  std::string getCodeName() const { return "kspaceFirstOrder-HIP v0.1 (gfx950)"; }
+
+ protected:
+  void initializeFftPlans();
+  template<SD simulationDimension> void preProcessing();
+  template<SD simulationDimension> void computeMainLoop();
+  template<SD simulationDimension> void postProcessing();
+  void storeSensorData();
+
+  template<SD simulationDimension> void computeVelocity();
+  template<SD simulationDimension> void computeVelocityGradient();
+  template<SD simulationDimension> void computeDensityNonliner();
+  template<SD simulationDimension> void computeDensityLinear();
+  template<SD simulationDimension> void computePressureNonlinear();
+  template<SD simulationDimension> void computePressureLinear();
+  void addVelocitySource();
+  template<SD simulationDimension> void addPressureSource();
+  void scaleSource(RealMatrix& scaledSource, const RealMatrix& sourceInput, const IndexMatrix& sourceIndex, const size_t manyFlag);
+  template<SD simulationDimension> void addInitialPressureSource();
+  template<SD simulationDimension> void computeShiftedVelocity();
+
+  void generateKappa();
+  void generateSourceKappa();
+  void generateKappaAndNablas();
+  void generateTauAndEta();
+  void computeC2();
+
+  // matrix shortcuts (reference: inline getters at KSpaceFirstOrderSolver.h:560-1070)
+  using MI = MatrixContainer::MatrixIdx;
+  RealMatrix& real(MI idx) { return mMatrixContainer.getMatrix<RealMatrix>(idx); }
+  HipFftComplexMatrix& fft(MI idx) { return mMatrixContainer.getMatrix<HipFftComplexMatrix>(idx); }
+  IndexMatrix& index(MI idx) { return mMatrixContainer.getMatrix<IndexMatrix>(idx); }
+  RealMatrix& getP() { return real(MI::kP); }
+  RealMatrix& getTemp1RealND() { return real(MI::kTemp1RealND); }
+  RealMatrix& getTemp2RealND() { return real(MI::kTemp2RealND); }
+  RealMatrix& getTemp3RealND() { return real(MI::kTemp3RealND); }
+  HipFftComplexMatrix& getTempHipFftX() { return fft(MI::kTempHipFftX); }
+  HipFftComplexMatrix& getTempHipFftY() { return fft(MI::kTempHipFftY); }
+  HipFftComplexMatrix& getTempHipFftZ() { return fft(MI::kTempHipFftZ); }
+
+ private:
+  MatrixContainer       mMatrixContainer;
+  OutputStreamContainer mOutputStreamContainer;
+  Parameters&           mParameters;
+  bool                  mPrepared = false;
+};
+#endif

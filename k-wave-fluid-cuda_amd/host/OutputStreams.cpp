@@ -1,0 +1,287 @@
+// OutputStreams.cpp — see OutputStreams.h.
+#include "OutputStreams.h"
+
+#include <cstring>
+#include <limits>
+
+#include "HipError.h"
+#include "MatrixNames.h"
+#include "Parameters.h"
+
+static kw_ctx* ctx() { return Parameters::getInstance().getHipParameters().getContext(); }
+
+namespace OutputStreamsHipKernels
+{
+void sampleIndex(ReduceOperator op, float* buf, const float* src, const size_t* mask, size_t n)
+{
+  kwCheck(kw_sample_index(ctx(), static_cast<kw_reduce_op>(op), buf, src, (const uint64_t*)mask, n));
+}
+void sampleCuboid(ReduceOperator op, float* buf, const float* src, const DimensionSizes& tl, const DimensionSizes& br,
+                  const DimensionSizes& size, size_t n)
+{
+  const uint32_t a[3] = {(uint32_t)tl.nx, (uint32_t)tl.ny, (uint32_t)tl.nz};
+  const uint32_t b[3] = {(uint32_t)br.nx, (uint32_t)br.ny, (uint32_t)br.nz};
+  const uint32_t s[3] = {(uint32_t)size.nx, (uint32_t)size.ny, (uint32_t)size.nz};
+  kwCheck(kw_sample_cuboid(ctx(), static_cast<kw_reduce_op>(op), buf, src, a, b, s, n));
+}
+void sampleAll(ReduceOperator op, float* buf, const float* src, size_t n)
+{
+  kwCheck(kw_sample_all(ctx(), static_cast<kw_reduce_op>(op), buf, src, n));
+}
+void postProcessingRms(float* buf, float coeff, size_t n) { kwCheck(kw_post_processing_rms(ctx(), buf, coeff, n)); }
+} // namespace OutputStreamsHipKernels
+
+// ---- BaseOutputStream -----------------------------------------------------------------------------------------------
+BaseOutputStream::~BaseOutputStream() { freeMemory(); }
+
+OutputStreamsHipKernels::ReduceOperator BaseOutputStream::kernelOp() const
+{
+  using K = OutputStreamsHipKernels::ReduceOperator;
+  switch (mReduceOp)
+  {
+    case ReduceOperator::kRms: return K::kRms;
+    case ReduceOperator::kMax: return K::kMax;
+    case ReduceOperator::kMin: return K::kMin;
+    default: return K::kNone;
+  }
+}
+
+void BaseOutputStream::allocateMemory()
+{
+  void* d = nullptr;
+  kwCheck(kw_malloc(ctx(), mSize * sizeof(float), &d));
+  mDeviceBuffer = static_cast<float*>(d);
+  // initial values per reduce operator (BaseOutputStream.cpp:271-367)
+  std::vector<float> init(mSize, 0.0f);
+  if (mReduceOp == ReduceOperator::kMax) init.assign(mSize, -1 * std::numeric_limits<float>::max());
+  if (mReduceOp == ReduceOperator::kMin) init.assign(mSize, std::numeric_limits<float>::max());
+  kwCheck(kw_memcpy_h2d(ctx(), mDeviceBuffer, init.data(), mSize * sizeof(float)));
+  if (mReduceOp == ReduceOperator::kNone)
+  {
+    for (int b = 0; b < 2; b++)
+    {
+      void* h = nullptr;
+      kwCheck(kw_host_alloc(ctx(), mSize * sizeof(float), &h));
+      mPinned[b] = static_cast<float*>(h);
+      kwCheck(kw_event_create(ctx(), &mEvent[b]));
+    }
+  }
+}
+
+void BaseOutputStream::freeMemory()
+{
+  if (!ctx()) return;
+  if (mDeviceBuffer) kw_free(ctx(), mDeviceBuffer);
+  mDeviceBuffer = nullptr;
+  for (int b = 0; b < 2; b++)
+  {
+    if (mPinned[b]) kw_host_free(ctx(), mPinned[b]);
+    if (mEvent[b]) kw_event_destroy(ctx(), mEvent[b]);
+    mPinned[b] = nullptr;
+    mEvent[b]  = nullptr;
+  }
+}
+
+void BaseOutputStream::copyAggregateFromDevice()
+{
+  mDataset.resize(mSize);
+  kwCheck(kw_memcpy_d2h(ctx(), mDataset.data(), mDeviceBuffer, mSize * sizeof(float)));
+}
+
+void BaseOutputStream::postProcess()
+{
+  if (mReduceOp == ReduceOperator::kRms)
+  { // BaseOutputStream.cpp:172-178
+    const Parameters& p = Parameters::getInstance();
+    const float scalingCoeff = 1.0f / (p.getNt() - p.getSamplingStartTimeIndex());
+    OutputStreamsHipKernels::postProcessingRms(mDeviceBuffer, scalingCoeff, mSize);
+  }
+  if (mReduceOp != ReduceOperator::kNone) copyAggregateFromDevice();
+}
+
+// ---- raw helpers ----------------------------------------------------------------------------------------------------
+static void rawSampleTail(kw_ctx* c, float* dev, float* pinned, void* event, size_t n)
+{
+  kwCheck(kw_memcpy_d2h_async(c, pinned, dev, n * sizeof(float)));
+  kwCheck(kw_event_record(c, event));
+}
+
+// ---- IndexOutputStream ----------------------------------------------------------------------------------------------
+void IndexOutputStream::create()
+{
+  mSize = mSensorMask.size();
+  allocateMemory();
+}
+void IndexOutputStream::sample()
+{
+  OutputStreamsHipKernels::sampleIndex(kernelOp(), mDeviceBuffer, mSourceMatrix.getDeviceData(),
+                                       mSensorMask.getDeviceData(), mSize);
+  if (mReduceOp == ReduceOperator::kNone)
+  {
+    const int b = mSampledSteps & 1;
+    rawSampleTail(ctx(), mDeviceBuffer, mPinned[b], mEvent[b], mSize);
+  }
+  mSampledSteps++;
+}
+void IndexOutputStream::flushRaw()
+{
+  if (mReduceOp != ReduceOperator::kNone || mFlushedSteps >= mSampledSteps) return;
+  const int b = mFlushedSteps & 1;
+  kwCheck(kw_event_synchronize(ctx(), mEvent[b])); // IndexOutputStream.cpp:354
+  mDataset.insert(mDataset.end(), mPinned[b], mPinned[b] + mSize);
+  mFlushedSteps++;
+}
+
+// ---- CuboidOutputStream ---------------------------------------------------------------------------------------------
+void CuboidOutputStream::create()
+{
+  mSize = mSensorMask.getSizeOfAllCuboids();
+  allocateMemory();
+}
+void CuboidOutputStream::sample()
+{
+  const DimensionSizes dims = mSourceMatrix.getDimensionSizes();
+  size_t offset = 0;
+  for (size_t c = 0; c < mSensorMask.getDimensionSizes().ny; c++)
+  {
+    const size_t n = mSensorMask.getSizeOfCuboid(c);
+    OutputStreamsHipKernels::sampleCuboid(kernelOp(), mDeviceBuffer + offset, mSourceMatrix.getDeviceData(),
+                                          mSensorMask.getTopLeftCorner(c), mSensorMask.getBottomRightCorner(c), dims, n);
+    offset += n;
+  }
+  if (mReduceOp == ReduceOperator::kNone)
+  {
+    const int b = mSampledSteps & 1;
+    rawSampleTail(ctx(), mDeviceBuffer, mPinned[b], mEvent[b], mSize);
+  }
+  mSampledSteps++;
+}
+void CuboidOutputStream::flushRaw()
+{
+  if (mReduceOp != ReduceOperator::kNone || mFlushedSteps >= mSampledSteps) return;
+  const int b = mFlushedSteps & 1;
+  kwCheck(kw_event_synchronize(ctx(), mEvent[b]));
+  mDataset.insert(mDataset.end(), mPinned[b], mPinned[b] + mSize);
+  mFlushedSteps++;
+}
+
+// ---- WholeDomainOutputStream ----------------------------------------------------------------------------------------
+void WholeDomainOutputStream::create()
+{
+  mSize = mSourceMatrix.size();
+  allocateMemory();
+}
+void WholeDomainOutputStream::sample()
+{
+  OutputStreamsHipKernels::sampleAll(kernelOp(), mDeviceBuffer, mSourceMatrix.getDeviceData(), mSize);
+  mSampledSteps++;
+}
+
+// ---- OutputStreamContainer ------------------------------------------------------------------------------------------
+BaseOutputStream* OutputStreamContainer::createOutputStream(MatrixContainer& mc, MatrixContainer::MatrixIdx sampled,
+                                                            const std::string& name, BaseOutputStream::ReduceOperator op)
+{
+  using MI = MatrixContainer::MatrixIdx;
+  const Parameters& params = Parameters::getInstance();
+  if (params.getSensorMaskType() == Parameters::SensorMaskType::kIndex)
+    return new IndexOutputStream(name, mc.getMatrix<RealMatrix>(sampled), mc.getMatrix<IndexMatrix>(MI::kSensorMaskIndex), op);
+  return new CuboidOutputStream(name, mc.getMatrix<RealMatrix>(sampled), mc.getMatrix<IndexMatrix>(MI::kSensorMaskCorners), op);
+}
+
+void OutputStreamContainer::init(MatrixContainer& mc)
+{
+  using OI = OutputStreamIdx;
+  using MI = MatrixContainer::MatrixIdx;
+  using RO = BaseOutputStream::ReduceOperator;
+  const Parameters& params = Parameters::getInstance();
+  const bool haveMask = mc.has(MI::kSensorMaskIndex) || mc.has(MI::kSensorMaskCorners);
+
+  if (haveMask)
+  {
+    if (params.getStorePressureRawFlag()) mContainer[OI::kPressureRaw] = createOutputStream(mc, MI::kP, kPName, RO::kNone);
+    if (params.getStorePressureRmsFlag()) mContainer[OI::kPressureRms] = createOutputStream(mc, MI::kP, kPRmsName, RO::kRms);
+    if (params.getStorePressureMaxFlag()) mContainer[OI::kPressureMax] = createOutputStream(mc, MI::kP, kPMaxName, RO::kMax);
+    if (params.getStorePressureMinFlag()) mContainer[OI::kPressureMin] = createOutputStream(mc, MI::kP, kPMinName, RO::kMin);
+  }
+  if (params.getStorePressureMaxAllFlag())
+    mContainer[OI::kPressureMaxAll] = new WholeDomainOutputStream(kPMaxAllName, mc.getMatrix<RealMatrix>(MI::kP), RO::kMax);
+  if (params.getStorePressureMinAllFlag())
+    mContainer[OI::kPressureMinAll] = new WholeDomainOutputStream(kPMinAllName, mc.getMatrix<RealMatrix>(MI::kP), RO::kMin);
+  if (haveMask)
+  {
+    if (params.getStoreVelocityRawFlag())
+    {
+      mContainer[OI::kVelocityXRaw] = createOutputStream(mc, MI::kUxSgx, kUxName, RO::kNone);
+      mContainer[OI::kVelocityYRaw] = createOutputStream(mc, MI::kUySgy, kUyName, RO::kNone);
+      mContainer[OI::kVelocityZRaw] = createOutputStream(mc, MI::kUzSgz, kUzName, RO::kNone);
+    }
+    if (params.getStoreVelocityNonStaggeredRawFlag())
+    {
+      mContainer[OI::kVelocityXNonStaggeredRaw] = createOutputStream(mc, MI::kUxShifted, kUxNonStaggeredName, RO::kNone);
+      mContainer[OI::kVelocityYNonStaggeredRaw] = createOutputStream(mc, MI::kUyShifted, kUyNonStaggeredName, RO::kNone);
+      mContainer[OI::kVelocityZNonStaggeredRaw] = createOutputStream(mc, MI::kUzShifted, kUzNonStaggeredName, RO::kNone);
+    }
+    struct Agg { bool on; RO op; const char* suffix; OI x, y, z; };
+    const Agg aggs[] = {
+      {params.getStoreVelocityRmsFlag(), RO::kRms, "_rms", OI::kVelocityXRms, OI::kVelocityYRms, OI::kVelocityZRms},
+      {params.getStoreVelocityMaxFlag(), RO::kMax, "_max", OI::kVelocityXMax, OI::kVelocityYMax, OI::kVelocityZMax},
+      {params.getStoreVelocityMinFlag(), RO::kMin, "_min", OI::kVelocityXMin, OI::kVelocityYMin, OI::kVelocityZMin}};
+    for (const Agg& a : aggs)
+      if (a.on)
+      {
+        mContainer[a.x] = createOutputStream(mc, MI::kUxSgx, kUxName + a.suffix, a.op);
+        mContainer[a.y] = createOutputStream(mc, MI::kUySgy, kUyName + a.suffix, a.op);
+        mContainer[a.z] = createOutputStream(mc, MI::kUzSgz, kUzName + a.suffix, a.op);
+      }
+  }
+  if (params.getStoreVelocityMaxAllFlag())
+  {
+    mContainer[OI::kVelocityXMaxAll] = new WholeDomainOutputStream(kUxName + "_max_all", mc.getMatrix<RealMatrix>(MI::kUxSgx), RO::kMax);
+    mContainer[OI::kVelocityYMaxAll] = new WholeDomainOutputStream(kUyName + "_max_all", mc.getMatrix<RealMatrix>(MI::kUySgy), RO::kMax);
+    mContainer[OI::kVelocityZMaxAll] = new WholeDomainOutputStream(kUzName + "_max_all", mc.getMatrix<RealMatrix>(MI::kUzSgz), RO::kMax);
+  }
+  if (params.getStoreVelocityMinAllFlag())
+  {
+    mContainer[OI::kVelocityXMinAll] = new WholeDomainOutputStream(kUxName + "_min_all", mc.getMatrix<RealMatrix>(MI::kUxSgx), RO::kMin);
+    mContainer[OI::kVelocityYMinAll] = new WholeDomainOutputStream(kUyName + "_min_all", mc.getMatrix<RealMatrix>(MI::kUySgy), RO::kMin);
+    mContainer[OI::kVelocityZMinAll] = new WholeDomainOutputStream(kUzName + "_min_all", mc.getMatrix<RealMatrix>(MI::kUzSgz), RO::kMin);
+  }
+}
+
+void OutputStreamContainer::createStreams()
+{
+  for (auto& it : mContainer) it.second->create();
+}
+void OutputStreamContainer::sampleStreams()
+{
+  for (auto& it : mContainer) it.second->sample();
+}
+void OutputStreamContainer::flushRawStreams()
+{
+  for (auto& it : mContainer) it.second->flushRaw();
+}
+void OutputStreamContainer::postProcessStreams()
+{
+  for (auto& it : mContainer) it.second->postProcess();
+}
+void OutputStreamContainer::closeStreams()
+{
+  for (auto& it : mContainer) it.second->close();
+}
+void OutputStreamContainer::freeStreams()
+{
+  for (auto& it : mContainer) delete it.second;
+  mContainer.clear();
+}
+BaseOutputStream* OutputStreamContainer::find(const std::string& name) const
+{
+  for (auto& it : mContainer)
+    if (it.second->name() == name) return it.second;
+  return nullptr;
+}
+std::vector<std::string> OutputStreamContainer::names() const
+{
+  std::vector<std::string> v;
+  for (auto& it : mContainer) v.push_back(it.second->name());
+  return v;
+}

@@ -1,0 +1,127 @@
+// OutputStreams.h — sampling streams on the caller side of the sampling kernels.
+// Mirror of OutputStreams/{Base,Index,Cuboid,WholeDomain}OutputStream.{h,cpp} and
+// Containers/OutputStreamContainer.{h,cpp}, restricted to what sits on the per-step path:
+// sample() -> kernel call sites, reduce-operator initial values (BaseOutputStream.cpp:271-367), the
+// one-step-delayed flush of raw series (KSpaceFirstOrderSolver.cpp:1060-1093) and RMS post-processing.
+// Raw series land in pinned double buffers (async D2H + event) instead of the reference's zero-copy mapped
+// buffer (BaseOutputStream.cpp:369-388); the HDF5 dataset behind a stream is replaced by an in-memory dataset
+// (std::vector) that the HDF5 writer (optional component) or Python reads out.
+#ifndef KW_HOST_OUTPUT_STREAMS_H
+#define KW_HOST_OUTPUT_STREAMS_H
+#include <map>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "MatrixContainer.h"
+
+/// Replaces namespace OutputStreamsCudaKernels (OutputStreams/OutputStreamsCudaKernels.cuh:47-106)
+namespace OutputStreamsHipKernels
+{
+enum class ReduceOperator { kNone = 0, kRms = 1, kMax = 2, kMin = 3 };
+void sampleIndex(ReduceOperator op, float* samplingBuffer, const float* sourceData, const size_t* sensorData, size_t nSamples);
+void sampleCuboid(ReduceOperator op, float* samplingBuffer, const float* sourceData, const DimensionSizes& topLeftCorner,
+                  const DimensionSizes& bottomRightCorner, const DimensionSizes& matrixSize, size_t nSamples);
+void sampleAll(ReduceOperator op, float* samplingBuffer, const float* sourceData, size_t nSamples);
+void postProcessingRms(float* samplingBuffer, float scalingCoeff, size_t nSamples);
+} // namespace OutputStreamsHipKernels
+
+class BaseOutputStream
+{
+ public:
+  enum class ReduceOperator { kNone, kRms, kMax, kMin, kC, kIAvgC };
+  BaseOutputStream(const std::string& name, const RealMatrix& source, ReduceOperator op)
+    : mName(name), mSourceMatrix(source), mReduceOp(op) {}
+  virtual ~BaseOutputStream();
+  virtual void create() = 0;
+  virtual void sample() = 0;
+  virtual void flushRaw() {}
+  virtual void postProcess();
+  virtual void close() {}
+  const std::string& name() const { return mName; }
+  ReduceOperator     reduceOp() const { return mReduceOp; }
+  /// stored dataset: raw = [sampledSteps][mSize]; aggregated = [mSize] (valid after postProcess)
+  const std::vector<float>& dataset() const { return mDataset; }
+  size_t size() const { return mSize; }
+  size_t sampledSteps() const { return mFlushedSteps; }
+
+ protected:
+  void allocateMemory();
+  void freeMemory();
+  void copyAggregateFromDevice();
+  OutputStreamsHipKernels::ReduceOperator kernelOp() const;
+
+  std::string       mName;
+  const RealMatrix& mSourceMatrix;
+  ReduceOperator    mReduceOp;
+  size_t            mSize = 0;
+  float*            mDeviceBuffer = nullptr;       // aggregate or raw staging (device)
+  float*            mPinned[2]    = {nullptr, nullptr}; // raw: pinned double buffer
+  void*             mEvent[2]     = {nullptr, nullptr};
+  size_t            mSampledSteps = 0, mFlushedSteps = 0;
+  std::vector<float> mDataset;
+};
+
+class IndexOutputStream : public BaseOutputStream
+{
+ public:
+  IndexOutputStream(const std::string& name, const RealMatrix& source, const IndexMatrix& sensorMask, ReduceOperator op)
+    : BaseOutputStream(name, source, op), mSensorMask(sensorMask) {}
+  void create() override;
+  void sample() override;   // IndexOutputStream.cpp:253-293
+  void flushRaw() override; // IndexOutputStream.cpp:348-371 (raw branch)
+ private:
+  const IndexMatrix& mSensorMask;
+};
+
+class CuboidOutputStream : public BaseOutputStream
+{
+ public:
+  CuboidOutputStream(const std::string& name, const RealMatrix& source, const IndexMatrix& sensorMask, ReduceOperator op)
+    : BaseOutputStream(name, source, op), mSensorMask(sensorMask) {}
+  void create() override;
+  void sample() override;   // CuboidOutputStream.cpp:263-345: one launch per cuboid
+  void flushRaw() override;
+ private:
+  const IndexMatrix& mSensorMask;
+};
+
+class WholeDomainOutputStream : public BaseOutputStream
+{
+ public:
+  WholeDomainOutputStream(const std::string& name, const RealMatrix& source, ReduceOperator op)
+    : BaseOutputStream(name, source, op) {}
+  void create() override;
+  void sample() override; // WholeDomainOutputStream.cpp:143-198
+};
+
+class OutputStreamContainer
+{
+ public:
+  /// order is semantic (OutputStreamContainer.h:56-57): iteration follows the enum
+  enum class OutputStreamIdx
+  {
+    kPressureRaw, kPressureRms, kPressureMax, kPressureMin, kPressureMaxAll, kPressureMinAll,
+    kVelocityXRaw, kVelocityYRaw, kVelocityZRaw, kVelocityXNonStaggeredRaw, kVelocityYNonStaggeredRaw,
+    kVelocityZNonStaggeredRaw, kVelocityXRms, kVelocityYRms, kVelocityZRms, kVelocityXMax, kVelocityYMax,
+    kVelocityZMax, kVelocityXMin, kVelocityYMin, kVelocityZMin, kVelocityXMaxAll, kVelocityYMaxAll, kVelocityZMaxAll,
+    kVelocityXMinAll, kVelocityYMinAll, kVelocityZMinAll
+  };
+  ~OutputStreamContainer() { freeStreams(); }
+  void init(MatrixContainer& matrixContainer); // OutputStreamContainer.cpp:70-325
+  void createStreams();
+  void sampleStreams();      // :364-373
+  void flushRawStreams();    // :380-403
+  void postProcessStreams(); // :339-345
+  void closeStreams();
+  void freeStreams();
+  bool empty() const { return mContainer.empty(); }
+  BaseOutputStream* find(const std::string& name) const;
+  std::vector<std::string> names() const;
+
+ private:
+  BaseOutputStream* createOutputStream(MatrixContainer& mc, MatrixContainer::MatrixIdx sampled, const std::string& name,
+                                       BaseOutputStream::ReduceOperator op);
+  std::map<OutputStreamIdx, BaseOutputStream*> mContainer;
+};
+#endif

@@ -1,0 +1,178 @@
+// host_capi.cpp — extern "C" entry points of libkwave_host.so (include/kwave_host.h).
+#include <cstdio>
+#include <cstring>
+#include <exception>
+#include <memory>
+#include <string>
+
+#include "HipError.h"
+#include "KSpaceFirstOrderSolver.h"
+#include "kwave_host.h"
+
+static thread_local std::string g_err;
+
+struct kwh_solver
+{
+  MemoryInput                             input;
+  std::unique_ptr<KSpaceFirstOrderSolver> solver;
+};
+
+#define KWH_TRY try {
+#define KWH_CATCH                                                                                                      \
+  }                                                                                                                    \
+  catch (const std::bad_alloc&) { g_err = "out of memory"; return 4; }                                                 \
+  catch (const std::exception& e) { g_err = e.what(); return 1; }                                                      \
+  catch (...) { g_err = "unknown exception"; return 1; }                                                               \
+  return 0;
+
+extern "C" {
+
+const char* kwh_last_error(void) { return g_err.c_str(); }
+
+int kwh_create(const kwh_dataset* datasets, size_t n, const kwh_options* o, kwh_solver** out)
+{
+  KWH_TRY
+  if (!datasets || !o || !out) throw std::invalid_argument("kwh_create: NULL argument");
+  *out = nullptr;
+  std::unique_ptr<kwh_solver> s(new kwh_solver());
+  for (size_t i = 0; i < n; i++)
+  {
+    const kwh_dataset& d = datasets[i];
+    DimensionSizes dims(d.nx, d.ny, d.nz);
+    // complex datasets come with their float count in nx*ny*nz already doubled by the caller's shape
+    s->input.add(d.name, d.data, d.dtype == 0 ? InputProvider::DataType::kFloat : InputProvider::DataType::kLong, dims);
+  }
+  Parameters::Options opt;
+  opt.deviceIdx              = o->device_idx;
+  opt.fusedKernels           = o->fused_kernels != 0;
+  opt.samplingStartTimeIndex = o->sampling_start_time_index;
+  opt.benchmarkTimeStepCount = o->benchmark_time_steps;
+  opt.storePressureRaw = o->p_raw; opt.storePressureRms = o->p_rms; opt.storePressureMax = o->p_max;
+  opt.storePressureMin = o->p_min; opt.storePressureMaxAll = o->p_max_all; opt.storePressureMinAll = o->p_min_all;
+  opt.storePressureFinalAll = o->p_final;
+  opt.storeVelocityRaw = o->u_raw; opt.storeVelocityRms = o->u_rms; opt.storeVelocityMax = o->u_max;
+  opt.storeVelocityMin = o->u_min; opt.storeVelocityMaxAll = o->u_max_all; opt.storeVelocityMinAll = o->u_min_all;
+  opt.storeVelocityFinalAll = o->u_final; opt.storeVelocityNonStaggeredRaw = o->u_non_staggered_raw;
+  opt.storePressureC = o->p_c; opt.storeVelocityNonStaggeredC = o->u_non_staggered_c;
+  opt.storeIntensityAvgC = o->i_avg_c; opt.noCompressionOverlap = o->no_overlap;
+  opt.period = o->period; opt.mos = o->mos ? o->mos : 1; opt.harmonics = o->harmonics ? o->harmonics : 1;
+
+  Parameters& params = Parameters::getInstance();
+  params.init(s->input, opt);
+  params.selectDevice();
+  params.getHipParameters().setUpDeviceConstants();
+  s->solver.reset(new KSpaceFirstOrderSolver());
+  s->solver->allocateMemory();
+  s->solver->loadInputData(s->input);
+  *out = s.release();
+  KWH_CATCH
+}
+
+int kwh_destroy(kwh_solver* s)
+{
+  KWH_TRY
+  if (s)
+  {
+    if (s->solver) kw_sync(Parameters::getInstance().getHipParameters().getContext());
+    s->solver.reset();
+    delete s;
+  }
+  KWH_CATCH
+}
+
+int kwh_run(kwh_solver* s, uint64_t n_steps)
+{
+  KWH_TRY
+  if (!s) throw std::invalid_argument("kwh_run: NULL solver");
+  s->solver->runTimeSteps(n_steps);
+  KWH_CATCH
+}
+
+int kwh_finish(kwh_solver* s)
+{
+  KWH_TRY
+  if (!s) throw std::invalid_argument("kwh_finish: NULL solver");
+  s->solver->finish();
+  KWH_CATCH
+}
+
+int kwh_sync(kwh_solver* s)
+{
+  KWH_TRY
+  (void)s;
+  kwCheck(kw_sync(Parameters::getInstance().getHipParameters().getContext()));
+  KWH_CATCH
+}
+
+uint64_t kwh_time_index(const kwh_solver*) { return Parameters::getInstance().getTimeIndex(); }
+void*    kwh_context(kwh_solver*) { return Parameters::getInstance().getHipParameters().getContext(); }
+
+static BaseMatrix* findMatrix(kwh_solver* s, const char* name, MatrixRecord::MatrixType* type)
+{
+  for (auto& rec : s->solver->getMatrixContainer().records())
+    if (rec.second.matrixName == name)
+    {
+      *type = rec.second.matrixType;
+      return rec.second.matrixPtr;
+    }
+  throw std::invalid_argument(std::string("no matrix named ") + name + " in this simulation");
+}
+
+int kwh_matrix_size(kwh_solver* s, const char* name, uint64_t* n)
+{
+  KWH_TRY
+  MatrixRecord::MatrixType t;
+  BaseMatrix* m = findMatrix(s, name, &t);
+  if (t == MatrixRecord::MatrixType::kIndex) throw std::invalid_argument("index matrices are not float matrices");
+  *n = static_cast<BaseFloatMatrix*>(m)->capacity();
+  KWH_CATCH
+}
+
+int kwh_get_matrix(kwh_solver* s, const char* name, float* dst, uint64_t n)
+{
+  KWH_TRY
+  MatrixRecord::MatrixType t;
+  BaseMatrix* m = findMatrix(s, name, &t);
+  if (t == MatrixRecord::MatrixType::kIndex) throw std::invalid_argument("index matrices are not float matrices");
+  BaseFloatMatrix* f = static_cast<BaseFloatMatrix*>(m);
+  if (f->capacity() != n) throw std::invalid_argument(std::string("size mismatch for matrix ") + name);
+  kwCheck(kw_memcpy_d2h(Parameters::getInstance().getHipParameters().getContext(), dst, f->getDeviceData(), n * sizeof(float)));
+  KWH_CATCH
+}
+
+int kwh_get_scalar(kwh_solver*, const char* name, float* out)
+{
+  KWH_TRY
+  const Parameters& p = Parameters::getInstance();
+  const std::string n(name);
+  if (n == "absorb_tau") *out = p.getAbsorbTauScalar();
+  else if (n == "absorb_eta") *out = p.getAbsorbEtaScalar();
+  else if (n == "c2") *out = p.getC2Scalar();
+  else if (n == "dt_rho0_sgx") *out = p.getDtRho0SgxScalar();
+  else if (n == "dt_rho0_sgy") *out = p.getDtRho0SgyScalar();
+  else if (n == "dt_rho0_sgz") *out = p.getDtRho0SgzScalar();
+  else if (n == "dt") *out = p.getDt();
+  else throw std::invalid_argument("unknown scalar " + n);
+  KWH_CATCH
+}
+
+int kwh_stream_info(kwh_solver* s, const char* name, uint64_t* size, uint64_t* steps)
+{
+  KWH_TRY
+  BaseOutputStream* st = s->solver->getOutputStreamContainer().find(name);
+  if (!st) throw std::invalid_argument(std::string("no output stream named ") + name);
+  *size  = st->size();
+  *steps = (st->reduceOp() == BaseOutputStream::ReduceOperator::kNone) ? st->sampledSteps() : 1;
+  KWH_CATCH
+}
+
+int kwh_stream_read(kwh_solver* s, const char* name, float* dst, uint64_t n)
+{
+  KWH_TRY
+  BaseOutputStream* st = s->solver->getOutputStreamContainer().find(name);
+  if (!st) throw std::invalid_argument(std::string("no output stream named ") + name);
+  if (st->dataset().size() != n) throw std::invalid_argument(std::string("size mismatch for stream ") + name);
+  std::memcpy(dst, st->dataset().data(), n * sizeof(float));
+  KWH_CATCH
+}
+}

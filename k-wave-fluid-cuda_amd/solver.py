@@ -1,0 +1,188 @@
+"""ctypes front-end of the C++ host layer (include/kwave_host.h -> lib/libkwave_host.so).
+
+`HostSolver` runs the C++ `KSpaceFirstOrderSolver` time loop (k-wave-fluid-cuda_amd/host/) on an MI355X from a
+problem given as a dict of NumPy arrays keyed by the k-Wave HDF5 dataset names.  No CPU fallback: a missing
+library or device raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Dict, Optional
+
+import numpy as np
+
+from . import capi
+
+HOST_LIB_PATH = os.path.join(capi.PKG, "lib", "libkwave_host.so")
+
+
+class Dataset(C.Structure):
+    _fields_ = [("name", C.c_char_p), ("data", C.c_void_p), ("dtype", C.c_int32), ("pad_", C.c_int32),
+                ("nx", C.c_uint64), ("ny", C.c_uint64), ("nz", C.c_uint64)]
+
+
+class Options(C.Structure):
+    _fields_ = [("device_idx", C.c_int32), ("fused_kernels", C.c_int32),
+                ("sampling_start_time_index", C.c_uint64), ("benchmark_time_steps", C.c_uint64)] + \
+               [(n, C.c_int32) for n in ("p_raw", "p_rms", "p_max", "p_min", "p_max_all", "p_min_all", "p_final",
+                                         "u_raw", "u_rms", "u_max", "u_min", "u_max_all", "u_min_all", "u_final",
+                                         "u_non_staggered_raw", "p_c", "u_non_staggered_c", "i_avg_c", "no_overlap")] + \
+               [("period", C.c_float), ("mos", C.c_uint64), ("harmonics", C.c_uint64)]
+
+
+_hlib: Optional[C.CDLL] = None
+
+
+def load_host() -> C.CDLL:
+    global _hlib
+    if _hlib is None:
+        capi.load()  # libkwave_hip.so first (RTLD_GLOBAL not needed: host lib links it via rpath $ORIGIN)
+        if not os.path.exists(HOST_LIB_PATH):
+            raise capi.KWaveError(f"{HOST_LIB_PATH} is missing: run build() first")
+        L = C.CDLL(HOST_LIB_PATH)
+        L.kwh_last_error.restype = C.c_char_p
+        L.kwh_create.argtypes = [C.POINTER(Dataset), C.c_size_t, C.POINTER(Options), C.POINTER(C.c_void_p)]
+        L.kwh_destroy.argtypes = [C.c_void_p]
+        L.kwh_run.argtypes = [C.c_void_p, C.c_uint64]
+        L.kwh_finish.argtypes = [C.c_void_p]
+        L.kwh_sync.argtypes = [C.c_void_p]
+        L.kwh_time_index.restype = C.c_uint64
+        L.kwh_time_index.argtypes = [C.c_void_p]
+        L.kwh_context.restype = C.c_void_p
+        L.kwh_context.argtypes = [C.c_void_p]
+        L.kwh_get_matrix.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_uint64]
+        L.kwh_matrix_size.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_uint64)]
+        L.kwh_get_scalar.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_float)]
+        L.kwh_stream_info.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+        L.kwh_stream_read.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_uint64]
+        _hlib = L
+    return _hlib
+
+
+def _check(rc: int):
+    if rc != 0:
+        raise capi.KWaveError(load_host().kwh_last_error().decode(errors="replace"))
+
+
+# reference-style matrix names (MatrixContainer records) for the state arrays
+STATE_NAMES = {"p": "p", "ux": "ux_sgx", "uy": "uy_sgy", "uz": "uz_sgz", "rhox": "rhox", "rhoy": "rhoy",
+               "rhoz": "rhoz", "duxdx": "duxdx", "duydy": "duydy", "duzdz": "duzdz", "kappa": "kappa_r",
+               "nabla1": "absorb_nabla1_r", "nabla2": "absorb_nabla2_r", "source_kappa": "source_kappa_r",
+               "tau": "absorb_tau", "eta": "absorb_eta", "c2": "c0", "dtrho0sgx": "rho0_sgx", "dtrho0sgy": "rho0_sgy",
+               "dtrho0sgz": "rho0_sgz", "ux_shifted": "ux_shifted", "uy_shifted": "uy_shifted",
+               "uz_shifted": "uz_shifted"}
+
+
+class HostSolver:
+    """One simulation on the GPU through the C++ host layer."""
+
+    def __init__(self, pr: Dict[str, np.ndarray], **opts):
+        L = load_host()
+        self._keep = []
+        sets = (Dataset * len(pr))()
+        for i, (name, a) in enumerate(pr.items()):
+            if a.dtype == np.uint64:
+                arr, dt = np.ascontiguousarray(a, dtype=np.uint64), 1
+            else:
+                arr, dt = np.ascontiguousarray(a, dtype=np.float32), 0
+            self._keep.append(arr)
+            shp = list(arr.shape)[::-1]
+            while len(shp) < 3:
+                shp.append(1)
+            if len(shp) > 3:
+                shp = shp[:2] + [int(np.prod(shp[2:]))]
+            nm = name.encode()
+            self._keep.append(nm)
+            sets[i].name, sets[i].data, sets[i].dtype = nm, arr.ctypes.data, dt
+            sets[i].nx, sets[i].ny, sets[i].nz = shp
+        o = Options()
+        o.device_idx = opts.pop("device_idx", -1)
+        o.fused_kernels = int(opts.pop("fused_kernels", True))
+        o.sampling_start_time_index = opts.pop("sampling_start", 0)
+        o.benchmark_time_steps = opts.pop("benchmark_steps", 0)
+        o.period = float(opts.pop("period", 0.0))
+        o.mos = int(opts.pop("mos", 1))
+        o.harmonics = int(opts.pop("harmonics", 1))
+        for k, v in opts.items():
+            if not hasattr(o, k):
+                raise TypeError(f"unknown option {k}")
+            setattr(o, k, int(v))
+        self.nx, self.ny, self.nz = (int(np.asarray(pr[k]).ravel()[0]) for k in ("Nx", "Ny", "Nz"))
+        h = C.c_void_p()
+        _check(L.kwh_create(sets, len(pr), C.byref(o), C.byref(h)))
+        self._h = h
+        self.L = L
+
+    def run(self, n_steps: int):
+        _check(self.L.kwh_run(self._h, n_steps))
+
+    def step(self, n: int = 1):
+        self.run(n)
+
+    def finish(self):
+        _check(self.L.kwh_finish(self._h))
+
+    def sync(self):
+        _check(self.L.kwh_sync(self._h))
+
+    @property
+    def t(self) -> int:
+        return int(self.L.kwh_time_index(self._h))
+
+    @property
+    def ctx(self):
+        return C.c_void_p(self.L.kwh_context(self._h))
+
+    def field(self, name: str) -> np.ndarray:
+        ref = STATE_NAMES.get(name, name).encode()
+        n = C.c_uint64()
+        _check(self.L.kwh_matrix_size(self._h, ref, C.byref(n)))
+        out = np.empty(n.value, dtype=np.float32)
+        _check(self.L.kwh_get_matrix(self._h, ref, out.ctypes.data, n.value))
+        full, red = self.nx * self.ny * self.nz, (self.nx // 2 + 1) * self.ny * self.nz
+        if n.value == full:
+            return out.reshape(self.nz, self.ny, self.nx)
+        if n.value == red:
+            return out.reshape(self.nz, self.ny, self.nx // 2 + 1)
+        return out
+
+    def scalar(self, name: str) -> float:
+        v = C.c_float()
+        _check(self.L.kwh_get_scalar(self._h, name.encode(), C.byref(v)))
+        return float(v.value)
+
+    def stream(self, name: str) -> np.ndarray:
+        size, steps = C.c_uint64(), C.c_uint64()
+        _check(self.L.kwh_stream_info(self._h, name.encode(), C.byref(size), C.byref(steps)))
+        out = np.empty(size.value * steps.value, dtype=np.float32)
+        _check(self.L.kwh_stream_read(self._h, name.encode(), out.ctypes.data, out.size))
+        return out.reshape(steps.value, size.value) if steps.value != 1 else out
+
+    # HIP-event timing of n steps on the solver's stream
+    def time_steps(self, n_steps: int) -> float:
+        hip = capi.load()
+        ctx = self.ctx
+        e0, e1 = C.c_void_p(), C.c_void_p()
+        capi.check(hip.kw_event_create(ctx, C.byref(e0)))
+        capi.check(hip.kw_event_create(ctx, C.byref(e1)))
+        capi.check(hip.kw_event_record(ctx, e0))
+        self.run(n_steps)
+        capi.check(hip.kw_event_record(ctx, e1))
+        capi.check(hip.kw_event_synchronize(ctx, e1))
+        ms = C.c_float()
+        capi.check(hip.kw_event_elapsed_ms(ctx, e0, e1, C.byref(ms)))
+        hip.kw_event_destroy(ctx, e0)
+        hip.kw_event_destroy(ctx, e1)
+        return float(ms.value)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self.L.kwh_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1022,7 +1022,7 @@ static inline void reduce_one(int op, float* b, float v)
   switch (op)
   {
     case KWO_OP_NONE: *b = v; break;
-    case KWO_OP_RMS: *b += (v * v); break;
+    case KWO_OP_RMS: *b = fmaf(v, v, *b); break; /* nvcc default -fmad=true contracts buf += v*v (:91-93) into one FMA */
     case KWO_OP_MAX: *b = (*b > v) ? *b : v; break; /* max(buf, v): :97-99 */
     case KWO_OP_MIN: *b = (*b < v) ? *b : v; break;
   }
