@@ -1,0 +1,160 @@
+#!/usr/bin/env python3
+"""bench.py — time-steps/s of the k-space first-order loop on MI355X (BASELINE.json metric).
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--size n] [--no-cpu]
+
+N=1 workload: BASELINE config 3 — 256^3 heterogeneous (c0, rho0, BonA, alpha_coeff as arrays), power-law absorption +
+nonlinear term, p0 source, p_raw + p_max sampled on one xy plane (the manual's benchmark setup).
+A "step" is one pass of the per-step loop (KSpaceFirstOrderSolver.cpp:885-935) over the whole grid, with all inputs
+resident in HBM before the timed region.  The C++ host loop (libkwave_host) drives libkwave_hip; there is no CPU
+fallback.  One JSON line is printed by rank 0.
+
+Extra objects: "roofline" (dominant device entry point: algorithmic bytes per launch / HIP-event duration, vs the
+8 TB/s HBM peak; "step" carries the whole-step figure with B_alg of SURVEY.md §8d) and "cpu_baseline" (the CPU oracle
+on the host cores for a bounded number of steps of the same workload).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
+BASELINE_STEPS_PER_S_256 = 1000.0 / 49.72  # kspaceFirstOrder3D-CUDA, TITAN X, 256^3, manual Table C.4
+
+
+def alg_bytes(n: int, *, het=True, nonlinear=True, absorbing=True):
+    """Algorithmic bytes per step and per device entry point (SURVEY.md §8d convention: every element-wise stage is
+    charged its array reads+writes once, every 3-D FFT one read of its input + one write of its output)."""
+    N = n ** 3
+    Nc = (n // 2 + 1) * n * n
+    R, Cx, K = 4 * N, 8 * Nc, 4 * Nc
+    h = int(het)
+    per = {
+        "fft_r2c_3d": R + Cx,
+        "fft_c2r_3d": R + Cx,
+        "compute_pressure_gradient": 4 * Cx + K,
+        "compute_velocity": (9 + 3 * h) * R,
+        "compute_velocity_gradient": 6 * Cx + K,
+        "compute_density_nonlinear": (9 + h) * R,
+        "compute_density_linear": (9 + h) * R,
+        "compute_pressure_terms_nonlinear": (9 + 2 * h) * R,
+        "compute_pressure_terms_linear": (8 + h) * R,
+        "compute_absorbtion_term": 4 * Cx + 2 * K,
+        "sum_pressure_terms": (4 + 3 * h) * R,
+        "sum_pressure_nonlinear_lossless": (4 + 3 * h) * R,
+        "sum_pressure_linear_lossless": (4 + h) * R,
+    }
+    n_fft = 10 + 4 * int(absorbing)
+    b = n_fft * (R + Cx) + per["compute_pressure_gradient"] + per["compute_velocity"] + per["compute_velocity_gradient"]
+    b += per["compute_density_nonlinear"]
+    if absorbing:
+        b += (per["compute_pressure_terms_nonlinear"] if nonlinear else per["compute_pressure_terms_linear"])
+        b += per["compute_absorbtion_term"] + per["sum_pressure_terms"]
+    else:
+        b += per["sum_pressure_nonlinear_lossless"] if nonlinear else per["sum_pressure_linear_lossless"]
+    return b, per
+
+
+def cpu_baseline(pr, n, budget_s=25.0):
+    """CPU oracle ("port" of the reference algorithm, own FFT — no FFTW/MKL in the image) on the host cores."""
+    from oracle import oracle as orc
+    cores = os.cpu_count() or 1
+    sim = orc.OracleSim(pr)
+    sim.step(1)  # step 0 (p0 initialisation) is not part of the steady loop
+    t0 = time.time()
+    sim.step(1)
+    one = time.time() - t0
+    steps = max(1, min(20, int(budget_s / max(one, 1e-3)) - 1))
+    t0 = time.time()
+    sim.step(steps)
+    dt = time.time() - t0
+    sim.close()
+    return {"value": steps / dt, "unit": "time-steps/s", "cores": cores, "kind": "port",
+            "sample": f"{steps} steps of the same {n}^3 workload after 2 untimed steps, OpenMP on {cores} threads, "
+                      f"in-repo FFT (no FFTW/MKL); manual Table C.3: 224.5 ms/step on 2x12-core Haswell + MKL"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--size", type=int, default=0, help="grid size n (n^3); default 256 at N=1, 512 at N>1")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--profile-steps", type=int, default=5)
+    ap.add_argument("--granular", action="store_true", help="one launch per reference kernel instead of fused kernels")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    if args.gpus > 1 or world > 1:
+        from kwave_amd_dist_bench import run_distributed  # noqa: F401  (multi-GPU slab path)
+        return run_distributed(args)
+
+    import kwave_amd  # noqa: F401
+    from kwave_amd import capi, synthetic
+    from kwave_amd.solver import HostSolver
+
+    n = args.size or 256
+    K, W, P = args.steps, args.warmup, args.profile_steps
+    t_gen = time.time()
+    pr = synthetic.make_problem(n, heterogeneous=True, nonlinear=True, absorbing=True, source="p0", nt=W + K + P + 8)
+    t_gen = time.time() - t_gen
+    sim = HostSolver(pr, p_raw=1, p_max=1, fused_kernels=not args.granular)
+    sim.run(W)
+    sim.sync()
+    ms = sim.time_steps(K)  # HIP events on the solver's stream around exactly K steps; synchronises on the stop event
+    sim.sync()
+    steps_per_s = K / (ms * 1e-3)
+
+    # --- per entry point timing (live, same process, same workload) ---
+    hip = capi.load()
+    capi.check(hip.kw_profile_enable(sim.ctx, 1))
+    sim.run(P)
+    prof = capi.profile_collect(sim.ctx)
+    capi.check(hip.kw_profile_enable(sim.ctx, 0))
+    b_step, per = alg_bytes(n)
+    table = {}
+    for name, (calls, total_ms) in prof.items():
+        avg = total_ms / max(calls, 1)
+        ab = per.get(name)
+        table[name] = {"calls_per_step": calls / P, "avg_ms": round(avg, 4),
+                       "ms_per_step": round(total_ms / P, 4),
+                       "alg_gbs": round(ab / (avg * 1e-3) / 1e9, 1) if ab else None}
+    dom = max((k for k in table if per.get(k)), key=lambda k: table[k]["ms_per_step"])
+    achieved = per[dom] / (table[dom]["avg_ms"] * 1e-3) / 1e9
+    roofline = {"bound": "hbm", "kernel": "kw_" + dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                "alg_bytes_per_launch": per[dom], "avg_ms": table[dom]["avg_ms"],
+                "step": {"alg_bytes": b_step, "achieved": round(b_step / (ms * 1e-3 / K) / 1e9, 1),
+                         "frac": round(b_step / (ms * 1e-3 / K) / 1e9 / HBM_PEAK_GBS, 4)},
+                "entry_points": table}
+    info = capi.DeviceInfo()
+    capi.check(hip.kw_device_info_get(sim.ctx, info))
+    sim.close()
+
+    out = {"metric": "time-steps/sec on 256^3 heterogeneous grid; achieved HBM GB/s vs roofline",
+           "value": round(steps_per_s, 2), "unit": "time-steps/s", "n_gpus": 1, "steps": K, "warmup": W,
+           "ms_per_step": round(ms / K, 4), "higher_is_better": True, "scaling": "weak",
+           "vs_baseline": round(steps_per_s / BASELINE_STEPS_PER_S_256, 2) if n == 256 else None,
+           "dtype": "f32", "data": "synthetic",
+           "config": {"workload": f"{n}^3 heterogeneous (c0,rho0,BonA,alpha_coeff arrays), power-law absorption + "
+                                  f"nonlinear, p0 source, p_raw+p_max on one xy plane ({n * n} points)",
+                      "grid": [n, n, n], "fused_kernels": not args.granular, "fft": "rocFFT 3-D R2C/C2R",
+                      "device": info.name.decode(), "baseline_ref": "BASELINE.md: 49.72 ms/step, TITAN X, "
+                      "kspaceFirstOrder3D-CUDA v1.1 (manual Table C.4)", "input_generation_s": round(t_gen, 1)},
+           "roofline": roofline}
+    if not args.no_cpu:
+        out["cpu_baseline"] = cpu_baseline(pr, n)
+    print(json.dumps(out))
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -112,6 +112,18 @@ KW_API kw_status   kw_event_synchronize(kw_ctx* ctx, void* event);
 KW_API kw_status   kw_event_elapsed_ms(kw_ctx* ctx, void* start, void* stop, float* out_ms);
 KW_API kw_status   kw_event_destroy(kw_ctx* ctx, void* event);
 
+/* Per-entry-point device timing (HIP events around every kw_* compute call while enabled); used by bench.py to
+ * report kernel durations live.  The reference has only host wall-clock timers (Utils/TimeMeasure.h:90-123). */
+typedef struct kw_profile_entry
+{
+  char     name[64];
+  uint64_t calls;
+  double   total_ms;
+} kw_profile_entry;
+KW_API kw_status kw_profile_enable(kw_ctx* ctx, int on);
+/* synchronises, aggregates by entry-point name, clears the recorded events; *n_out = number of entries written */
+KW_API kw_status kw_profile_collect(kw_ctx* ctx, kw_profile_entry* out, size_t capacity, size_t* n_out);
+
 /* ------------------------------------------------------------------------------------------------------------------
  * Memory verbs — replace BaseFloatMatrix/BaseIndexMatrix allocate/copyToDevice/copyFromDevice/zeroDeviceMatrix
  * (MatrixClasses/BaseFloatMatrix.cpp:77-80,124-168; BaseIndexMatrix.cpp)

@@ -36,6 +36,19 @@ class Constants(C.Structure):
                                           "pressure_source_size", "pressure_source_mode", "pressure_source_many")]
 
 
+class ProfileEntry(C.Structure):
+    _fields_ = [("name", C.c_char * 64), ("calls", C.c_uint64), ("total_ms", C.c_double)]
+
+
+def profile_collect(ctx) -> Dict[str, tuple]:
+    """{entry point: (calls, total_ms)} since the last collect (kw_profile_collect)."""
+    L = load()
+    buf = (ProfileEntry * 64)()
+    n = C.c_size_t()
+    check(L.kw_profile_collect(ctx, buf, 64, C.byref(n)))
+    return {buf[i].name.decode(): (int(buf[i].calls), float(buf[i].total_ms)) for i in range(min(n.value, 64))}
+
+
 class DeviceInfo(C.Structure):
     _fields_ = [("name", C.c_char * 128), ("arch", C.c_char * 64), ("device_id", C.c_int32),
                 ("compute_units", C.c_int32), ("wavefront_size", C.c_int32), ("clock_mhz", C.c_int32),
@@ -64,6 +77,8 @@ _SIG: Dict[str, list] = {
     "kw_event_synchronize": [_P, _P],
     "kw_event_elapsed_ms": [_P, _P, _P, C.POINTER(C.c_float)],
     "kw_event_destroy": [_P, _P],
+    "kw_profile_enable": [_P, C.c_int],
+    "kw_profile_collect": [_P, _P, C.c_size_t, C.POINTER(C.c_size_t)],
     "kw_malloc": [_P, C.c_size_t, C.POINTER(_P)],
     "kw_free": [_P, _P],
     "kw_memcpy_h2d": [_P, _P, _P, C.c_size_t],
@@ -140,7 +155,7 @@ class DeviceArray:
 
     def __init__(self, dev: "Device", shape, dtype):
         self.dev = dev
-        self.shape = tuple(int(s) for s in shape)
+        self.shape = (int(shape),) if np.isscalar(shape) else tuple(int(s) for s in shape)
         self.dtype = np.dtype(dtype)
         self.nbytes = int(np.prod(self.shape)) * self.dtype.itemsize
         p = _P()

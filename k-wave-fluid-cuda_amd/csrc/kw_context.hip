@@ -4,6 +4,9 @@
 // MatrixClasses/BaseFloatMatrix.cpp:77-80,124-168.
 #include "kw_internal.h"
 
+#include <map>
+#include <string>
+
 static thread_local char g_err[1024] = "";
 
 void kw_set_error(const char* fmt, ...)
@@ -158,6 +161,49 @@ kw_status kw_event_destroy(kw_ctx* ctx, void* event)
 {
   KW_CHECK_CTX(ctx);
   KW_HIP(hipEventDestroy((hipEvent_t)event));
+  return KW_OK;
+}
+
+// ---- profiling -----------------------------------------------------------------------------------------------------
+kw_status kw_profile_enable(kw_ctx* ctx, int on)
+{
+  KW_CHECK_CTX(ctx);
+  ctx->profiling = (on != 0);
+  return KW_OK;
+}
+
+kw_status kw_profile_collect(kw_ctx* ctx, kw_profile_entry* out, size_t capacity, size_t* n_out)
+{
+  KW_CHECK_CTX(ctx);
+  KW_REQUIRE(n_out != nullptr);
+  KW_HIP(hipStreamSynchronize(ctx->stream));
+  std::map<std::string, std::pair<uint64_t, double>> agg;
+  for (auto& r : ctx->prof)
+  {
+    float ms = 0.0f;
+    if (hipEventElapsedTime(&ms, r.e0, r.e1) == hipSuccess)
+    {
+      auto& a = agg[r.name];
+      a.first++;
+      a.second += ms;
+    }
+    (void)hipEventDestroy(r.e0);
+    (void)hipEventDestroy(r.e1);
+  }
+  ctx->prof.clear();
+  size_t n = 0;
+  for (auto& kv : agg)
+  {
+    if (out != nullptr && n < capacity)
+    {
+      memset(&out[n], 0, sizeof(out[n]));
+      snprintf(out[n].name, sizeof(out[n].name), "%s", kv.first.c_str());
+      out[n].calls    = kv.second.first;
+      out[n].total_ms = kv.second.second;
+    }
+    n++;
+  }
+  *n_out = n;
   return KW_OK;
 }
 

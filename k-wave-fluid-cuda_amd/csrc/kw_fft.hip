@@ -181,6 +181,7 @@ kw_status kw_fft_destroy_plans(kw_ctx* ctx)
 kw_status kw_fft_r2c_3d(kw_ctx* ctx, const float* in, float* out)
 {
   KW_CHECK_CONSTS(ctx);
+  KW_PROF(ctx, "fft_r2c_3d");
   KW_REQUIRE(in != nullptr && out != nullptr);
   if (!ctx->r2c_3d.plan) { kw_set_error("kw_fft_r2c_3d: plans not created (kw_fft_create_plans_3d)"); return KW_ERR_STATE; }
   void* ib[1] = { (void*)in };
@@ -192,6 +193,7 @@ kw_status kw_fft_r2c_3d(kw_ctx* ctx, const float* in, float* out)
 kw_status kw_fft_c2r_3d(kw_ctx* ctx, float* in, float* out)
 {
   KW_CHECK_CONSTS(ctx);
+  KW_PROF(ctx, "fft_c2r_3d");
   KW_REQUIRE(in != nullptr && out != nullptr);
   if (!ctx->c2r_3d.plan) { kw_set_error("kw_fft_c2r_3d: plans not created (kw_fft_create_plans_3d)"); return KW_ERR_STATE; }
   void* ib[1] = { (void*)in };
@@ -203,6 +205,7 @@ kw_status kw_fft_c2r_3d(kw_ctx* ctx, float* in, float* out)
 kw_status kw_fft_r2c_1d(kw_ctx* ctx, int axis, const float* in, float* out)
 {
   KW_CHECK_CONSTS(ctx);
+  KW_PROF(ctx, "fft_r2c_1d");
   KW_REQUIRE(axis >= 0 && axis <= 2 && in != nullptr && out != nullptr);
   kw_fft_plan& p = ctx->r2c_1d[axis];
   if (!p.plan) { kw_set_error("kw_fft_r2c_1d: plan for axis %d not created", axis); return KW_ERR_STATE; }
@@ -220,6 +223,7 @@ kw_status kw_fft_r2c_1d(kw_ctx* ctx, int axis, const float* in, float* out)
 kw_status kw_fft_c2r_1d(kw_ctx* ctx, int axis, float* in, float* out)
 {
   KW_CHECK_CONSTS(ctx);
+  KW_PROF(ctx, "fft_c2r_1d");
   KW_REQUIRE(axis >= 0 && axis <= 2 && in != nullptr && out != nullptr);
   kw_fft_plan& p = ctx->c2r_1d[axis];
   if (!p.plan) { kw_set_error("kw_fft_c2r_1d: plan for axis %d not created", axis); return KW_ERR_STATE; }

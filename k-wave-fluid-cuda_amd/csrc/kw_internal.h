@@ -8,6 +8,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <vector>
 
 #include "kwave_hip.h"
 
@@ -32,7 +33,33 @@ struct kw_ctx
   kw_fft_plan  r2c_1d[3], c2r_1d[3];
   void*        fft_work       = nullptr; // one shared work buffer, sized for the largest plan
   size_t       fft_work_bytes = 0;
+  // profiling (kw_profile_enable)
+  struct prof_rec { const char* name; hipEvent_t e0, e1; };
+  bool                  profiling = false;
+  std::vector<prof_rec> prof;
 };
+
+// RAII: records a HIP event pair around one entry point while profiling is on
+struct kw_prof_scope
+{
+  kw_ctx* ctx;
+  size_t  idx;
+  bool    on;
+  kw_prof_scope(kw_ctx* c, const char* name) : ctx(c), idx(0), on(c && c->profiling)
+  {
+    if (!on) return;
+    kw_ctx::prof_rec r{name, nullptr, nullptr};
+    if (hipEventCreate(&r.e0) != hipSuccess || hipEventCreate(&r.e1) != hipSuccess) { on = false; return; }
+    (void)hipEventRecord(r.e0, ctx->stream);
+    idx = ctx->prof.size();
+    ctx->prof.push_back(r);
+  }
+  ~kw_prof_scope()
+  {
+    if (on) (void)hipEventRecord(ctx->prof[idx].e1, ctx->stream);
+  }
+};
+#define KW_PROF(ctx, name) kw_prof_scope kw_prof_scope_(ctx, name)
 
 // thread-local error text (kw_last_error)
 void kw_set_error(const char* fmt, ...) __attribute__((format(printf, 1, 2)));

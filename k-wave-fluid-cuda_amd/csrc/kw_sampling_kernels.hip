@@ -94,6 +94,7 @@ extern "C" {
 kw_status kw_sample_index(kw_ctx* ctx, kw_reduce_op op, float* buf, const float* src, const uint64_t* mask, uint64_t n)
 {
   KW_CHECK_CTX(ctx);
+  KW_PROF(ctx, "sample_index");
   if (n == 0) return KW_OK;
   KW_REQUIRE(buf && src && mask);
   DISPATCH_OP(op, k_sample_index, dim3(sampler_grid(ctx, n)), buf, src, mask, n);
@@ -104,6 +105,7 @@ kw_status kw_sample_cuboid(kw_ctx* ctx, kw_reduce_op op, float* buf, const float
                            const uint32_t br[3], const uint32_t size[3], uint64_t n)
 {
   KW_CHECK_CTX(ctx);
+  KW_PROF(ctx, "sample_cuboid");
   if (n == 0) return KW_OK;
   KW_REQUIRE(buf && src && tl && br && size);
   KW_REQUIRE(br[0] >= tl[0] && br[1] >= tl[1] && br[2] >= tl[2]);
@@ -120,6 +122,7 @@ kw_status kw_sample_cuboid(kw_ctx* ctx, kw_reduce_op op, float* buf, const float
 kw_status kw_sample_all(kw_ctx* ctx, kw_reduce_op op, float* buf, const float* src, uint64_t n)
 {
   KW_CHECK_CTX(ctx);
+  KW_PROF(ctx, "sample_all");
   if (n == 0) return KW_OK;
   KW_REQUIRE(buf && src);
   DISPATCH_OP(op, k_sample_all, dim3(sampler_grid(ctx, n)), buf, src, n);
@@ -129,6 +132,7 @@ kw_status kw_sample_all(kw_ctx* ctx, kw_reduce_op op, float* buf, const float* s
 kw_status kw_post_processing_rms(kw_ctx* ctx, float* buf, float scale, uint64_t n)
 {
   KW_CHECK_CTX(ctx);
+  KW_PROF(ctx, "post_processing_rms");
   if (n == 0) return KW_OK;
   KW_REQUIRE(buf);
   LAUNCH(k_post_rms, dim3(sampler_grid(ctx, n)), dim3(256), buf, scale, n);

@@ -676,6 +676,7 @@ static kw_status density_impl(kw_ctx* ctx, float* rx, float* ry, float* rz, cons
                               const float* rho0)
 {
   KW_CHECK_CONSTS(ctx);
+  KW_PROF(ctx, kNonlinear ? "compute_density_nonlinear" : "compute_density_linear");
   KW_REQUIRE(rx && ry && rz && pmlx && pmly && pmlz && dux && duy && duz);
   const kw_constants& c = ctx->c;
   const bool v4 = (c.nx % 4 == 0) && all_aligned16(rx, ry, rz, dux, duy, duz, rho0, pmlx);
@@ -701,6 +702,7 @@ kw_status kw_compute_velocity(kw_ctx* ctx, float* ux, float* uy, float* uz, cons
                               const float* pmlx, const float* pmly, const float* pmlz)
 {
   KW_CHECK_CONSTS(ctx);
+  KW_PROF(ctx, "compute_velocity");
   KW_REQUIRE(ux && uy && uz && gx && gy && gz && pmlx && pmly && pmlz);
   const bool het = (dx_ != nullptr);
   KW_REQUIRE(het ? (dy_ != nullptr && dz_ != nullptr) : (dy_ == nullptr && dz_ == nullptr));
@@ -725,6 +727,7 @@ kw_status kw_add_transducer_source(kw_ctx* ctx, float* ux, const uint64_t* index
                                    const uint64_t* delay, uint64_t t)
 {
   KW_CHECK_CONSTS(ctx);
+  KW_PROF(ctx, "add_transducer_source");
   const uint32_t n = ctx->c.velocity_source_size;
   if (n == 0) return KW_OK;
   KW_REQUIRE(ux && index && input && delay);
@@ -735,6 +738,7 @@ kw_status kw_add_transducer_source(kw_ctx* ctx, float* ux, const uint64_t* index
 kw_status kw_add_velocity_source(kw_ctx* ctx, float* u, const float* input, const uint64_t* index, uint64_t t)
 {
   KW_CHECK_CONSTS(ctx);
+  KW_PROF(ctx, "add_velocity_source");
   const uint32_t n = ctx->c.velocity_source_size;
   if (n == 0) return KW_OK;
   KW_REQUIRE(u && input && index);
@@ -747,6 +751,7 @@ kw_status kw_add_pressure_source(kw_ctx* ctx, float* rx, float* ry, float* rz, c
                                  const uint64_t* index, uint64_t t)
 {
   KW_CHECK_CONSTS(ctx);
+  KW_PROF(ctx, "add_pressure_source");
   const uint32_t n = ctx->c.pressure_source_size;
   if (n == 0) return KW_OK;
   KW_REQUIRE(rx && ry && rz && input && index);
@@ -759,6 +764,7 @@ kw_status kw_insert_source_into_scaling_matrix(kw_ctx* ctx, float* scaled, const
                                                uint64_t n, int many, uint64_t t)
 {
   KW_CHECK_CONSTS(ctx);
+  KW_PROF(ctx, "insert_source_into_scaling_matrix");
   if (n == 0) return KW_OK;
   KW_REQUIRE(scaled && input && index);
   LAUNCH(k_insert_source, grid1d(n), dim3(256), n, many, scaled, input, index, t);
@@ -768,6 +774,7 @@ kw_status kw_insert_source_into_scaling_matrix(kw_ctx* ctx, float* scaled, const
 kw_status kw_compute_source_gradient(kw_ctx* ctx, float* S, const float* sk)
 {
   KW_CHECK_CONSTS(ctx);
+  KW_PROF(ctx, "compute_source_gradient");
   KW_REQUIRE(S && sk);
   const kw_constants& c = ctx->c;
   if ((c.n_elements_complex % 2 == 0) && all_aligned16(S) && ((reinterpret_cast<uintptr_t>(sk) & 7u) == 0))
@@ -780,6 +787,7 @@ kw_status kw_compute_source_gradient(kw_ctx* ctx, float* S, const float* sk)
 kw_status kw_add_velocity_scaled_source(kw_ctx* ctx, float* u, const float* scaled)
 {
   KW_CHECK_CONSTS(ctx);
+  KW_PROF(ctx, "add_velocity_scaled_source");
   KW_REQUIRE(u && scaled);
   const kw_constants& c = ctx->c;
   if (c.n_elements % 4 == 0 && all_aligned16(u, scaled))
@@ -792,6 +800,7 @@ kw_status kw_add_velocity_scaled_source(kw_ctx* ctx, float* u, const float* scal
 kw_status kw_add_pressure_scaled_source(kw_ctx* ctx, float* rx, float* ry, float* rz, const float* scaled)
 {
   KW_CHECK_CONSTS(ctx);
+  KW_PROF(ctx, "add_pressure_scaled_source");
   KW_REQUIRE(rx && ry && rz && scaled);
   const kw_constants& c = ctx->c;
   if (c.n_elements % 4 == 0 && all_aligned16(rx, ry, rz, scaled))
@@ -805,6 +814,7 @@ kw_status kw_add_initial_pressure_source(kw_ctx* ctx, float* p, float* rx, float
                                          const float* c2)
 {
   KW_CHECK_CONSTS(ctx);
+  KW_PROF(ctx, "add_initial_pressure_source");
   KW_REQUIRE(p && rx && ry && rz && p0);
   const kw_constants& c = ctx->c;
   const bool v4 = c.n_elements % 4 == 0 && all_aligned16(p, rx, ry, rz, p0, c2);
@@ -826,6 +836,7 @@ kw_status kw_compute_initial_velocity(kw_ctx* ctx, float* ux, float* uy, float* 
                                       const float* dy_, const float* dz_)
 {
   KW_CHECK_CONSTS(ctx);
+  KW_PROF(ctx, "compute_initial_velocity");
   KW_REQUIRE(ux && uy && uz);
   const bool het = (dx_ != nullptr);
   KW_REQUIRE(het ? (dy_ != nullptr && dz_ != nullptr) : (dy_ == nullptr && dz_ == nullptr));
@@ -851,6 +862,7 @@ kw_status kw_compute_pressure_gradient(kw_ctx* ctx, float* X, float* Y, float* Z
                                        const float* ddx, const float* ddy, const float* ddz)
 {
   KW_CHECK_CONSTS(ctx);
+  KW_PROF(ctx, "compute_pressure_gradient");
   KW_REQUIRE(X && Y && Z && kappa && ddx && ddy && ddz);
   const kw_constants& c = ctx->c;
   const uint32_t plane  = c.nx_complex * c.ny;
@@ -867,6 +879,7 @@ kw_status kw_compute_velocity_gradient(kw_ctx* ctx, float* X, float* Y, float* Z
                                        const float* ddx, const float* ddy, const float* ddz)
 {
   KW_CHECK_CONSTS(ctx);
+  KW_PROF(ctx, "compute_velocity_gradient");
   KW_REQUIRE(X && Y && Z && kappa && ddx && ddy && ddz);
   const kw_constants& c = ctx->c;
   const uint32_t plane  = c.nx_complex * c.ny;
@@ -897,6 +910,7 @@ kw_status kw_compute_pressure_terms_nonlinear(kw_ctx* ctx, float* densitySum, fl
                                               const float* duy, const float* duz, const float* bona, const float* rho0)
 {
   KW_CHECK_CONSTS(ctx);
+  KW_PROF(ctx, "compute_pressure_terms_nonlinear");
   KW_REQUIRE(densitySum && nonlinearTerm && velGradSum && rx && ry && rz && dux && duy && duz);
   const kw_constants& c = ctx->c;
   const bool v4 = c.n_elements % 4 == 0 && all_aligned16(densitySum, nonlinearTerm, velGradSum, rx, ry, rz, dux, duy, duz, bona, rho0);
@@ -921,6 +935,7 @@ kw_status kw_compute_pressure_terms_linear(kw_ctx* ctx, float* densitySum, float
                                            const float* duz, const float* rho0)
 {
   KW_CHECK_CONSTS(ctx);
+  KW_PROF(ctx, "compute_pressure_terms_linear");
   KW_REQUIRE(densitySum && velGradSum && rx && ry && rz && dux && duy && duz);
   const kw_constants& c = ctx->c;
   const bool v4 = c.n_elements % 4 == 0 && all_aligned16(densitySum, velGradSum, rx, ry, rz, dux, duy, duz, rho0);
@@ -941,6 +956,7 @@ kw_status kw_compute_pressure_terms_linear(kw_ctx* ctx, float* densitySum, float
 kw_status kw_compute_absorbtion_term(kw_ctx* ctx, float* A, float* B, const float* n1, const float* n2)
 {
   KW_CHECK_CONSTS(ctx);
+  KW_PROF(ctx, "compute_absorbtion_term");
   KW_REQUIRE(A && B && n1 && n2);
   const kw_constants& c = ctx->c;
   const bool p2 = (c.n_elements_complex % 2 == 0) && all_aligned16(A, B) &&
@@ -954,6 +970,7 @@ static kw_status sum_terms_impl(kw_ctx* ctx, float* p, const float* first, const
                                 const float* c2, const float* tau, const float* eta)
 {
   KW_CHECK_CONSTS(ctx);
+  KW_PROF(ctx, "sum_pressure_terms");
   KW_REQUIRE(p && first && tauTerm && etaTerm);
   KW_REQUIRE((tau == nullptr) == (eta == nullptr));
   const kw_constants& c = ctx->c;
@@ -989,6 +1006,7 @@ kw_status kw_sum_pressure_nonlinear_lossless(kw_ctx* ctx, float* p, const float*
                                              const float* c2, const float* bona, const float* rho0)
 {
   KW_CHECK_CONSTS(ctx);
+  KW_PROF(ctx, "sum_pressure_nonlinear_lossless");
   KW_REQUIRE(p && rx && ry && rz);
   const kw_constants& c = ctx->c;
   const bool v4 = c.n_elements % 4 == 0 && all_aligned16(p, rx, ry, rz, c2, bona, rho0);
@@ -1011,6 +1029,7 @@ kw_status kw_sum_pressure_linear_lossless(kw_ctx* ctx, float* p, const float* rx
                                           const float* c2)
 {
   KW_CHECK_CONSTS(ctx);
+  KW_PROF(ctx, "sum_pressure_linear_lossless");
   KW_REQUIRE(p && rx && ry && rz);
   const kw_constants& c = ctx->c;
   const bool v4 = c.n_elements % 4 == 0 && all_aligned16(p, rx, ry, rz, c2);
@@ -1031,6 +1050,7 @@ kw_status kw_sum_pressure_linear_lossless(kw_ctx* ctx, float* p, const float* rx
 kw_status kw_compute_velocity_shift(kw_ctx* ctx, int axis, float* spectrum, const float* shift)
 {
   KW_CHECK_CONSTS(ctx);
+  KW_PROF(ctx, "compute_velocity_shift");
   KW_REQUIRE(axis >= 0 && axis <= 2 && spectrum && shift);
   const kw_constants& c = ctx->c;
   const uint32_t ox = (axis == 0) ? c.nx / 2 + 1 : c.nx;
