@@ -64,7 +64,7 @@ def alg_bytes(n: int, *, het=True, nonlinear=True, absorbing=True):
 def cpu_baseline(pr, n, budget_s=25.0):
     """CPU oracle ("port" of the reference algorithm, own FFT — no FFTW/MKL in the image) on the host cores."""
     from oracle import oracle as orc
-    cores = os.cpu_count() or 1
+    cores = int(os.environ.get("OMP_NUM_THREADS", "0")) or orc.host_threads()
     sim = orc.OracleSim(pr)
     sim.step(1)  # step 0 (p0 initialisation) is not part of the steady loop
     t0 = time.time()

@@ -1,0 +1,851 @@
+// kw_fused.hip — the MI355X-fused spectral pipeline: hand-written 3-D FFT passes with the element-wise physics
+// folded into them.  This is the fast path of the per-step loop; it computes exactly the stages of
+// KSpaceFirstOrderSolver::computeVelocity / computeVelocityGradient / computeDensity* / computePressure*
+// (KSpaceSolver/KSpaceFirstOrderSolver.cpp:2087-2245) with the arithmetic of the SolverCudaKernels.cu lines cited at
+// each epilogue, but organised around memory traffic instead of around one kernel per MATLAB statement:
+//
+//   x-forward   real rows -> half-spectrum rows (two real rows ride one complex FFT)          R  -> C
+//   y-pass      in-place complex FFT along y on 16-column tiles (128-B segments)              C <-> C
+//   z-fused     forward FFT along z, spectral multiply (kappa*ddk, nabla, sourceKappa), inverse FFT along z,
+//               all in registers/LDS — the spectrum never makes a round trip to HBM            C  -> C (x1..3)
+//   y-pass^-1   in-place inverse along y
+//   x-inverse   half-spectrum rows -> real rows + epilogue: velocity update / density update (+ pressure terms) /
+//               pressure sum — the gradients never exist in HBM as separate arrays
+//
+// vs. the reference order (14 library FFTs + 7 element-wise kernels, each a full HBM round trip).
+// Internal spectral scratch is private to the pipeline: rows are padded to a multiple of 16 complex (128 B) so every
+// tile access is line-aligned; kappa/nabla operators are imported once into the same padded layout.
+// Supported: Nx, Ny, Nz powers of two in [16, 1024] (k-Wave's recommended grid sizes), Ny*Nz % 32 == 0; anything else
+// uses the rocFFT path (kw_fft.hip + kw_solver_kernels.hip).
+#include "kw_fft_device.h"
+#include "kw_internal.h"
+
+#include <cmath>
+#include <vector>
+
+using namespace kwfft;
+
+namespace {
+
+constexpr int NL = 16; // lines per tile (16 complex = 128 B segments)
+
+constexpr int cmax(int a, int b) { return a > b ? a : b; }
+
+template<int L> struct Geo
+{
+  static constexpr int R1 = Fac<L>::R1, R2 = Fac<L>::R2;
+  static constexpr int TPL     = cmax(R1, R2);
+  static constexpr int THREADS = NL * TPL;
+  // y/z passes: LDS[k1][n2][c]; +16 complex per k1 block keeps the step-B reads conflict-free
+  static constexpr int PADB    = 16;
+  static constexpr int SF      = R2 * NL + PADB; // stride per k1 (forward / standalone inverse)
+  static constexpr int SI      = R1 * NL + PADB; // stride per q1 (inverse started from registers)
+  static constexpr int LDSB    = cmax(R1 * SF, R2 * SI);
+  // x passes: LDS[c][k1][n2] (pitch LP per line) aliased with a natural-order line buffer (pitch ZP)
+  static constexpr int LP0  = R1 * (R2 + 1);
+  static constexpr int LP   = LP0 + ((16 - LP0 % 32) + 32) % 32;
+  static constexpr int ZP   = L + 16;
+  static constexpr int LDSX = NL * cmax(LP, ZP);
+};
+
+// ---- register-level steps -------------------------------------------------------------------------------------------
+template<int L, int DIR> __device__ __forceinline__ void step_a(float2 (&v)[Fac<L>::R1], int n2, const float2* __restrict__ tw)
+{
+  Dft<Fac<L>::R1, DIR>::run(v);
+#pragma unroll
+  for (int k1 = 1; k1 < Fac<L>::R1; k1++) v[k1] = apply_tw<DIR>(v[k1], tw[n2 * k1]);
+}
+
+// =====================================================================================================================
+// y-pass: in-place complex FFT along y (stride P) for tile (z = blockIdx.y, kx tile = blockIdx.x), array blockIdx.z
+// =====================================================================================================================
+struct PassArgs
+{
+  float2*       s[3];
+  const float2* tw;
+  uint32_t      nxc, P, ny, nz;
+};
+
+template<int L, int DIR> __global__ __launch_bounds__(Geo<L>::THREADS) void k_ypass(PassArgs a)
+{
+  using G = Geo<L>;
+  constexpr int R1 = G::R1, R2 = G::R2;
+  __shared__ float2 lds[G::LDSB];
+  float2* __restrict__ S = a.s[blockIdx.z];
+  const int      c     = threadIdx.x % NL;
+  const int      j     = threadIdx.x / NL;
+  const uint32_t kx    = blockIdx.x * NL + c;
+  const bool     valid = kx < a.nxc;
+  const size_t   base  = static_cast<size_t>(blockIdx.y) * L * a.P + kx;
+  if (j < R2)
+  {
+    float2 v[R1];
+#pragma unroll
+    for (int n1 = 0; n1 < R1; n1++)
+      v[n1] = valid ? S[base + static_cast<size_t>(n1 * R2 + j) * a.P] : make_float2(0.f, 0.f);
+    step_a<L, DIR>(v, j, a.tw);
+#pragma unroll
+    for (int k1 = 0; k1 < R1; k1++) lds[k1 * G::SF + j * NL + c] = v[k1];
+  }
+  __syncthreads();
+  if (j < R1)
+  {
+    float2 w[R2];
+#pragma unroll
+    for (int n2 = 0; n2 < R2; n2++) w[n2] = lds[j * G::SF + n2 * NL + c];
+    Dft<R2, DIR>::run(w);
+    if (valid)
+    {
+#pragma unroll
+      for (int k2 = 0; k2 < R2; k2++) S[base + static_cast<size_t>(j + R1 * k2) * a.P] = w[k2];
+    }
+  }
+}
+
+// =====================================================================================================================
+// z-fused: forward along z, spectral multiply, inverse along z.  Tile (y = blockIdx.y, kx tile = blockIdx.x).
+// =====================================================================================================================
+enum ZMode { Z_PGRAD = 0, Z_VGRAD = 1, Z_ABSORB = 2, Z_SOURCE = 3 };
+
+struct ZArgs
+{
+  const float2* in[3];
+  float2*       out[3];
+  const float*  op[2];  // padded reduced real operators: kappa (PGRAD/VGRAD), nabla1/nabla2 (ABSORB), sourceKappa
+  const float2* dd[3];  // ddx[kx], ddy[ky], ddz[kz]
+  const float2* tw;
+  float         divider;
+  uint32_t      nxc, P, ny, nz;
+};
+
+// inverse along the line, started from the step-B register layout (thread (c,k1) holds X[k1 + R1*k2]); result:
+// thread (c,q1) holds x[q1 + R2*q2], q2 < R1 — returned in v
+template<int L>
+__device__ __forceinline__ void inverse_from_regs(float2 (&w)[Fac<L>::R2], float2 (&v)[Fac<L>::R1], float2* lds, int c,
+                                                  int j, const float2* __restrict__ tw)
+{
+  using G = Geo<L>;
+  constexpr int R1 = G::R1, R2 = G::R2;
+  if (j < R1)
+  {
+    Dft<R2, kInv>::run(w);
+#pragma unroll
+    for (int q1 = 0; q1 < R2; q1++)
+    {
+      const float2 t = (q1 == 0) ? w[0] : apply_tw<kInv>(w[q1], tw[j * q1]);
+      lds[q1 * G::SI + j * NL + c] = t;
+    }
+  }
+  __syncthreads();
+  if (j < R2)
+  {
+#pragma unroll
+    for (int k1 = 0; k1 < R1; k1++) v[k1] = lds[j * G::SI + k1 * NL + c];
+    Dft<R1, kInv>::run(v);
+  }
+}
+
+template<int L, int MODE> __global__ __launch_bounds__(Geo<L>::THREADS) void k_zfused(ZArgs a)
+{
+  using G = Geo<L>;
+  constexpr int R1 = G::R1, R2 = G::R2;
+  __shared__ float2 lds[G::LDSB];
+  const int      c      = threadIdx.x % NL;
+  const int      j      = threadIdx.x / NL;
+  const uint32_t kx     = blockIdx.x * NL + c;
+  const uint32_t ky     = blockIdx.y;
+  const bool     valid  = kx < a.nxc;
+  const size_t   zstr   = static_cast<size_t>(a.ny) * a.P;
+  const size_t   base   = static_cast<size_t>(ky) * a.P + kx;
+  const uint32_t arr    = (MODE == Z_VGRAD || MODE == Z_ABSORB) ? blockIdx.z : 0;
+  const float2* __restrict__ in = a.in[arr];
+
+  if (j < R2)
+  {
+    float2 v[R1];
+#pragma unroll
+    for (int n1 = 0; n1 < R1; n1++)
+      v[n1] = valid ? in[base + static_cast<size_t>(n1 * R2 + j) * zstr] : make_float2(0.f, 0.f);
+    step_a<L, kFwd>(v, j, a.tw);
+#pragma unroll
+    for (int k1 = 0; k1 < R1; k1++) lds[k1 * G::SF + j * NL + c] = v[k1];
+  }
+  __syncthreads();
+  float2 X[R2];
+  if (j < R1)
+  {
+#pragma unroll
+    for (int n2 = 0; n2 < R2; n2++) X[n2] = lds[j * G::SF + n2 * NL + c];
+    Dft<R2, kFwd>::run(X);
+  }
+  __syncthreads(); // forward exchange buffer is free again
+
+  constexpr int NOUT = (MODE == Z_PGRAD) ? 3 : 1;
+  // spectral operators for the elements this thread holds: kz = j + R1*k2
+  float kap[R2];
+  if (j < R1)
+  {
+    const float* __restrict__ op = a.op[(MODE == Z_ABSORB) ? arr : 0];
+#pragma unroll
+    for (int k2 = 0; k2 < R2; k2++)
+      kap[k2] = valid ? op[base + static_cast<size_t>(j + R1 * k2) * zstr] : 0.f;
+  }
+#pragma unroll
+  for (int o = 0; o < NOUT; o++)
+  {
+    float2 w[R2];
+    if (j < R1)
+    {
+      if (MODE == Z_PGRAD)
+      { // SolverCudaKernels.cu:1149-1155: e = X*kappa; out = e (x) dd{x,y,z}_pos
+        const float2 dxy = (o == 0) ? (valid ? a.dd[0][kx] : make_float2(0.f, 0.f)) : a.dd[1][ky];
+#pragma unroll
+        for (int k2 = 0; k2 < R2; k2++)
+        {
+          const float2 e = make_float2(X[k2].x * kap[k2], X[k2].y * kap[k2]);
+          const float2 d = (o == 2) ? a.dd[2][j + R1 * k2] : dxy;
+          w[k2]          = cmulf(e, d);
+        }
+      }
+      else if (MODE == Z_VGRAD)
+      { // :1220-1236: (X * (kappa*divider)) (x) dd_neg of this array's own axis
+        const float2 dxy = (arr == 0) ? (valid ? a.dd[0][kx] : make_float2(0.f, 0.f)) : a.dd[1][ky];
+#pragma unroll
+        for (int k2 = 0; k2 < R2; k2++)
+        {
+          const float  ek = kap[k2] * a.divider;
+          const float2 e  = make_float2(X[k2].x * ek, X[k2].y * ek);
+          const float2 d  = (arr == 2) ? a.dd[2][j + R1 * k2] : dxy;
+          w[k2]           = cmulf(e, d);
+        }
+      }
+      else if (MODE == Z_ABSORB)
+      { // :1817-1818: X *= nabla
+#pragma unroll
+        for (int k2 = 0; k2 < R2; k2++) w[k2] = make_float2(X[k2].x * kap[k2], X[k2].y * kap[k2]);
+      }
+      else
+      { // Z_SOURCE :742-744: S *= sourceKappa * divider
+#pragma unroll
+        for (int k2 = 0; k2 < R2; k2++)
+        {
+          const float s = kap[k2] * a.divider;
+          w[k2]         = make_float2(X[k2].x * s, X[k2].y * s);
+        }
+      }
+    }
+    float2 v[R1];
+    inverse_from_regs<L>(w, v, lds, c, j, a.tw);
+    if (j < R2 && valid)
+    {
+      float2* __restrict__ out = a.out[(MODE == Z_PGRAD) ? o : arr];
+#pragma unroll
+      for (int q2 = 0; q2 < R1; q2++) out[base + static_cast<size_t>(j + R2 * q2) * zstr] = v[q2];
+    }
+    if (o + 1 < NOUT) __syncthreads(); // exchange buffer reused by the next output
+  }
+}
+
+// =====================================================================================================================
+// x-forward: two real rows per complex line -> two half-spectrum rows
+// =====================================================================================================================
+struct XfwdArgs
+{
+  const float*  in[3];
+  float2*       out[3];
+  const float2* tw;
+  uint32_t      nx, P;
+};
+
+template<int L> __global__ __launch_bounds__(Geo<L>::THREADS) void k_xfwd(XfwdArgs a)
+{
+  using G = Geo<L>;
+  constexpr int R1 = G::R1, R2 = G::R2, HALF = L / 2 + 1;
+  __shared__ float2 lds[G::LDSX];
+  const int    f   = threadIdx.x % G::TPL;
+  const int    c   = threadIdx.x / G::TPL;
+  const float* __restrict__ in = a.in[blockIdx.y];
+  const size_t row0 = (static_cast<size_t>(blockIdx.x) * NL + c) * 2;
+  if (f < R2)
+  {
+    float2 v[R1];
+    const float* __restrict__ ra = in + row0 * L;
+    const float* __restrict__ rb = ra + L;
+#pragma unroll
+    for (int n1 = 0; n1 < R1; n1++) v[n1] = make_float2(ra[n1 * R2 + f], rb[n1 * R2 + f]);
+    step_a<L, kFwd>(v, f, a.tw);
+#pragma unroll
+    for (int k1 = 0; k1 < R1; k1++) lds[c * G::LP + k1 * (R2 + 1) + f] = v[k1];
+  }
+  __syncthreads();
+  float2 w[R2];
+  if (f < R1)
+  {
+#pragma unroll
+    for (int n2 = 0; n2 < R2; n2++) w[n2] = lds[c * G::LP + f * (R2 + 1) + n2];
+    Dft<R2, kFwd>::run(w);
+  }
+  __syncthreads();
+  if (f < R1)
+  {
+#pragma unroll
+    for (int k2 = 0; k2 < R2; k2++) lds[c * G::ZP + f + R1 * k2] = w[k2];
+  }
+  __syncthreads();
+  float2* __restrict__ out = a.out[blockIdx.y];
+  const size_t tile_row0 = static_cast<size_t>(blockIdx.x) * NL * 2;
+  for (int e = threadIdx.x; e < NL * HALF; e += G::THREADS)
+  {
+    const int    cc = e / HALF;
+    const int    k  = e - cc * HALF;
+    const float2 zk = lds[cc * G::ZP + k];
+    const float2 zn = lds[cc * G::ZP + ((L - k) & (L - 1))];
+    const float2 xa = make_float2(0.5f * (zk.x + zn.x), 0.5f * (zk.y - zn.y));
+    const float2 xb = make_float2(0.5f * (zk.y + zn.y), 0.5f * (zn.x - zk.x));
+    const size_t r  = tile_row0 + 2 * cc;
+    out[r * a.P + k]       = xa;
+    out[(r + 1) * a.P + k] = xb;
+  }
+}
+
+// =====================================================================================================================
+// x-inverse + epilogue
+// =====================================================================================================================
+enum Epi { EPI_STORE = 0, EPI_VELOCITY = 1, EPI_INITVEL = 2, EPI_DENSITY = 3, EPI_PSUM = 4 };
+
+struct XinvArgs
+{
+  const float2* in[3];
+  const float2* tw;
+  kw_constants  c;
+  uint32_t      P;
+  // EPI_STORE: out[0]; EPI_VELOCITY/INITVEL: u[3], dtrho[3] (NULL -> scalar), pml[3]
+  // EPI_DENSITY: rho[3] in/out, pml[3], rho0, bona, du[3] (optional store), t[3] terms outputs, flags
+  // EPI_PSUM: p, first, c2, tau, eta
+  float*        out[3];
+  const float*  m0[3]; // dtrho / (rho0, bona, -) / (first, c2, -)
+  const float*  m1[3]; // pml / (tau, eta, -)
+  float*        aux[3]; // du stores / -
+  float*        t[3];  // pressure-term outputs
+  int           nonlinear;
+  int           terms; // 0 none, 1 linear (t0 = sum rho, t1 = rho0*sum du), 2 nonlinear (t0, t1 = nonlinear term, t2)
+};
+
+// standalone inverse of one array for this block's 32 rows; thread (c, f<R1) ends with x[f + R1*k2] of rows (2c, 2c+1)
+template<int L>
+__device__ __forceinline__ void xinv_lines(const float2* __restrict__ src, uint32_t P, float2* lds, int c, int f,
+                                           const float2* __restrict__ tw, float2 (&w)[Fac<L>::R2])
+{
+  using G = Geo<L>;
+  constexpr int R1 = G::R1, R2 = G::R2, HALF = L / 2 + 1;
+  const size_t tile_row0 = static_cast<size_t>(blockIdx.x) * NL * 2;
+  for (int e = threadIdx.x; e < NL * HALF; e += G::THREADS)
+  {
+    const int    cc = e / HALF;
+    const int    k  = e - cc * HALF;
+    const size_t r  = tile_row0 + 2 * cc;
+    float2       A  = src[r * P + k];
+    float2       B  = src[(r + 1) * P + k];
+    if (k == 0 || k == L / 2) { A.y = 0.f; B.y = 0.f; } // C2R ignores the imaginary part of DC / Nyquist
+    lds[cc * G::ZP + k] = make_float2(A.x - B.y, A.y + B.x);
+    if (k != 0 && k != L / 2) lds[cc * G::ZP + L - k] = make_float2(A.x + B.y, B.x - A.y);
+  }
+  __syncthreads();
+  float2 v[R1];
+  if (f < R2)
+  {
+#pragma unroll
+    for (int n1 = 0; n1 < R1; n1++) v[n1] = lds[c * G::ZP + n1 * R2 + f];
+  }
+  __syncthreads();
+  if (f < R2)
+  {
+    step_a<L, kInv>(v, f, tw);
+#pragma unroll
+    for (int k1 = 0; k1 < R1; k1++) lds[c * G::LP + k1 * (R2 + 1) + f] = v[k1];
+  }
+  __syncthreads();
+  if (f < R1)
+  {
+#pragma unroll
+    for (int n2 = 0; n2 < R2; n2++) w[n2] = lds[c * G::LP + f * (R2 + 1) + n2];
+    Dft<R2, kInv>::run(w);
+  }
+  __syncthreads();
+}
+
+template<int L, int EPI> __global__ __launch_bounds__(Geo<L>::THREADS) void k_xinv(XinvArgs a)
+{
+  using G = Geo<L>;
+  constexpr int R1 = G::R1, R2 = G::R2;
+  constexpr int NA = (EPI == EPI_DENSITY) ? 3 : (EPI == EPI_PSUM) ? 2 : 1;
+  __shared__ float2 lds[G::LDSX];
+  const int f = threadIdx.x % G::TPL;
+  const int c = threadIdx.x / G::TPL;
+  const uint32_t comp = (NA == 1) ? blockIdx.y : 0; // component / array index for single-array epilogues
+  float2 res[NA][R2];
+#pragma unroll
+  for (int i = 0; i < NA; i++) xinv_lines<L>(a.in[(NA == 1) ? comp : i], a.P, lds, c, f, a.tw, res[i]);
+  if (f >= R1) return;
+
+  const kw_constants& k = a.c;
+  const size_t   row0 = (static_cast<size_t>(blockIdx.x) * NL + c) * 2;
+  const uint32_t z    = static_cast<uint32_t>(row0 / k.ny);
+  const uint32_t y0   = static_cast<uint32_t>(row0 - static_cast<size_t>(z) * k.ny);
+#pragma unroll
+  for (int k2 = 0; k2 < R2; k2++)
+  {
+    const uint32_t x = f + R1 * k2;
+#pragma unroll
+    for (int h = 0; h < 2; h++)
+    {
+      const size_t   i = (row0 + h) * L + x;
+      const uint32_t y = y0 + h;
+      if (EPI == EPI_STORE)
+      {
+        a.out[comp][i] = h ? res[0][k2].y : res[0][k2].x;
+      }
+      else if (EPI == EPI_VELOCITY)
+      { // SolverCudaKernels.cu:199-212 (heterogeneous) / :287-305 (homogeneous)
+        const float g    = h ? res[0][k2].y : res[0][k2].x;
+        const float pml  = (comp == 0) ? a.m1[0][x] : (comp == 1) ? a.m1[1][y] : a.m1[2][z];
+        float*      u    = a.out[comp];
+        float       e;
+        if (a.m0[comp] != nullptr) e = k.fft_divider * g * a.m0[comp][i];
+        else
+        {
+          const float dtr = (comp == 0) ? k.dt_rho0_sgx : (comp == 1) ? k.dt_rho0_sgy : k.dt_rho0_sgz;
+          e               = (dtr * k.fft_divider) * g;
+        }
+        u[i] = (u[i] * pml - e) * pml;
+      }
+      else if (EPI == EPI_INITVEL)
+      { // :957-980: u = ifft * (dtRho0Sg * (fftDivider*0.5)) | u = ifft * (fftDivider*0.5*dtRho0Sg)
+        const float g = h ? res[0][k2].y : res[0][k2].x;
+        float*      u = a.out[comp];
+        if (a.m0[comp] != nullptr) u[i] = g * (a.m0[comp][i] * (k.fft_divider * 0.5f));
+        else
+        {
+          const float dtr = (comp == 0) ? k.dt_rho0_sgx : (comp == 1) ? k.dt_rho0_sgy : k.dt_rho0_sgz;
+          u[i]            = g * (k.fft_divider * 0.5f * dtr);
+        }
+      }
+      else if (EPI == EPI_DENSITY)
+      { // :1368-1392 (nonlinear) / :1480-1496 (linear); du already carries fftDivider (applied in k-space, :1220)
+        const float dux = h ? res[0][k2].y : res[0][k2].x;
+        const float duy = h ? res[1][k2].y : res[1][k2].x;
+        const float duz = h ? res[2][k2].y : res[2][k2].x;
+        const float px = a.m1[0][x], py = a.m1[1][y], pz = a.m1[2][z];
+        const float rx = a.out[0][i], ry = a.out[1][i], rz = a.out[2][i];
+        const float r0 = (a.m0[0] != nullptr) ? a.m0[0][i] : k.rho0;
+        float nrx, nry, nrz;
+        if (a.nonlinear)
+        {
+          const float sumRhosDt = (2.0f * (rx + ry + rz) + r0) * k.dt;
+          nrx = px * ((px * rx) - sumRhosDt * dux);
+          nry = py * ((py * ry) - sumRhosDt * duy);
+          nrz = pz * ((pz * rz) - sumRhosDt * duz);
+        }
+        else
+        {
+          const float dtRho0 = (a.m0[0] != nullptr) ? k.dt * r0 : k.dt_rho0;
+          nrx = px * (px * rx - dtRho0 * dux);
+          nry = py * (py * ry - dtRho0 * duy);
+          nrz = pz * (pz * rz - dtRho0 * duz);
+        }
+        a.out[0][i] = nrx;
+        a.out[1][i] = nry;
+        a.out[2][i] = nrz;
+        if (a.aux[0] != nullptr)
+        {
+          a.aux[0][i] = dux;
+          a.aux[1][i] = duy;
+          a.aux[2][i] = duz;
+        }
+        if (a.terms == 2)
+        { // :1588-1601 with the updated densities
+          const float eBonA   = (a.m0[1] != nullptr) ? a.m0[1][i] : k.b_on_a;
+          const float eRhoSum = (nrx + nry + nrz);
+          const float eDuSum  = (dux + duy + duz);
+          a.t[0][i] = eRhoSum;
+          a.t[1][i] = ((eBonA * eRhoSum * eRhoSum) / (2.0f * r0)) + eRhoSum;
+          a.t[2][i] = r0 * eDuSum;
+        }
+        else if (a.terms == 1)
+        { // :1733-1741
+          a.t[0][i]         = nrx + nry + nrz;
+          const float duSum = dux + duy + duz;
+          a.t[1][i]         = r0 * duSum;
+        }
+      }
+      else if (EPI == EPI_PSUM)
+      { // :1877 / :1978: p = c2*(first + (fftDivider*((tauTerm*tau) - (etaTerm*eta))))
+        const float tt  = h ? res[0][k2].y : res[0][k2].x;
+        const float et  = h ? res[1][k2].y : res[1][k2].x;
+        const float c2  = (a.m0[1] != nullptr) ? a.m0[1][i] : k.c2;
+        const float tau = (a.m1[0] != nullptr) ? a.m1[0][i] : k.absorb_tau;
+        const float eta = (a.m1[1] != nullptr) ? a.m1[1][i] : k.absorb_eta;
+        a.out[0][i]     = c2 * (a.m0[0][i] + (k.fft_divider * ((tt * tau) - (et * eta))));
+      }
+    }
+  }
+}
+
+// padded import of a reduced real operator: dst[z][y][P] <- src[z][y][nxc]
+__global__ void k_import_reduced(float* __restrict__ dst, const float* __restrict__ src, uint32_t nxc, uint32_t P,
+                                 uint32_t rows)
+{
+  const uint32_t x = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t r = blockIdx.y;
+  if (x >= P || r >= rows) return;
+  dst[static_cast<size_t>(r) * P + x] = (x < nxc) ? src[static_cast<size_t>(r) * nxc + x] : 0.f;
+}
+
+// ---- host side ------------------------------------------------------------------------------------------------------
+bool supported_len(uint32_t n) { return n == 16 || n == 32 || n == 64 || n == 128 || n == 256 || n == 512 || n == 1024; }
+
+// dispatch on a runtime power-of-two length
+#define KW_LEN_SWITCH(len, MACRO)                                                                                      \
+  switch (len)                                                                                                         \
+  {                                                                                                                    \
+    case 16: MACRO(16); break;                                                                                         \
+    case 32: MACRO(32); break;                                                                                         \
+    case 64: MACRO(64); break;                                                                                         \
+    case 128: MACRO(128); break;                                                                                       \
+    case 256: MACRO(256); break;                                                                                       \
+    case 512: MACRO(512); break;                                                                                       \
+    case 1024: MACRO(1024); break;                                                                                     \
+    default: kw_set_error("fused pipeline: unsupported length %u", (unsigned)(len)); return KW_ERR_INVALID;            \
+  }
+
+#define LAUNCH(kernel, grid, block, ...)                                                                               \
+  do {                                                                                                                 \
+    hipLaunchKernelGGL(kernel, grid, block, 0, ctx->stream, __VA_ARGS__);                                              \
+    KW_LAUNCH_CHECK();                                                                                                 \
+  } while (0)
+
+kw_status launch_xfwd(kw_ctx* ctx, int narr, const float* const* in, float2* const* out)
+{
+  const kw_constants& c = ctx->c;
+  XfwdArgs a{};
+  for (int i = 0; i < narr; i++) { a.in[i] = in[i]; a.out[i] = out[i]; }
+  a.tw = ctx->fused.tw[0];
+  a.nx = c.nx;
+  a.P  = ctx->fused.P;
+  const dim3 grid(c.ny * c.nz / (2 * NL), narr, 1);
+#define M(LEN) LAUNCH((k_xfwd<LEN>), grid, dim3(Geo<LEN>::THREADS), a)
+  KW_LEN_SWITCH(c.nx, M)
+#undef M
+  return KW_OK;
+}
+
+kw_status launch_ypass(kw_ctx* ctx, int dir, int narr, float2* const* s)
+{
+  const kw_constants& c = ctx->c;
+  PassArgs a{};
+  for (int i = 0; i < narr; i++) a.s[i] = s[i];
+  a.tw  = ctx->fused.tw[1];
+  a.nxc = c.nx_complex;
+  a.P   = ctx->fused.P;
+  a.ny  = c.ny;
+  a.nz  = c.nz;
+  const dim3 grid(ctx->fused.P / NL, c.nz, narr);
+#define M(LEN)                                                                                                         \
+  if (dir < 0) LAUNCH((k_ypass<LEN, kFwd>), grid, dim3(Geo<LEN>::THREADS), a);                                         \
+  else LAUNCH((k_ypass<LEN, kInv>), grid, dim3(Geo<LEN>::THREADS), a)
+  KW_LEN_SWITCH(c.ny, M)
+#undef M
+  return KW_OK;
+}
+
+template<int MODE> kw_status launch_zfused(kw_ctx* ctx, int narr, ZArgs a)
+{
+  const kw_constants& c = ctx->c;
+  a.tw      = ctx->fused.tw[2];
+  a.divider = c.fft_divider;
+  a.nxc     = c.nx_complex;
+  a.P       = ctx->fused.P;
+  a.ny      = c.ny;
+  a.nz      = c.nz;
+  const dim3 grid(ctx->fused.P / NL, c.ny, narr);
+#define M(LEN) LAUNCH((k_zfused<LEN, MODE>), grid, dim3(Geo<LEN>::THREADS), a)
+  KW_LEN_SWITCH(c.nz, M)
+#undef M
+  return KW_OK;
+}
+
+template<int EPI> kw_status launch_xinv(kw_ctx* ctx, int ncomp, XinvArgs a)
+{
+  const kw_constants& c = ctx->c;
+  a.tw = ctx->fused.tw[0];
+  a.c  = c;
+  a.P  = ctx->fused.P;
+  const dim3 grid(c.ny * c.nz / (2 * NL), ncomp, 1);
+#define M(LEN) LAUNCH((k_xinv<LEN, EPI>), grid, dim3(Geo<LEN>::THREADS), a)
+  KW_LEN_SWITCH(c.nx, M)
+#undef M
+  return KW_OK;
+}
+
+#define KW_FUSED_READY(ctx)                                                                                            \
+  do {                                                                                                                 \
+    KW_CHECK_CONSTS(ctx);                                                                                              \
+    if (!(ctx)->fused.ready) { kw_set_error("%s: kw_fused_create has not been called", __func__); return KW_ERR_STATE; } \
+  } while (0)
+
+#define KW_TRY(call)                                                                                                   \
+  do {                                                                                                                 \
+    kw_status st_ = (call);                                                                                            \
+    if (st_ != KW_OK) return st_;                                                                                      \
+  } while (0)
+
+} // namespace
+
+extern "C" {
+
+kw_status kw_fused_supported(kw_ctx* ctx, int* out)
+{
+  KW_CHECK_CONSTS(ctx);
+  KW_REQUIRE(out != nullptr);
+  const kw_constants& c = ctx->c;
+  *out = supported_len(c.nx) && supported_len(c.ny) && supported_len(c.nz) && ((c.ny * c.nz) % (2 * NL) == 0);
+  return KW_OK;
+}
+
+kw_status kw_fused_destroy(kw_ctx* ctx)
+{
+  KW_CHECK_CTX(ctx);
+  if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+  for (int i = 0; i < 3; i++)
+  {
+    if (ctx->fused.s[i]) (void)hipFree(ctx->fused.s[i]);
+    if (ctx->fused.tw[i]) (void)hipFree(ctx->fused.tw[i]);
+    ctx->fused.s[i]  = nullptr;
+    ctx->fused.tw[i] = nullptr;
+  }
+  ctx->fused.ready = false;
+  return KW_OK;
+}
+
+kw_status kw_fused_create(kw_ctx* ctx)
+{
+  KW_CHECK_CONSTS(ctx);
+  int ok = 0;
+  kw_fused_supported(ctx, &ok);
+  if (!ok) { kw_set_error("kw_fused_create: grid %ux%ux%u is not supported by the fused pipeline", ctx->c.nx, ctx->c.ny, ctx->c.nz); return KW_ERR_INVALID; }
+  kw_fused_destroy(ctx);
+  KW_HIP(hipSetDevice(ctx->device));
+  const kw_constants& c = ctx->c;
+  ctx->fused.P          = (c.nx_complex + NL - 1) / NL * NL;
+  const size_t elems    = static_cast<size_t>(ctx->fused.P) * c.ny * c.nz;
+  for (int i = 0; i < 3; i++)
+  {
+    KW_HIP(hipMalloc(reinterpret_cast<void**>(&ctx->fused.s[i]), elems * sizeof(float2)));
+    KW_HIP(hipMemsetAsync(ctx->fused.s[i], 0, elems * sizeof(float2), ctx->stream));
+  }
+  const uint32_t lens[3] = { c.nx, c.ny, c.nz };
+  for (int i = 0; i < 3; i++)
+  {
+    std::vector<float2> tw(lens[i]);
+    for (uint32_t m = 0; m < lens[i]; m++)
+    {
+      const double ph = -2.0 * M_PI * static_cast<double>(m) / static_cast<double>(lens[i]);
+      tw[m]           = make_float2(static_cast<float>(std::cos(ph)), static_cast<float>(std::sin(ph)));
+    }
+    KW_HIP(hipMalloc(reinterpret_cast<void**>(&ctx->fused.tw[i]), lens[i] * sizeof(float2)));
+    KW_HIP(hipMemcpyAsync(ctx->fused.tw[i], tw.data(), lens[i] * sizeof(float2), hipMemcpyHostToDevice, ctx->stream));
+    KW_HIP(hipStreamSynchronize(ctx->stream));
+  }
+  ctx->fused.ready = true;
+  return KW_OK;
+}
+
+kw_status kw_fused_reduced_elems(kw_ctx* ctx, size_t* out)
+{
+  KW_FUSED_READY(ctx);
+  KW_REQUIRE(out != nullptr);
+  *out = static_cast<size_t>(ctx->fused.P) * ctx->c.ny * ctx->c.nz;
+  return KW_OK;
+}
+
+kw_status kw_fused_import_reduced(kw_ctx* ctx, float* dst_padded, const float* src)
+{
+  KW_FUSED_READY(ctx);
+  KW_REQUIRE(dst_padded && src);
+  const kw_constants& c = ctx->c;
+  const uint32_t rows   = c.ny * c.nz;
+  KW_REQUIRE(rows <= 0x7fffffffu);
+  // rows on grid.y can exceed 65535: loop in chunks
+  for (uint32_t r0 = 0; r0 < rows; r0 += 32768)
+  {
+    const uint32_t n = (rows - r0 < 32768u) ? rows - r0 : 32768u;
+    LAUNCH(k_import_reduced, dim3((ctx->fused.P + 255) / 256, n), dim3(256),
+           dst_padded + static_cast<size_t>(r0) * ctx->fused.P, src + static_cast<size_t>(r0) * c.nx_complex,
+           c.nx_complex, ctx->fused.P, n);
+  }
+  return KW_OK;
+}
+
+// A1-A4: u <- pml_sg*(pml_sg*u - dt/rho0_sg * ifftn(ddk_pos * kappa * fftn(p)) / N)
+kw_status kw_fused_velocity(kw_ctx* ctx, const float* p, float* ux, float* uy, float* uz, const float* dtx,
+                            const float* dty, const float* dtz, const float* pmlx, const float* pmly, const float* pmlz,
+                            const float* kappa_padded, const float* ddx, const float* ddy, const float* ddz)
+{
+  KW_FUSED_READY(ctx);
+  KW_PROF(ctx, "fused_velocity");
+  KW_REQUIRE(p && ux && uy && uz && pmlx && pmly && pmlz && kappa_padded && ddx && ddy && ddz);
+  KW_REQUIRE((dtx == nullptr) == (dty == nullptr) && (dtx == nullptr) == (dtz == nullptr));
+  float2** S = ctx->fused.s;
+  const float* in1[1] = { p };
+  KW_TRY(launch_xfwd(ctx, 1, in1, S));
+  KW_TRY(launch_ypass(ctx, -1, 1, S));
+  ZArgs z{};
+  z.in[0] = S[0];
+  for (int i = 0; i < 3; i++) z.out[i] = S[i];
+  z.op[0] = kappa_padded;
+  z.dd[0] = (const float2*)ddx; z.dd[1] = (const float2*)ddy; z.dd[2] = (const float2*)ddz;
+  KW_TRY(launch_zfused<Z_PGRAD>(ctx, 1, z));
+  KW_TRY(launch_ypass(ctx, +1, 3, S));
+  XinvArgs x{};
+  float* u[3] = { ux, uy, uz };
+  const float* dt[3] = { dtx, dty, dtz };
+  const float* pml[3] = { pmlx, pmly, pmlz };
+  for (int i = 0; i < 3; i++) { x.in[i] = S[i]; x.out[i] = u[i]; x.m0[i] = dt[i]; x.m1[i] = pml[i]; }
+  KW_TRY(launch_xinv<EPI_VELOCITY>(ctx, 3, x));
+  return KW_OK;
+}
+
+// A12 second half: u <- +0.5*dt/rho0_sg * ifftn(ddk_pos * kappa * fftn(p)) / N
+kw_status kw_fused_initial_velocity(kw_ctx* ctx, const float* p, float* ux, float* uy, float* uz, const float* dtx,
+                                    const float* dty, const float* dtz, const float* kappa_padded, const float* ddx,
+                                    const float* ddy, const float* ddz)
+{
+  KW_FUSED_READY(ctx);
+  KW_PROF(ctx, "fused_initial_velocity");
+  KW_REQUIRE(p && ux && uy && uz && kappa_padded && ddx && ddy && ddz);
+  float2** S = ctx->fused.s;
+  const float* in1[1] = { p };
+  KW_TRY(launch_xfwd(ctx, 1, in1, S));
+  KW_TRY(launch_ypass(ctx, -1, 1, S));
+  ZArgs z{};
+  z.in[0] = S[0];
+  for (int i = 0; i < 3; i++) z.out[i] = S[i];
+  z.op[0] = kappa_padded;
+  z.dd[0] = (const float2*)ddx; z.dd[1] = (const float2*)ddy; z.dd[2] = (const float2*)ddz;
+  KW_TRY(launch_zfused<Z_PGRAD>(ctx, 1, z));
+  KW_TRY(launch_ypass(ctx, +1, 3, S));
+  XinvArgs x{};
+  float* u[3] = { ux, uy, uz };
+  const float* dt[3] = { dtx, dty, dtz };
+  for (int i = 0; i < 3; i++) { x.in[i] = S[i]; x.out[i] = u[i]; x.m0[i] = dt[i]; }
+  KW_TRY(launch_xinv<EPI_INITVEL>(ctx, 3, x));
+  return KW_OK;
+}
+
+// A6-A9 (+ the term kernels of A11 when terms != 0): du = ifftn(ddk_neg*kappa*fftn(u))/N; rho update; pressure terms
+kw_status kw_fused_density(kw_ctx* ctx, int nonlinear, const float* ux, const float* uy, const float* uz, float* rx,
+                           float* ry, float* rz, const float* pmlx, const float* pmly, const float* pmlz,
+                           const float* rho0, const float* kappa_padded, const float* ddx, const float* ddy,
+                           const float* ddz, float* duxdx, float* duydy, float* duzdz, int terms, const float* bona,
+                           float* t0, float* t1, float* t2)
+{
+  KW_FUSED_READY(ctx);
+  KW_PROF(ctx, "fused_density");
+  KW_REQUIRE(ux && uy && uz && rx && ry && rz && pmlx && pmly && pmlz && kappa_padded && ddx && ddy && ddz);
+  KW_REQUIRE((duxdx == nullptr) == (duydy == nullptr) && (duxdx == nullptr) == (duzdz == nullptr));
+  KW_REQUIRE(terms >= 0 && terms <= 2);
+  KW_REQUIRE(terms == 0 || (t0 && t1 && (terms == 1 || t2)));
+  float2** S = ctx->fused.s;
+  const float* in3[3] = { ux, uy, uz };
+  KW_TRY(launch_xfwd(ctx, 3, in3, S));
+  KW_TRY(launch_ypass(ctx, -1, 3, S));
+  ZArgs z{};
+  for (int i = 0; i < 3; i++) { z.in[i] = S[i]; z.out[i] = S[i]; }
+  z.op[0] = kappa_padded;
+  z.dd[0] = (const float2*)ddx; z.dd[1] = (const float2*)ddy; z.dd[2] = (const float2*)ddz;
+  KW_TRY(launch_zfused<Z_VGRAD>(ctx, 3, z));
+  KW_TRY(launch_ypass(ctx, +1, 3, S));
+  XinvArgs x{};
+  float* rho[3] = { rx, ry, rz };
+  const float* pml[3] = { pmlx, pmly, pmlz };
+  float* du[3] = { duxdx, duydy, duzdz };
+  float* t[3] = { t0, t1, t2 };
+  for (int i = 0; i < 3; i++) { x.in[i] = S[i]; x.out[i] = rho[i]; x.m1[i] = pml[i]; x.aux[i] = du[i]; x.t[i] = t[i]; }
+  x.m0[0]     = rho0;
+  x.m0[1]     = bona;
+  x.nonlinear = nonlinear;
+  x.terms     = terms;
+  KW_TRY(launch_xinv<EPI_DENSITY>(ctx, 1, x));
+  return KW_OK;
+}
+
+// A11 absorbing branch after the terms: p = c2*(first + d*(tau*ifftn(nabla1*fftn(vel_grad_term)) - eta*ifftn(nabla2*fftn(density_sum))))
+kw_status kw_fused_absorption_pressure(kw_ctx* ctx, float* p, const float* vel_grad_term, const float* density_sum,
+                                       const float* first, const float* nabla1_padded, const float* nabla2_padded,
+                                       const float* c2, const float* tau, const float* eta)
+{
+  KW_FUSED_READY(ctx);
+  KW_PROF(ctx, "fused_absorption_pressure");
+  KW_REQUIRE(p && vel_grad_term && density_sum && first && nabla1_padded && nabla2_padded);
+  KW_REQUIRE((tau == nullptr) == (eta == nullptr));
+  float2** S = ctx->fused.s;
+  const float* in2[2] = { vel_grad_term, density_sum };
+  KW_TRY(launch_xfwd(ctx, 2, in2, S));
+  KW_TRY(launch_ypass(ctx, -1, 2, S));
+  ZArgs z{};
+  for (int i = 0; i < 2; i++) { z.in[i] = S[i]; z.out[i] = S[i]; }
+  z.op[0] = nabla1_padded;
+  z.op[1] = nabla2_padded;
+  KW_TRY(launch_zfused<Z_ABSORB>(ctx, 2, z));
+  KW_TRY(launch_ypass(ctx, +1, 2, S));
+  XinvArgs x{};
+  x.in[0] = S[0]; x.in[1] = S[1];
+  x.out[0] = p;
+  x.m0[0] = first; x.m0[1] = c2;
+  x.m1[0] = tau;   x.m1[1] = eta;
+  KW_TRY(launch_xinv<EPI_PSUM>(ctx, 1, x));
+  return KW_OK;
+}
+
+// scaleSource body (KSpaceFirstOrderSolver.cpp:2346-2351): scaled <- ifftn(sourceKappa*fftn(scaled))/N, in place
+kw_status kw_fused_scale_source(kw_ctx* ctx, float* scaled, const float* source_kappa_padded)
+{
+  KW_FUSED_READY(ctx);
+  KW_PROF(ctx, "fused_scale_source");
+  KW_REQUIRE(scaled && source_kappa_padded);
+  float2** S = ctx->fused.s;
+  const float* in1[1] = { scaled };
+  KW_TRY(launch_xfwd(ctx, 1, in1, S));
+  KW_TRY(launch_ypass(ctx, -1, 1, S));
+  ZArgs z{};
+  z.in[0] = S[0]; z.out[0] = S[0];
+  z.op[0] = source_kappa_padded;
+  KW_TRY(launch_zfused<Z_SOURCE>(ctx, 1, z));
+  KW_TRY(launch_ypass(ctx, +1, 1, S));
+  XinvArgs x{};
+  x.in[0] = S[0];
+  x.out[0] = scaled;
+  KW_TRY(launch_xinv<EPI_STORE>(ctx, 1, x));
+  return KW_OK;
+}
+
+// plain transforms on the fused path (testing / generic use): unnormalised, reference layout in and out
+kw_status kw_fused_fft_roundtrip(kw_ctx* ctx, const float* in, float* out)
+{
+  KW_FUSED_READY(ctx);
+  KW_REQUIRE(in && out);
+  float2** S = ctx->fused.s;
+  const float* in1[1] = { in };
+  KW_TRY(launch_xfwd(ctx, 1, in1, S));
+  KW_TRY(launch_ypass(ctx, -1, 1, S));
+  // z forward then z inverse through the fused kernel with unit operator is not available without an operator array;
+  // use two y-pass style launches along z instead: not needed by the solver, so the round trip exercises x and y only.
+  KW_TRY(launch_ypass(ctx, +1, 1, S));
+  XinvArgs x{};
+  x.in[0] = S[0];
+  x.out[0] = out;
+  KW_TRY(launch_xinv<EPI_STORE>(ctx, 1, x));
+  return KW_OK;
+}
+
+} // extern "C"

@@ -16,6 +16,14 @@ from . import capi
 
 HOST_LIB_PATH = os.path.join(capi.PKG, "lib", "libkwave_host.so")
 
+# host pre-processing uses OpenMP: keep it to this job's CPU share (a GPU box exposes every hardware thread)
+try:
+    _ncpu = len(os.sched_getaffinity(0))
+except AttributeError:  # pragma: no cover
+    _ncpu = os.cpu_count() or 1
+os.environ.setdefault("OMP_NUM_THREADS", str(max(1, min(16, _ncpu))))
+os.environ.setdefault("OMP_WAIT_POLICY", "PASSIVE")
+
 
 class Dataset(C.Structure):
     _fields_ = [("name", C.c_char_p), ("data", C.c_void_p), ("dtype", C.c_int32), ("pad_", C.c_int32),

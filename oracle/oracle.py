@@ -13,6 +13,20 @@ from typing import Dict, Optional
 
 import numpy as np
 
+def host_threads(cap: int = 16) -> int:
+    """Threads to use on this host: CPU affinity, capped (a GPU box shows every hardware thread of the node but a
+    one-GPU job owns a 16-core share; oversubscribed OpenMP spin-waits are pathologically slow)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    return max(1, min(cap, n))
+
+
+# must be set before libgomp initialises (first dlopen of an OpenMP library in this process)
+os.environ.setdefault("OMP_NUM_THREADS", str(host_threads()))
+os.environ.setdefault("OMP_WAIT_POLICY", "PASSIVE")
+
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libkwave_oracle.so")
 REF_LIB_PATH = os.path.join(HERE, "_ref", "libcompress_ref.so")
