@@ -250,6 +250,50 @@ KW_API kw_status kw_sum_pressure_linear_lossless(kw_ctx* ctx, float* p, const fl
 KW_API kw_status kw_compute_velocity_shift(kw_ctx* ctx, int axis, float* spectrum, const float* shift_neg_r);
 
 /* ------------------------------------------------------------------------------------------------------------------
+ * Fused spectral pipeline (MI355X fast path; csrc/kw_fused.hip).  Each entry computes one whole stage of the step —
+ * FFTs, spectral multiply and the real-space update — with hand-written FFT passes, so the gradients and spectra never
+ * make an HBM round trip as separate arrays.  Same arithmetic as the kernels cited; supported for Nx,Ny,Nz powers of
+ * two in [16,1024].  kappa / nabla / sourceKappa must first be imported into the pipeline's padded row layout.
+ * ---------------------------------------------------------------------------------------------------------------- */
+KW_API kw_status kw_fused_supported(kw_ctx* ctx, int* out_supported);
+KW_API kw_status kw_fused_create(kw_ctx* ctx);   /* scratch + twiddles; needs kw_set_constants */
+KW_API kw_status kw_fused_destroy(kw_ctx* ctx);
+KW_API kw_status kw_fused_reduced_elems(kw_ctx* ctx, size_t* out_floats);  /* floats of one padded reduced array */
+KW_API kw_status kw_fused_import_reduced(kw_ctx* ctx, float* dst_padded, const float* src_reduced);
+/* computeVelocity (KSpaceFirstOrderSolver.cpp:2087-2119): R2C(p), computePressureGradient (.cu:1139-1157), 3x C2R,
+ * computeVelocityHeterogeneous/HomogeneousUniform (.cu:184-215,278-308); dt_rho0_sg* NULL -> scalars */
+KW_API kw_status kw_fused_velocity(kw_ctx* ctx, const float* p, float* ux_sgx, float* uy_sgy, float* uz_sgz,
+                                   const float* dt_rho0_sgx, const float* dt_rho0_sgy, const float* dt_rho0_sgz,
+                                   const float* pml_x_sgx, const float* pml_y_sgy, const float* pml_z_sgz,
+                                   const float* kappa_padded, const float* ddx_k_shift_pos,
+                                   const float* ddy_k_shift_pos, const float* ddz_k_shift_pos);
+/* second half of addInitialPressureSource (KSpaceFirstOrderSolver.cpp:2368-2395; .cu:949-982) */
+KW_API kw_status kw_fused_initial_velocity(kw_ctx* ctx, const float* p, float* ux_sgx, float* uy_sgy, float* uz_sgz,
+                                           const float* dt_rho0_sgx, const float* dt_rho0_sgy,
+                                           const float* dt_rho0_sgz, const float* kappa_padded,
+                                           const float* ddx_k_shift_pos, const float* ddy_k_shift_pos,
+                                           const float* ddz_k_shift_pos);
+/* computeVelocityGradient + computeDensity{Nonlinear,Linear} (KSpaceFirstOrderSolver.cpp:2126-2173; .cu:1210-1239,
+ * 1358-1393, 1470-1497) and, when terms != 0, computePressureTerms{Linear(1),Nonlinear(2)} (.cu:1577-1602,1724-1742)
+ * on the updated densities.  duxdx..duzdz may be NULL (gradients not stored).  terms==1: t0 = sum rho,
+ * t1 = rho0 * sum du; terms==2: t0 = sum rho, t1 = nonlinear term, t2 = rho0 * sum du. */
+KW_API kw_status kw_fused_density(kw_ctx* ctx, int nonlinear, const float* ux_sgx, const float* uy_sgy,
+                                  const float* uz_sgz, float* rho_x, float* rho_y, float* rho_z, const float* pml_x,
+                                  const float* pml_y, const float* pml_z, const float* rho0,
+                                  const float* kappa_padded, const float* ddx_k_shift_neg,
+                                  const float* ddy_k_shift_neg, const float* ddz_k_shift_neg, float* duxdx,
+                                  float* duydy, float* duzdz, int terms, const float* b_on_a, float* t0, float* t1,
+                                  float* t2);
+/* absorbing branch of computePressure{Nonlinear,Linear} after the terms (KSpaceFirstOrderSolver.cpp:2196-2204,
+ * 2231-2239; .cu:1812-1820,1865-1879,1966-1980): first = nonlinear term or density sum */
+KW_API kw_status kw_fused_absorption_pressure(kw_ctx* ctx, float* p, const float* velocity_gradient_term,
+                                              const float* density_sum, const float* first,
+                                              const float* nabla1_padded, const float* nabla2_padded, const float* c2,
+                                              const float* absorb_tau, const float* absorb_eta);
+/* FFT part of scaleSource (KSpaceFirstOrderSolver.cpp:2346-2351; .cu:740-745), in place on scaled_source */
+KW_API kw_status kw_fused_scale_source(kw_ctx* ctx, float* scaled_source, const float* source_kappa_padded);
+
+/* ------------------------------------------------------------------------------------------------------------------
  * Sampling kernels — replace namespace OutputStreamsCudaKernels (OutputStreams/OutputStreamsCudaKernels.cuh:47-106)
  * ---------------------------------------------------------------------------------------------------------------- */
 /* sampleIndex<op> (.cuh:58-62, .cu:83-126) */

@@ -829,23 +829,4 @@ kw_status kw_fused_scale_source(kw_ctx* ctx, float* scaled, const float* source_
   return KW_OK;
 }
 
-// plain transforms on the fused path (testing / generic use): unnormalised, reference layout in and out
-kw_status kw_fused_fft_roundtrip(kw_ctx* ctx, const float* in, float* out)
-{
-  KW_FUSED_READY(ctx);
-  KW_REQUIRE(in && out);
-  float2** S = ctx->fused.s;
-  const float* in1[1] = { in };
-  KW_TRY(launch_xfwd(ctx, 1, in1, S));
-  KW_TRY(launch_ypass(ctx, -1, 1, S));
-  // z forward then z inverse through the fused kernel with unit operator is not available without an operator array;
-  // use two y-pass style launches along z instead: not needed by the solver, so the round trip exercises x and y only.
-  KW_TRY(launch_ypass(ctx, +1, 1, S));
-  XinvArgs x{};
-  x.in[0] = S[0];
-  x.out[0] = out;
-  KW_TRY(launch_xinv<EPI_STORE>(ctx, 1, x));
-  return KW_OK;
-}
-
 } // extern "C"

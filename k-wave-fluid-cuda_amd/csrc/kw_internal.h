@@ -33,6 +33,14 @@ struct kw_ctx
   kw_fft_plan  r2c_1d[3], c2r_1d[3];
   void*        fft_work       = nullptr; // one shared work buffer, sized for the largest plan
   size_t       fft_work_bytes = 0;
+  // fused spectral pipeline (kw_fused.hip): private padded spectral scratch + per-axis twiddle tables
+  struct fused_plan
+  {
+    bool     ready = false;
+    uint32_t P     = 0;                            // padded half-spectrum row pitch (complex), multiple of 16
+    float2*  s[3]  = {nullptr, nullptr, nullptr};  // three padded complex scratch arrays [nz][ny][P]
+    float2*  tw[3] = {nullptr, nullptr, nullptr};  // exp(-2 pi i m / n) for n = nx, ny, nz
+  } fused;
   // profiling (kw_profile_enable)
   struct prof_rec { const char* name; hipEvent_t e0, e1; };
   bool                  profiling = false;
