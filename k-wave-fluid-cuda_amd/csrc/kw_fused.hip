@@ -502,7 +502,7 @@ __global__ void k_import_reduced(float* __restrict__ dst, const float* __restric
 }
 
 // ---- host side ------------------------------------------------------------------------------------------------------
-bool supported_len(uint32_t n) { return n == 16 || n == 32 || n == 64 || n == 128 || n == 256 || n == 512 || n == 1024; }
+bool supported_len(uint32_t n) { return n == 16 || n == 32 || n == 64 || n == 128 || n == 256 || n == 512; }
 
 // dispatch on a runtime power-of-two length
 #define KW_LEN_SWITCH(len, MACRO)                                                                                      \
@@ -514,7 +514,6 @@ bool supported_len(uint32_t n) { return n == 16 || n == 32 || n == 64 || n == 12
     case 128: MACRO(128); break;                                                                                       \
     case 256: MACRO(256); break;                                                                                       \
     case 512: MACRO(512); break;                                                                                       \
-    case 1024: MACRO(1024); break;                                                                                     \
     default: kw_set_error("fused pipeline: unsupported length %u", (unsigned)(len)); return KW_ERR_INVALID;            \
   }
 

@@ -23,6 +23,7 @@ void KSpaceFirstOrderSolver::allocateMemory()
 
 void KSpaceFirstOrderSolver::freeMemory()
 {
+  releaseFusedPipeline();
   mOutputStreamContainer.freeStreams();
   mMatrixContainer.freeMatrices();
   HipFftComplexMatrix::destroyAllPlansAndStaticData();
@@ -38,8 +39,19 @@ void KSpaceFirstOrderSolver::loadInputData(const InputProvider& input)
 void KSpaceFirstOrderSolver::initializeFftPlans()
 { // KSpaceFirstOrderSolver.cpp:747-777
   const DimensionSizes dims = mParameters.getFullDimensionSizes();
-  HipFftComplexMatrix::createR2CFftPlanND(dims);
-  HipFftComplexMatrix::createC2RFftPlanND(dims);
+  kw_ctx* ctx = mParameters.getHipParameters().getContext();
+  int fusedOk = 0;
+  if (mParameters.getOptions().fusedKernels) kwCheck(kw_fused_supported(ctx, &fusedOk));
+  mFused = (fusedOk != 0);
+  if (mFused)
+  {
+    kwCheck(kw_fused_create(ctx)); // hand-written FFT passes: no library plans needed for the 3-D transforms
+  }
+  else
+  {
+    HipFftComplexMatrix::createR2CFftPlanND(dims);
+    HipFftComplexMatrix::createC2RFftPlanND(dims);
+  }
   if (mParameters.needsShiftedVelocity())
   {
     HipFftComplexMatrix::createR2CFftPlan1DX(dims);
@@ -57,6 +69,7 @@ void KSpaceFirstOrderSolver::prepare()
   mParameters.getHipParameters().setKernelConfiguration();
   mParameters.getHipParameters().setUpDeviceConstants(); // again: tau/eta scalars exist only after preProcessing
   mMatrixContainer.copyMatricesToDevice();               // KSpaceFirstOrderSolver.cpp:880
+  if (mFused) initializeFusedPipeline();
   // host twins of the big arrays are not needed during the loop
   for (auto& rec : mMatrixContainer.records())
     if (rec.second.matrixType != MatrixRecord::MatrixType::kIndex)
@@ -154,6 +167,20 @@ void KSpaceFirstOrderSolver::storeSensorData()
 // ---------------------------------------------------------------------------------------------------------------------
 template<SD sd> void KSpaceFirstOrderSolver::computeVelocity()
 { // :2087-2119
+  if (mFused)
+  {
+    const MatrixContainer& c = mMatrixContainer;
+    kwCheck(kw_fused_velocity(mParameters.getHipParameters().getContext(), getP().getDeviceData(),
+                              real(MI::kUxSgx).getDeviceData(), real(MI::kUySgy).getDeviceData(),
+                              real(MI::kUzSgz).getDeviceData(), c.realDeviceOrNull(MI::kDtRho0Sgx),
+                              c.realDeviceOrNull(MI::kDtRho0Sgy), c.realDeviceOrNull(MI::kDtRho0Sgz),
+                              real(MI::kPmlXSgx).getDeviceData(), real(MI::kPmlYSgy).getDeviceData(),
+                              real(MI::kPmlZSgz).getDeviceData(), mKappaPadded,
+                              c.getMatrix<ComplexMatrix>(MI::kDdxKShiftPosR).getDeviceData(),
+                              c.getMatrix<ComplexMatrix>(MI::kDdyKShiftPos).getDeviceData(),
+                              c.getMatrix<ComplexMatrix>(MI::kDdzKShiftPos).getDeviceData()));
+    return;
+  }
   getTempHipFftX().computeR2CFftND(getP());
   SolverHipKernels::computePressureGradient<sd>(mMatrixContainer);
   getTempHipFftX().computeC2RFftND(getTemp1RealND());
@@ -165,6 +192,7 @@ template<SD sd> void KSpaceFirstOrderSolver::computeVelocity()
 
 template<SD sd> void KSpaceFirstOrderSolver::computeVelocityGradient()
 { // :2126-2150
+  if (mFused) return; // folded into the density stage (kw_fused_density)
   getTempHipFftX().computeR2CFftND(real(MI::kUxSgx));
   getTempHipFftY().computeR2CFftND(real(MI::kUySgy));
   getTempHipFftZ().computeR2CFftND(real(MI::kUzSgz));
@@ -174,8 +202,44 @@ template<SD sd> void KSpaceFirstOrderSolver::computeVelocityGradient()
   getTempHipFftZ().computeC2RFftND(real(MI::kDuzdz));
 }
 
-template<SD sd> void KSpaceFirstOrderSolver::computeDensityNonliner() { SolverHipKernels::computeDensityNonlinear<sd>(mMatrixContainer); }
-template<SD sd> void KSpaceFirstOrderSolver::computeDensityLinear() { SolverHipKernels::computeDensityLinear<sd>(mMatrixContainer); }
+// fused: velocity gradient + density update (+ pressure terms when no pressure source sits between them this step)
+void KSpaceFirstOrderSolver::fusedDensity(bool nonlinear)
+{
+  const MatrixContainer& c = mMatrixContainer;
+  const bool absorbing     = mParameters.getAbsorbingFlag() != 0;
+  const bool pSourceActive = mParameters.getPressureSourceFlag() > mParameters.getTimeIndex();
+  mTermsFused              = absorbing && !pSourceActive;
+  const bool storeDu       = absorbing && pSourceActive; // the stand-alone terms kernel will need the gradients
+  const int  terms         = mTermsFused ? (nonlinear ? 2 : 1) : 0;
+  // aliasing of the temporaries as in :2184-2190 (nonlinear) / :2221-2225 (linear)
+  float* t0 = getTemp1RealND().getDeviceData();
+  float* t1 = getTemp2RealND().getDeviceData();
+  float* t2 = getTemp3RealND().getDeviceData();
+  kwCheck(kw_fused_density(mParameters.getHipParameters().getContext(), nonlinear ? 1 : 0,
+                           real(MI::kUxSgx).getDeviceData(), real(MI::kUySgy).getDeviceData(),
+                           real(MI::kUzSgz).getDeviceData(), real(MI::kRhoX).getDeviceData(),
+                           real(MI::kRhoY).getDeviceData(), real(MI::kRhoZ).getDeviceData(),
+                           real(MI::kPmlX).getDeviceData(), real(MI::kPmlY).getDeviceData(),
+                           real(MI::kPmlZ).getDeviceData(), c.realDeviceOrNull(MI::kRho0), mKappaPadded,
+                           c.getMatrix<ComplexMatrix>(MI::kDdxKShiftNegR).getDeviceData(),
+                           c.getMatrix<ComplexMatrix>(MI::kDdyKShiftNeg).getDeviceData(),
+                           c.getMatrix<ComplexMatrix>(MI::kDdzKShiftNeg).getDeviceData(),
+                           storeDu ? real(MI::kDuxdx).getDeviceData() : nullptr,
+                           storeDu ? real(MI::kDuydy).getDeviceData() : nullptr,
+                           storeDu ? real(MI::kDuzdz).getDeviceData() : nullptr, terms, c.realDeviceOrNull(MI::kBOnA),
+                           t0, t1, t2));
+}
+
+template<SD sd> void KSpaceFirstOrderSolver::computeDensityNonliner()
+{
+  if (mFused) fusedDensity(true);
+  else SolverHipKernels::computeDensityNonlinear<sd>(mMatrixContainer);
+}
+template<SD sd> void KSpaceFirstOrderSolver::computeDensityLinear()
+{
+  if (mFused) fusedDensity(false);
+  else SolverHipKernels::computeDensityLinear<sd>(mMatrixContainer);
+}
 
 template<SD sd> void KSpaceFirstOrderSolver::computePressureNonlinear()
 { // :2180-2210
@@ -186,7 +250,18 @@ template<SD sd> void KSpaceFirstOrderSolver::computePressureNonlinear()
     RealMatrix& velocityGradientSum = getTemp3RealND();
     RealMatrix& absorbTauTerm       = velocityGradientSum;
     RealMatrix& absorbEtaTerm       = densitySum;
-    SolverHipKernels::computePressureTermsNonlinear<sd>(densitySum, nonlinearTerm, velocityGradientSum, mMatrixContainer);
+    if (!(mFused && mTermsFused))
+      SolverHipKernels::computePressureTermsNonlinear<sd>(densitySum, nonlinearTerm, velocityGradientSum, mMatrixContainer);
+    if (mFused)
+    {
+      kwCheck(kw_fused_absorption_pressure(mParameters.getHipParameters().getContext(), getP().getDeviceData(),
+                                           velocityGradientSum.getDeviceData(), densitySum.getDeviceData(),
+                                           nonlinearTerm.getDeviceData(), mNabla1Padded, mNabla2Padded,
+                                           mMatrixContainer.realDeviceOrNull(MI::kC2),
+                                           mMatrixContainer.realDeviceOrNull(MI::kAbsorbTau),
+                                           mMatrixContainer.realDeviceOrNull(MI::kAbsorbEta)));
+      return;
+    }
     getTempHipFftX().computeR2CFftND(velocityGradientSum);
     getTempHipFftY().computeR2CFftND(densitySum);
     SolverHipKernels::computeAbsorbtionTerm(getTempHipFftX(), getTempHipFftY(), real(MI::kAbsorbNabla1), real(MI::kAbsorbNabla2));
@@ -208,7 +283,18 @@ template<SD sd> void KSpaceFirstOrderSolver::computePressureLinear()
     RealMatrix& velocityGradientTerm = getTemp2RealND();
     RealMatrix& absorbTauTerm        = getTemp2RealND();
     RealMatrix& absorbEtaTerm        = getTemp3RealND();
-    SolverHipKernels::computePressureTermsLinear<sd>(densitySum, velocityGradientTerm, mMatrixContainer);
+    if (!(mFused && mTermsFused))
+      SolverHipKernels::computePressureTermsLinear<sd>(densitySum, velocityGradientTerm, mMatrixContainer);
+    if (mFused)
+    {
+      kwCheck(kw_fused_absorption_pressure(mParameters.getHipParameters().getContext(), getP().getDeviceData(),
+                                           velocityGradientTerm.getDeviceData(), densitySum.getDeviceData(),
+                                           densitySum.getDeviceData(), mNabla1Padded, mNabla2Padded,
+                                           mMatrixContainer.realDeviceOrNull(MI::kC2),
+                                           mMatrixContainer.realDeviceOrNull(MI::kAbsorbTau),
+                                           mMatrixContainer.realDeviceOrNull(MI::kAbsorbEta)));
+      return;
+    }
     getTempHipFftX().computeR2CFftND(velocityGradientTerm);
     getTempHipFftY().computeR2CFftND(densitySum);
     SolverHipKernels::computeAbsorbtionTerm(getTempHipFftX(), getTempHipFftY(), real(MI::kAbsorbNabla1), real(MI::kAbsorbNabla2));
@@ -267,6 +353,11 @@ void KSpaceFirstOrderSolver::scaleSource(RealMatrix& scaledSource, const RealMat
 { // :2339-2352
   scaledSource.zeroDeviceMatrix();
   SolverHipKernels::insertSourceIntoScalingMatrix(scaledSource, sourceInput, sourceIndex, manyFlag);
+  if (mFused)
+  {
+    kwCheck(kw_fused_scale_source(mParameters.getHipParameters().getContext(), scaledSource.getDeviceData(), mSourceKappaPadded));
+    return;
+  }
   getTempHipFftX().computeR2CFftND(scaledSource);
   SolverHipKernels::computeSourceGradient(getTempHipFftX(), real(MI::kSourceKappa));
   getTempHipFftX().computeC2RFftND(scaledSource);
@@ -275,6 +366,18 @@ void KSpaceFirstOrderSolver::scaleSource(RealMatrix& scaledSource, const RealMat
 template<SD sd> void KSpaceFirstOrderSolver::addInitialPressureSource()
 { // :2359-2396
   SolverHipKernels::addInitialPressureSource<sd>(mMatrixContainer);
+  if (mFused)
+  {
+    const MatrixContainer& c = mMatrixContainer;
+    kwCheck(kw_fused_initial_velocity(mParameters.getHipParameters().getContext(), getP().getDeviceData(),
+                                      real(MI::kUxSgx).getDeviceData(), real(MI::kUySgy).getDeviceData(),
+                                      real(MI::kUzSgz).getDeviceData(), c.realDeviceOrNull(MI::kDtRho0Sgx),
+                                      c.realDeviceOrNull(MI::kDtRho0Sgy), c.realDeviceOrNull(MI::kDtRho0Sgz),
+                                      mKappaPadded, c.getMatrix<ComplexMatrix>(MI::kDdxKShiftPosR).getDeviceData(),
+                                      c.getMatrix<ComplexMatrix>(MI::kDdyKShiftPos).getDeviceData(),
+                                      c.getMatrix<ComplexMatrix>(MI::kDdzKShiftPos).getDeviceData()));
+    return;
+  }
   getTempHipFftX().computeR2CFftND(getP());
   SolverHipKernels::computePressureGradient<sd>(mMatrixContainer);
   getTempHipFftX().computeC2RFftND(real(MI::kUxSgx));
@@ -296,6 +399,45 @@ template<SD sd> void KSpaceFirstOrderSolver::computeShiftedVelocity()
   tempShift.computeR2CFft1DZ(real(MI::kUzSgz));
   SolverHipKernels::computeVelocityShiftInZ(tempShift, mMatrixContainer.getMatrix<ComplexMatrix>(MI::kZShiftNegR));
   tempShift.computeC2RFft1DZ(real(MI::kUzShifted));
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Fused pipeline set-up: the reduced operators are imported once into the pipeline's padded row layout
+// ---------------------------------------------------------------------------------------------------------------------
+float* KSpaceFirstOrderSolver::importPadded(MI idx)
+{
+  kw_ctx* ctx = mParameters.getHipParameters().getContext();
+  size_t  n   = 0;
+  kwCheck(kw_fused_reduced_elems(ctx, &n));
+  void* d = nullptr;
+  kwCheck(kw_malloc(ctx, n * sizeof(float), &d));
+  kwCheck(kw_fused_import_reduced(ctx, static_cast<float*>(d), real(idx).getDeviceData()));
+  return static_cast<float*>(d);
+}
+
+void KSpaceFirstOrderSolver::initializeFusedPipeline()
+{
+  mKappaPadded = importPadded(MI::kKappa);
+  if (mMatrixContainer.has(MI::kAbsorbNabla1))
+  {
+    mNabla1Padded = importPadded(MI::kAbsorbNabla1);
+    mNabla2Padded = importPadded(MI::kAbsorbNabla2);
+  }
+  if (mMatrixContainer.has(MI::kSourceKappa)) mSourceKappaPadded = importPadded(MI::kSourceKappa);
+}
+
+void KSpaceFirstOrderSolver::releaseFusedPipeline()
+{
+  kw_ctx* ctx = mParameters.getHipParameters().getContext();
+  if (!ctx) return;
+  float** bufs[] = { &mKappaPadded, &mNabla1Padded, &mNabla2Padded, &mSourceKappaPadded };
+  for (float** b : bufs)
+  {
+    if (*b) kw_free(ctx, *b);
+    *b = nullptr;
+  }
+  if (mFused) kw_fused_destroy(ctx);
+  mFused = false;
 }
 
 // ---------------------------------------------------------------------------------------------------------------------

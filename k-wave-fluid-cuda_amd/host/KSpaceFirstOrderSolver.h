@@ -46,6 +46,7 @@ class KSpaceFirstOrderSolver
   template<SD simulationDimension> void computeVelocityGradient();
   template<SD simulationDimension> void computeDensityNonliner();
   template<SD simulationDimension> void computeDensityLinear();
+  void fusedDensity(bool nonlinear);
   template<SD simulationDimension> void computePressureNonlinear();
   template<SD simulationDimension> void computePressureLinear();
   void addVelocitySource();
@@ -74,9 +75,20 @@ class KSpaceFirstOrderSolver
   HipFftComplexMatrix& getTempHipFftZ() { return fft(MI::kTempHipFftZ); }
 
  private:
+  // ---- MI355X fused spectral pipeline (Options::fusedKernels; csrc/kw_fused.hip) ----
+  void   initializeFusedPipeline();
+  void   releaseFusedPipeline();
+  float* importPadded(MI idx);
+
   MatrixContainer       mMatrixContainer;
   OutputStreamContainer mOutputStreamContainer;
   Parameters&           mParameters;
   bool                  mPrepared = false;
+  bool                  mFused    = false;   // fused pipeline active for this grid
+  bool                  mTermsFused = false; // pressure terms of this step already produced by the density stage
+  float*                mKappaPadded = nullptr;
+  float*                mNabla1Padded = nullptr;
+  float*                mNabla2Padded = nullptr;
+  float*                mSourceKappaPadded = nullptr;
 };
 #endif

@@ -88,6 +88,28 @@ def test_time_varying_sources(orc, syn, source, mode, many):
     assert max(errs.values()) < TOL, errs
 
 
+@pytest.mark.parametrize("source", ["p_source", "u_source"])
+@pytest.mark.parametrize("mode", [0, 2])
+def test_sources_on_fused_pipeline(orc, syn, source, mode):
+    """Power-of-two grid: the fused pipeline handles the k-space corrected additive source (scaleSource) and, with an
+    active pressure source, falls back to the stand-alone pressure-terms kernel after the injection."""
+    pr = syn.make_problem(32, heterogeneous=True, nonlinear=True, absorbing=True, source=source, source_mode=mode,
+                          source_many=1, nt=25, pml_size=4)
+    errs = compare(orc, pr, 40, fields=("p", "ux", "rhoz"), fused_kernels=True)  # 15 steps past the end of the signal
+    assert max(errs.values()) < TOL, errs
+
+
+def test_fused_mixed_power_of_two_dims(orc, syn):
+    """Nx != Ny != Nz (64 x 32 x 16): different line lengths per pass of the fused pipeline."""
+    for kw in (dict(nonlinear=True, absorbing=True), dict(nonlinear=False, absorbing=False)):
+        pr = syn.make_problem(64, 32, 16, heterogeneous=True, source="p0", pml_size=4, **kw)
+        errs = compare(orc, pr, 30, fused_kernels=True)
+        assert max(errs.values()) < TOL, (kw, errs)
+    pr = syn.make_problem(16, 64, 128, heterogeneous=False, nonlinear=False, absorbing=True, source="p0", pml_size=4)
+    errs = compare(orc, pr, 30, fused_kernels=True)
+    assert max(errs.values()) < TOL, errs
+
+
 def test_transducer_source(orc, syn):
     pr = syn.make_problem(24, heterogeneous=True, nonlinear=True, absorbing=True, source="transducer", nt=40,
                           pml_size=4)
