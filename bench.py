@@ -50,6 +50,12 @@ def alg_bytes(n: int, *, het=True, nonlinear=True, absorbing=True):
         "sum_pressure_nonlinear_lossless": (4 + 3 * h) * R,
         "sum_pressure_linear_lossless": (4 + h) * R,
     }
+    # fused entry points = the reference stages they replace (same convention, so the sum over a step is unchanged)
+    terms = per["compute_pressure_terms_nonlinear"] if nonlinear else per["compute_pressure_terms_linear"]
+    per["fused_velocity"] = 4 * (R + Cx) + per["compute_pressure_gradient"] + per["compute_velocity"]
+    per["fused_density"] = (6 * (R + Cx) + per["compute_velocity_gradient"] + per["compute_density_nonlinear"]
+                            + (terms if absorbing else 0))
+    per["fused_absorption_pressure"] = 4 * (R + Cx) + per["compute_absorbtion_term"] + per["sum_pressure_terms"]
     n_fft = 10 + 4 * int(absorbing)
     b = n_fft * (R + Cx) + per["compute_pressure_gradient"] + per["compute_velocity"] + per["compute_velocity_gradient"]
     b += per["compute_density_nonlinear"]
@@ -146,7 +152,8 @@ def main():
            "dtype": "f32", "data": "synthetic",
            "config": {"workload": f"{n}^3 heterogeneous (c0,rho0,BonA,alpha_coeff arrays), power-law absorption + "
                                   f"nonlinear, p0 source, p_raw+p_max on one xy plane ({n * n} points)",
-                      "grid": [n, n, n], "fused_kernels": not args.granular, "fft": "rocFFT 3-D R2C/C2R",
+                      "grid": [n, n, n], "fused_kernels": not args.granular,
+                      "fft": "rocFFT 3-D R2C/C2R" if args.granular else "hand-written fused FFT passes (kw_fused.hip)",
                       "device": info.name.decode(), "baseline_ref": "BASELINE.md: 49.72 ms/step, TITAN X, "
                       "kspaceFirstOrder3D-CUDA v1.1 (manual Table C.4)", "input_generation_s": round(t_gen, 1)},
            "roofline": roofline}

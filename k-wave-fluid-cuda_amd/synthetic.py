@@ -95,7 +95,8 @@ def make_problem(nx: int, ny: Optional[int] = None, nz: Optional[int] = None, *,
                  source: str = "p0", nt: int = 110, pml_size: int = 10, pml_alpha: float = 2.0,
                  pml_off: bool = False, dx: float = 2.0e-4, cfl: float = 0.3,
                  source_mode: int = 0, source_many: int = 0, sensor: str = "plane",
-                 hetero_subset: Optional[dict] = None, seed: int = 0x5EED1234) -> Dict[str, np.ndarray]:
+                 hetero_subset: Optional[dict] = None, seed: int = 0x5EED1234,
+                 nt_src: Optional[int] = None) -> Dict[str, np.ndarray]:
     """Build one synthetic problem.
 
     source: "p0" (1 MPa Gaussian ball), "p_source" (1 MHz tone burst on plane x=12),
@@ -187,7 +188,7 @@ def make_problem(nx: int, ny: Optional[int] = None, nz: Optional[int] = None, *,
         lin = (zz[sel].astype(np.int64) * ny + yy[sel].astype(np.int64)) * nx + xs
         lin = np.sort(lin).astype(U64) + U64(1)
         nsrc = lin.size
-        nt_src = nt
+        nt_src = nt if nt_src is None else nt_src
         t = np.arange(nt_src, dtype=np.float64) * dt
         f0 = 1.0e6
         env = np.minimum(1.0, t * f0 / 3.0)  # 3-cycle ramp

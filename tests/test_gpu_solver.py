@@ -94,7 +94,7 @@ def test_sources_on_fused_pipeline(orc, syn, source, mode):
     """Power-of-two grid: the fused pipeline handles the k-space corrected additive source (scaleSource) and, with an
     active pressure source, falls back to the stand-alone pressure-terms kernel after the injection."""
     pr = syn.make_problem(32, heterogeneous=True, nonlinear=True, absorbing=True, source=source, source_mode=mode,
-                          source_many=1, nt=25, pml_size=4)
+                          source_many=1, nt=40, nt_src=25, pml_size=4)
     errs = compare(orc, pr, 40, fields=("p", "ux", "rhoz"), fused_kernels=True)  # 15 steps past the end of the signal
     assert max(errs.values()) < TOL, errs
 
