@@ -21,6 +21,7 @@
 #include "kw_internal.h"
 
 #include <cmath>
+#include <cstdlib>
 #include <vector>
 
 using namespace kwfft;
@@ -116,6 +117,7 @@ struct ZArgs
   const float2* tw;
   float         divider;
   uint32_t      nxc, P, ny, nz;
+  uint32_t      arr0; // index of the first array of this launch (per-array launches)
 };
 
 // inverse along the line, started from the step-B register layout (thread (c,k1) holds X[k1 + R1*k2]); result:
@@ -157,7 +159,7 @@ template<int L, int MODE> __global__ __launch_bounds__(Geo<L>::THREADS) void k_z
   const bool     valid  = kx < a.nxc;
   const size_t   zstr   = static_cast<size_t>(a.ny) * a.P;
   const size_t   base   = static_cast<size_t>(ky) * a.P + kx;
-  const uint32_t arr    = (MODE == Z_VGRAD || MODE == Z_ABSORB) ? blockIdx.z : 0;
+  const uint32_t arr    = (MODE == Z_VGRAD || MODE == Z_ABSORB) ? blockIdx.z + a.arr0 : 0;
   const float2* __restrict__ in = a.in[arr];
 
   if (j < R2)
@@ -190,7 +192,7 @@ template<int L, int MODE> __global__ __launch_bounds__(Geo<L>::THREADS) void k_z
     for (int k2 = 0; k2 < R2; k2++)
       kap[k2] = valid ? op[base + static_cast<size_t>(j + R1 * k2) * zstr] : 0.f;
   }
-#pragma unroll
+#pragma unroll 1
   for (int o = 0; o < NOUT; o++)
   {
     float2 w[R2];
@@ -329,6 +331,7 @@ struct XinvArgs
   float*        t[3];  // pressure-term outputs
   int           nonlinear;
   int           terms; // 0 none, 1 linear (t0 = sum rho, t1 = rho0*sum du), 2 nonlinear (t0, t1 = nonlinear term, t2)
+  uint32_t      comp0; // first component of this launch (per-array launches)
 };
 
 // standalone inverse of one array for this block's 32 rows; thread (c, f<R1) ends with x[f + R1*k2] of rows (2c, 2c+1)
@@ -374,131 +377,232 @@ __device__ __forceinline__ void xinv_lines(const float2* __restrict__ src, uint3
   __syncthreads();
 }
 
+__device__ __forceinline__ float  f4get(const float4& v, int k) { return k == 0 ? v.x : k == 1 ? v.y : k == 2 ? v.z : v.w; }
+__device__ __forceinline__ void   f4put(float4& v, int k, float s)
+{
+  if (k == 0) v.x = s; else if (k == 1) v.y = s; else if (k == 2) v.z = s; else v.w = s;
+}
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ void   st4(float* p, const float4& v) { *reinterpret_cast<float4*>(p) = v; }
+
+// The inverse leaves each thread with x = f + R1*k2 of two rows — a 64-B-segment pattern.  The results are restaged
+// through LDS as a plain real tile [32 rows][L] and re-read as float4 in a row-contiguous mapping, so that every
+// epilogue access to the state / medium arrays is a 16-B-per-lane coalesced access.
 template<int L, int EPI> __global__ __launch_bounds__(Geo<L>::THREADS) void k_xinv(XinvArgs a)
 {
   using G = Geo<L>;
   constexpr int R1 = G::R1, R2 = G::R2;
-  constexpr int NA = (EPI == EPI_DENSITY) ? 3 : (EPI == EPI_PSUM) ? 2 : 1;
+  constexpr int NA  = (EPI == EPI_DENSITY) ? 3 : (EPI == EPI_PSUM) ? 2 : 1;
+  constexpr int RP  = L + 8;                       // real-tile row pitch (floats): conflict-free 4-B scatter
+  constexpr int Q4  = L / 4;                       // float4 per row
+  constexpr int NQ  = (2 * NL * Q4) / G::THREADS;  // float4 per thread
+  static_assert((2 * NL * Q4) % G::THREADS == 0, "tile must divide evenly");
   __shared__ float2 lds[G::LDSX];
+  float* ldsr = reinterpret_cast<float*>(lds);
   const int f = threadIdx.x % G::TPL;
   const int c = threadIdx.x / G::TPL;
-  const uint32_t comp = (NA == 1) ? blockIdx.y : 0; // component / array index for single-array epilogues
-  float2 res[NA][R2];
+  const uint32_t comp = (NA == 1) ? blockIdx.y + a.comp0 : 0; // component / array index for single-array epilogues
+  float4 res[NA][NQ];
 #pragma unroll
-  for (int i = 0; i < NA; i++) xinv_lines<L>(a.in[(NA == 1) ? comp : i], a.P, lds, c, f, a.tw, res[i]);
-  if (f >= R1) return;
+  for (int i = 0; i < NA; i++)
+  {
+    float2 w[R2];
+    xinv_lines<L>(a.in[(NA == 1) ? comp : i], a.P, lds, c, f, a.tw, w); // ends with a barrier
+    if (f < R1)
+    {
+#pragma unroll
+      for (int k2 = 0; k2 < R2; k2++)
+      {
+        ldsr[(2 * c) * RP + f + R1 * k2]     = w[k2].x;
+        ldsr[(2 * c + 1) * RP + f + R1 * k2] = w[k2].y;
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < NQ; q++)
+    {
+      const int e   = threadIdx.x + q * G::THREADS;
+      const int row = e / Q4;
+      const int x4  = e - row * Q4;
+      res[i][q]     = *reinterpret_cast<const float4*>(&ldsr[row * RP + 4 * x4]);
+    }
+    __syncthreads();
+  }
 
   const kw_constants& k = a.c;
-  const size_t   row0 = (static_cast<size_t>(blockIdx.x) * NL + c) * 2;
-  const uint32_t z    = static_cast<uint32_t>(row0 / k.ny);
-  const uint32_t y0   = static_cast<uint32_t>(row0 - static_cast<size_t>(z) * k.ny);
+  const size_t tile_row0 = static_cast<size_t>(blockIdx.x) * NL * 2;
 #pragma unroll
-  for (int k2 = 0; k2 < R2; k2++)
+  for (int q = 0; q < NQ; q++)
   {
-    const uint32_t x = f + R1 * k2;
-#pragma unroll
-    for (int h = 0; h < 2; h++)
+    const int      e   = threadIdx.x + q * G::THREADS;
+    const int      row = e / Q4;
+    const uint32_t x   = 4u * static_cast<uint32_t>(e - row * Q4);
+    const size_t   r   = tile_row0 + row;
+    const uint32_t z   = static_cast<uint32_t>(r / k.ny);
+    const uint32_t y   = static_cast<uint32_t>(r - static_cast<size_t>(z) * k.ny);
+    const size_t   i   = r * L + x;
+    if (EPI == EPI_STORE)
     {
-      const size_t   i = (row0 + h) * L + x;
-      const uint32_t y = y0 + h;
-      if (EPI == EPI_STORE)
+      st4(a.out[comp] + i, res[0][q]);
+    }
+    else if (EPI == EPI_VELOCITY)
+    { // SolverCudaKernels.cu:199-212 (heterogeneous) / :287-305 (homogeneous)
+      float*       u  = a.out[comp];
+      float4       vu = ld4(u + i);
+      const float4 g  = res[0][q];
+      float4       pml4;
+      if (comp == 0) pml4 = ld4(a.m1[0] + x);
+      else
       {
-        a.out[comp][i] = h ? res[0][k2].y : res[0][k2].x;
+        const float s = (comp == 1) ? a.m1[1][y] : a.m1[2][z];
+        pml4          = make_float4(s, s, s, s);
       }
-      else if (EPI == EPI_VELOCITY)
-      { // SolverCudaKernels.cu:199-212 (heterogeneous) / :287-305 (homogeneous)
-        const float g    = h ? res[0][k2].y : res[0][k2].x;
-        const float pml  = (comp == 0) ? a.m1[0][x] : (comp == 1) ? a.m1[1][y] : a.m1[2][z];
-        float*      u    = a.out[comp];
-        float       e;
-        if (a.m0[comp] != nullptr) e = k.fft_divider * g * a.m0[comp][i];
-        else
+      if (a.m0[comp] != nullptr)
+      {
+        const float4 d = ld4(a.m0[comp] + i);
+#pragma unroll
+        for (int t = 0; t < 4; t++)
         {
-          const float dtr = (comp == 0) ? k.dt_rho0_sgx : (comp == 1) ? k.dt_rho0_sgy : k.dt_rho0_sgz;
-          e               = (dtr * k.fft_divider) * g;
-        }
-        u[i] = (u[i] * pml - e) * pml;
-      }
-      else if (EPI == EPI_INITVEL)
-      { // :957-980: u = ifft * (dtRho0Sg * (fftDivider*0.5)) | u = ifft * (fftDivider*0.5*dtRho0Sg)
-        const float g = h ? res[0][k2].y : res[0][k2].x;
-        float*      u = a.out[comp];
-        if (a.m0[comp] != nullptr) u[i] = g * (a.m0[comp][i] * (k.fft_divider * 0.5f));
-        else
-        {
-          const float dtr = (comp == 0) ? k.dt_rho0_sgx : (comp == 1) ? k.dt_rho0_sgy : k.dt_rho0_sgz;
-          u[i]            = g * (k.fft_divider * 0.5f * dtr);
+          const float ee = k.fft_divider * f4get(g, t) * f4get(d, t);
+          const float pm = f4get(pml4, t);
+          f4put(vu, t, (f4get(vu, t) * pm - ee) * pm);
         }
       }
-      else if (EPI == EPI_DENSITY)
-      { // :1368-1392 (nonlinear) / :1480-1496 (linear); du already carries fftDivider (applied in k-space, :1220)
-        const float dux = h ? res[0][k2].y : res[0][k2].x;
-        const float duy = h ? res[1][k2].y : res[1][k2].x;
-        const float duz = h ? res[2][k2].y : res[2][k2].x;
-        const float px = a.m1[0][x], py = a.m1[1][y], pz = a.m1[2][z];
-        const float rx = a.out[0][i], ry = a.out[1][i], rz = a.out[2][i];
-        const float r0 = (a.m0[0] != nullptr) ? a.m0[0][i] : k.rho0;
-        float nrx, nry, nrz;
+      else
+      {
+        const float dtr     = (comp == 0) ? k.dt_rho0_sgx : (comp == 1) ? k.dt_rho0_sgy : k.dt_rho0_sgz;
+        const float divider = dtr * k.fft_divider;
+#pragma unroll
+        for (int t = 0; t < 4; t++)
+        {
+          const float pm = f4get(pml4, t);
+          f4put(vu, t, (f4get(vu, t) * pm - divider * f4get(g, t)) * pm);
+        }
+      }
+      st4(u + i, vu);
+    }
+    else if (EPI == EPI_INITVEL)
+    { // :957-980: u = ifft * (dtRho0Sg * (fftDivider*0.5)) | u = ifft * (fftDivider*0.5*dtRho0Sg)
+      const float4 g = res[0][q];
+      float4       o;
+      if (a.m0[comp] != nullptr)
+      {
+        const float4 d = ld4(a.m0[comp] + i);
+#pragma unroll
+        for (int t = 0; t < 4; t++) f4put(o, t, f4get(g, t) * (f4get(d, t) * (k.fft_divider * 0.5f)));
+      }
+      else
+      {
+        const float dtr = (comp == 0) ? k.dt_rho0_sgx : (comp == 1) ? k.dt_rho0_sgy : k.dt_rho0_sgz;
+#pragma unroll
+        for (int t = 0; t < 4; t++) f4put(o, t, f4get(g, t) * (k.fft_divider * 0.5f * dtr));
+      }
+      st4(a.out[comp] + i, o);
+    }
+    else if (EPI == EPI_DENSITY)
+    { // :1368-1392 (nonlinear) / :1480-1496 (linear); du already carries fftDivider (applied in k-space, :1220)
+      const float4 dux = res[0][q], duy = res[1][q], duz = res[2][q];
+      const float4 px4 = ld4(a.m1[0] + x);
+      const float  py = a.m1[1][y], pz = a.m1[2][z];
+      const float4 rx = ld4(a.out[0] + i), ry = ld4(a.out[1] + i), rz = ld4(a.out[2] + i);
+      const bool   hetRho0 = (a.m0[0] != nullptr);
+      float4       r04 = make_float4(k.rho0, k.rho0, k.rho0, k.rho0);
+      if (hetRho0) r04 = ld4(a.m0[0] + i);
+      float4 nrx, nry, nrz;
+#pragma unroll
+      for (int t = 0; t < 4; t++)
+      {
+        const float px = f4get(px4, t);
+        const float r0 = f4get(r04, t);
+        const float erx = f4get(rx, t), ery = f4get(ry, t), erz = f4get(rz, t);
         if (a.nonlinear)
         {
-          const float sumRhosDt = (2.0f * (rx + ry + rz) + r0) * k.dt;
-          nrx = px * ((px * rx) - sumRhosDt * dux);
-          nry = py * ((py * ry) - sumRhosDt * duy);
-          nrz = pz * ((pz * rz) - sumRhosDt * duz);
+          const float sumRhosDt = (2.0f * (erx + ery + erz) + r0) * k.dt;
+          f4put(nrx, t, px * ((px * erx) - sumRhosDt * f4get(dux, t)));
+          f4put(nry, t, py * ((py * ery) - sumRhosDt * f4get(duy, t)));
+          f4put(nrz, t, pz * ((pz * erz) - sumRhosDt * f4get(duz, t)));
         }
         else
         {
-          const float dtRho0 = (a.m0[0] != nullptr) ? k.dt * r0 : k.dt_rho0;
-          nrx = px * (px * rx - dtRho0 * dux);
-          nry = py * (py * ry - dtRho0 * duy);
-          nrz = pz * (pz * rz - dtRho0 * duz);
+          const float dtRho0 = hetRho0 ? k.dt * r0 : k.dt_rho0;
+          f4put(nrx, t, px * (px * erx - dtRho0 * f4get(dux, t)));
+          f4put(nry, t, py * (py * ery - dtRho0 * f4get(duy, t)));
+          f4put(nrz, t, pz * (pz * erz - dtRho0 * f4get(duz, t)));
         }
-        a.out[0][i] = nrx;
-        a.out[1][i] = nry;
-        a.out[2][i] = nrz;
-        if (a.aux[0] != nullptr)
+      }
+      st4(a.out[0] + i, nrx);
+      st4(a.out[1] + i, nry);
+      st4(a.out[2] + i, nrz);
+      if (a.aux[0] != nullptr)
+      {
+        st4(a.aux[0] + i, dux);
+        st4(a.aux[1] + i, duy);
+        st4(a.aux[2] + i, duz);
+      }
+      if (a.terms == 2)
+      { // :1588-1601 with the updated densities
+        float4 b4 = make_float4(k.b_on_a, k.b_on_a, k.b_on_a, k.b_on_a);
+        if (a.m0[1] != nullptr) b4 = ld4(a.m0[1] + i);
+        float4 o0, o1, o2;
+#pragma unroll
+        for (int t = 0; t < 4; t++)
         {
-          a.aux[0][i] = dux;
-          a.aux[1][i] = duy;
-          a.aux[2][i] = duz;
+          const float eBonA   = f4get(b4, t);
+          const float r0      = f4get(r04, t);
+          const float eRhoSum = (f4get(nrx, t) + f4get(nry, t) + f4get(nrz, t));
+          const float eDuSum  = (f4get(dux, t) + f4get(duy, t) + f4get(duz, t));
+          f4put(o0, t, eRhoSum);
+          f4put(o1, t, ((eBonA * eRhoSum * eRhoSum) / (2.0f * r0)) + eRhoSum);
+          f4put(o2, t, r0 * eDuSum);
         }
-        if (a.terms == 2)
-        { // :1588-1601 with the updated densities
-          const float eBonA   = (a.m0[1] != nullptr) ? a.m0[1][i] : k.b_on_a;
-          const float eRhoSum = (nrx + nry + nrz);
-          const float eDuSum  = (dux + duy + duz);
-          a.t[0][i] = eRhoSum;
-          a.t[1][i] = ((eBonA * eRhoSum * eRhoSum) / (2.0f * r0)) + eRhoSum;
-          a.t[2][i] = r0 * eDuSum;
-        }
-        else if (a.terms == 1)
-        { // :1733-1741
-          a.t[0][i]         = nrx + nry + nrz;
-          const float duSum = dux + duy + duz;
-          a.t[1][i]         = r0 * duSum;
-        }
+        st4(a.t[0] + i, o0);
+        st4(a.t[1] + i, o1);
+        st4(a.t[2] + i, o2);
       }
-      else if (EPI == EPI_PSUM)
-      { // :1877 / :1978: p = c2*(first + (fftDivider*((tauTerm*tau) - (etaTerm*eta))))
-        const float tt  = h ? res[0][k2].y : res[0][k2].x;
-        const float et  = h ? res[1][k2].y : res[1][k2].x;
-        const float c2  = (a.m0[1] != nullptr) ? a.m0[1][i] : k.c2;
-        const float tau = (a.m1[0] != nullptr) ? a.m1[0][i] : k.absorb_tau;
-        const float eta = (a.m1[1] != nullptr) ? a.m1[1][i] : k.absorb_eta;
-        a.out[0][i]     = c2 * (a.m0[0][i] + (k.fft_divider * ((tt * tau) - (et * eta))));
+      else if (a.terms == 1)
+      { // :1733-1741
+        float4 o0, o1;
+#pragma unroll
+        for (int t = 0; t < 4; t++)
+        {
+          f4put(o0, t, f4get(nrx, t) + f4get(nry, t) + f4get(nrz, t));
+          const float duSum = f4get(dux, t) + f4get(duy, t) + f4get(duz, t);
+          f4put(o1, t, f4get(r04, t) * duSum);
+        }
+        st4(a.t[0] + i, o0);
+        st4(a.t[1] + i, o1);
       }
+    }
+    else if (EPI == EPI_PSUM)
+    { // :1877 / :1978: p = c2*(first + (fftDivider*((tauTerm*tau) - (etaTerm*eta))))
+      const float4 tt = res[0][q], et = res[1][q];
+      const float4 fi = ld4(a.m0[0] + i);
+      float4 c24  = make_float4(k.c2, k.c2, k.c2, k.c2);
+      float4 tau4 = make_float4(k.absorb_tau, k.absorb_tau, k.absorb_tau, k.absorb_tau);
+      float4 eta4 = make_float4(k.absorb_eta, k.absorb_eta, k.absorb_eta, k.absorb_eta);
+      if (a.m0[1] != nullptr) c24 = ld4(a.m0[1] + i);
+      if (a.m1[0] != nullptr) tau4 = ld4(a.m1[0] + i);
+      if (a.m1[1] != nullptr) eta4 = ld4(a.m1[1] + i);
+      float4 o;
+#pragma unroll
+      for (int t = 0; t < 4; t++)
+        f4put(o, t, f4get(c24, t) * (f4get(fi, t) + (k.fft_divider * ((f4get(tt, t) * f4get(tau4, t)) - (f4get(et, t) * f4get(eta4, t))))));
+      st4(a.out[0] + i, o);
     }
   }
 }
 
 // padded import of a reduced real operator: dst[z][y][P] <- src[z][y][nxc]
 __global__ void k_import_reduced(float* __restrict__ dst, const float* __restrict__ src, uint32_t nxc, uint32_t P,
-                                 uint32_t rows)
+                                 size_t total)
 {
-  const uint32_t x = blockIdx.x * blockDim.x + threadIdx.x;
-  const uint32_t r = blockIdx.y;
-  if (x >= P || r >= rows) return;
-  dst[static_cast<size_t>(r) * P + x] = (x < nxc) ? src[static_cast<size_t>(r) * nxc + x] : 0.f;
+  for (size_t e = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x; e < total;
+       e += static_cast<size_t>(gridDim.x) * blockDim.x)
+  {
+    const size_t   r = e / P;
+    const uint32_t x = static_cast<uint32_t>(e - r * P);
+    dst[e]           = (x < nxc) ? src[r * nxc + x] : 0.f;
+  }
 }
 
 // ---- host side ------------------------------------------------------------------------------------------------------
@@ -655,6 +759,10 @@ kw_status kw_fused_create(kw_ctx* ctx)
     KW_HIP(hipMemcpyAsync(ctx->fused.tw[i], tw.data(), lens[i] * sizeof(float2), hipMemcpyHostToDevice, ctx->stream));
     KW_HIP(hipStreamSynchronize(ctx->stream));
   }
+  {
+    const char* e = getenv("KW_FUSED_PER_ARRAY");
+    ctx->fused.per_array = (e != nullptr) && (e[0] != '0');
+  }
   ctx->fused.ready = true;
   return KW_OK;
 }
@@ -672,16 +780,8 @@ kw_status kw_fused_import_reduced(kw_ctx* ctx, float* dst_padded, const float* s
   KW_FUSED_READY(ctx);
   KW_REQUIRE(dst_padded && src);
   const kw_constants& c = ctx->c;
-  const uint32_t rows   = c.ny * c.nz;
-  KW_REQUIRE(rows <= 0x7fffffffu);
-  // rows on grid.y can exceed 65535: loop in chunks
-  for (uint32_t r0 = 0; r0 < rows; r0 += 32768)
-  {
-    const uint32_t n = (rows - r0 < 32768u) ? rows - r0 : 32768u;
-    LAUNCH(k_import_reduced, dim3((ctx->fused.P + 255) / 256, n), dim3(256),
-           dst_padded + static_cast<size_t>(r0) * ctx->fused.P, src + static_cast<size_t>(r0) * c.nx_complex,
-           c.nx_complex, ctx->fused.P, n);
-  }
+  const size_t total = static_cast<size_t>(c.ny) * c.nz * ctx->fused.P;
+  LAUNCH(k_import_reduced, dim3(ctx->cu_count * 8), dim3(256), dst_padded, src, c.nx_complex, ctx->fused.P, total);
   return KW_OK;
 }
 
@@ -704,13 +804,25 @@ kw_status kw_fused_velocity(kw_ctx* ctx, const float* p, float* ux, float* uy, f
   z.op[0] = kappa_padded;
   z.dd[0] = (const float2*)ddx; z.dd[1] = (const float2*)ddy; z.dd[2] = (const float2*)ddz;
   KW_TRY(launch_zfused<Z_PGRAD>(ctx, 1, z));
-  KW_TRY(launch_ypass(ctx, +1, 3, S));
   XinvArgs x{};
   float* u[3] = { ux, uy, uz };
   const float* dt[3] = { dtx, dty, dtz };
   const float* pml[3] = { pmlx, pmly, pmlz };
   for (int i = 0; i < 3; i++) { x.in[i] = S[i]; x.out[i] = u[i]; x.m0[i] = dt[i]; x.m1[i] = pml[i]; }
-  KW_TRY(launch_xinv<EPI_VELOCITY>(ctx, 3, x));
+  if (ctx->fused.per_array)
+  { // producer -> consumer back to back per array: the 64 MiB spectrum is still in the Infinity Cache when re-read
+    for (int i = 0; i < 3; i++)
+    {
+      KW_TRY(launch_ypass(ctx, +1, 1, S + i));
+      x.comp0 = i;
+      KW_TRY(launch_xinv<EPI_VELOCITY>(ctx, 1, x));
+    }
+  }
+  else
+  {
+    KW_TRY(launch_ypass(ctx, +1, 3, S));
+    KW_TRY(launch_xinv<EPI_VELOCITY>(ctx, 3, x));
+  }
   return KW_OK;
 }
 
@@ -756,14 +868,28 @@ kw_status kw_fused_density(kw_ctx* ctx, int nonlinear, const float* ux, const fl
   KW_REQUIRE(terms == 0 || (t0 && t1 && (terms == 1 || t2)));
   float2** S = ctx->fused.s;
   const float* in3[3] = { ux, uy, uz };
-  KW_TRY(launch_xfwd(ctx, 3, in3, S));
-  KW_TRY(launch_ypass(ctx, -1, 3, S));
   ZArgs z{};
   for (int i = 0; i < 3; i++) { z.in[i] = S[i]; z.out[i] = S[i]; }
   z.op[0] = kappa_padded;
   z.dd[0] = (const float2*)ddx; z.dd[1] = (const float2*)ddy; z.dd[2] = (const float2*)ddz;
-  KW_TRY(launch_zfused<Z_VGRAD>(ctx, 3, z));
-  KW_TRY(launch_ypass(ctx, +1, 3, S));
+  if (ctx->fused.per_array)
+  {
+    for (int i = 0; i < 3; i++)
+    {
+      KW_TRY(launch_xfwd(ctx, 1, in3 + i, S + i));
+      KW_TRY(launch_ypass(ctx, -1, 1, S + i));
+      z.arr0 = i;
+      KW_TRY(launch_zfused<Z_VGRAD>(ctx, 1, z));
+      KW_TRY(launch_ypass(ctx, +1, 1, S + i));
+    }
+  }
+  else
+  {
+    KW_TRY(launch_xfwd(ctx, 3, in3, S));
+    KW_TRY(launch_ypass(ctx, -1, 3, S));
+    KW_TRY(launch_zfused<Z_VGRAD>(ctx, 3, z));
+    KW_TRY(launch_ypass(ctx, +1, 3, S));
+  }
   XinvArgs x{};
   float* rho[3] = { rx, ry, rz };
   const float* pml[3] = { pmlx, pmly, pmlz };
@@ -789,14 +915,28 @@ kw_status kw_fused_absorption_pressure(kw_ctx* ctx, float* p, const float* vel_g
   KW_REQUIRE((tau == nullptr) == (eta == nullptr));
   float2** S = ctx->fused.s;
   const float* in2[2] = { vel_grad_term, density_sum };
-  KW_TRY(launch_xfwd(ctx, 2, in2, S));
-  KW_TRY(launch_ypass(ctx, -1, 2, S));
   ZArgs z{};
   for (int i = 0; i < 2; i++) { z.in[i] = S[i]; z.out[i] = S[i]; }
   z.op[0] = nabla1_padded;
   z.op[1] = nabla2_padded;
-  KW_TRY(launch_zfused<Z_ABSORB>(ctx, 2, z));
-  KW_TRY(launch_ypass(ctx, +1, 2, S));
+  if (ctx->fused.per_array)
+  {
+    for (int i = 0; i < 2; i++)
+    {
+      KW_TRY(launch_xfwd(ctx, 1, in2 + i, S + i));
+      KW_TRY(launch_ypass(ctx, -1, 1, S + i));
+      z.arr0 = i;
+      KW_TRY(launch_zfused<Z_ABSORB>(ctx, 1, z));
+      KW_TRY(launch_ypass(ctx, +1, 1, S + i));
+    }
+  }
+  else
+  {
+    KW_TRY(launch_xfwd(ctx, 2, in2, S));
+    KW_TRY(launch_ypass(ctx, -1, 2, S));
+    KW_TRY(launch_zfused<Z_ABSORB>(ctx, 2, z));
+    KW_TRY(launch_ypass(ctx, +1, 2, S));
+  }
   XinvArgs x{};
   x.in[0] = S[0]; x.in[1] = S[1];
   x.out[0] = p;
