@@ -255,6 +255,21 @@ KW_API kw_status kw_compute_velocity_shift(kw_ctx* ctx, int axis, float* spectru
  * make an HBM round trip as separate arrays.  Same arithmetic as the kernels cited; supported for Nx,Ny,Nz powers of
  * two in [16,1024].  kappa / nabla / sourceKappa must first be imported into the pipeline's padded row layout.
  * ---------------------------------------------------------------------------------------------------------------- */
+/* Multi-GPU (new with this build; the reference is single-GPU, Readme.md:12-13): Z-slab decomposition with one
+ * all-to-all transpose per 3-D FFT.  A context in slab mode holds nz = nz_global/nranks planes of every real array
+ * (kw_set_constants gets the LOCAL nz; fft_divider stays 1/(nx*ny*nz_global)) and, in k-space, ny/nranks rows with all
+ * nz_global planes ("transposed" layout [nz_global][ny/nranks][P]); reduced operators (kappa, nabla, sourceKappa) are
+ * supplied in that transposed layout.  The exchange itself is delegated to the caller, which owns the communicator:
+ * exchange(user, send, recv, bytes_per_peer) must perform an all-to-all of equal contiguous chunks (chunk q of `send`
+ * goes to rank q; chunk q of `recv` comes from rank q), ordered after all prior work on the context's stream and
+ * complete (or stream-ordered) before it returns — e.g. torch.distributed.all_to_all_single over RCCL. */
+typedef void (*kw_exchange_fn)(void* user, void* send, void* recv, size_t bytes_per_peer);
+KW_API kw_status kw_fused_set_slab(kw_ctx* ctx, uint32_t nranks, uint32_t rank, uint32_t nz_global,
+                                   kw_exchange_fn exchange, void* user);   /* before kw_fused_create */
+KW_API kw_status kw_fused_scratch_bytes(kw_ctx* ctx, size_t* out_bytes_per_array);
+/* like kw_fused_create but with caller-owned scratch (each of kw_fused_scratch_bytes bytes): s[3], and t[3] when
+ * nranks > 1 — lets the caller register the buffers with its communication library */
+KW_API kw_status kw_fused_create_with_scratch(kw_ctx* ctx, void* const s[3], void* const t[3]);
 KW_API kw_status kw_fused_supported(kw_ctx* ctx, int* out_supported);
 KW_API kw_status kw_fused_create(kw_ctx* ctx);   /* scratch + twiddles; needs kw_set_constants */
 KW_API kw_status kw_fused_destroy(kw_ctx* ctx);

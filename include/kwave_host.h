@@ -44,6 +44,13 @@ typedef struct kwh_options
   int32_t  p_c, u_non_staggered_c, i_avg_c, no_overlap;
   float    period;
   uint64_t mos, harmonics;
+  /* Z-slab decomposition (one process per GPU).  With slab_ranks > 1 the datasets describe this rank's slab: "Nz" is
+   * the local plane count, 3-D arrays / pml_z / pml_z_sgz are the local slices, source and sensor indices are local
+   * (re-based, 1-based) indices; ddz_* stay global.  exchange_fn is the all-to-all (kw_exchange_fn of kwave_hip.h). */
+  uint64_t slab_ranks, slab_rank, nz_global;
+  void*    exchange_fn;
+  void*    exchange_user;
+  void*    scratch[6]; /* optional caller-owned pipeline scratch (kw_fused_create_with_scratch), else all NULL */
 } kwh_options;
 
 KWH_API const char* kwh_last_error(void);

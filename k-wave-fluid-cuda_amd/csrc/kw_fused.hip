@@ -60,11 +60,25 @@ template<int L, int DIR> __device__ __forceinline__ void step_a(float2 (&v)[Fac<
 // =====================================================================================================================
 // y-pass: in-place complex FFT along y (stride P) for tile (z = blockIdx.y, kx tile = blockIdx.x), array blockIdx.z
 // =====================================================================================================================
+// Row addressing of a y-line element.  Natural layout: row(z, ky) = z*ny + ky.  Packed layout (slab mode, the send /
+// receive side of the all-to-all): row(z, ky) = ((ky / nyl) * nzl + z) * nyl + ky % nyl, i.e. one contiguous chunk
+// [nzl][nyl][P] per peer rank.  Both are  (ky >> sh) * qstride + (ky & mask) + z * zmul ; with one rank they coincide.
+struct RowAddr
+{
+  uint32_t sh, mask, qstride, zmul;
+  __device__ __forceinline__ size_t row(uint32_t z, uint32_t ky) const
+  {
+    return static_cast<size_t>(ky >> sh) * qstride + (ky & mask) + static_cast<size_t>(z) * zmul;
+  }
+};
+
 struct PassArgs
 {
-  float2*       s[3];
+  const float2* in[3];
+  float2*       out[3];
   const float2* tw;
-  uint32_t      nxc, P, ny, nz;
+  uint32_t      nxc, P;
+  RowAddr       ain, aout;
 };
 
 template<int L, int DIR> __global__ __launch_bounds__(Geo<L>::THREADS) void k_ypass(PassArgs a)
@@ -72,18 +86,19 @@ template<int L, int DIR> __global__ __launch_bounds__(Geo<L>::THREADS) void k_yp
   using G = Geo<L>;
   constexpr int R1 = G::R1, R2 = G::R2;
   __shared__ float2 lds[G::LDSB];
-  float2* __restrict__ S = a.s[blockIdx.z];
+  const float2* __restrict__ Sin = a.in[blockIdx.z];
+  float2* __restrict__ Sout      = a.out[blockIdx.z];
   const int      c     = threadIdx.x % NL;
   const int      j     = threadIdx.x / NL;
   const uint32_t kx    = blockIdx.x * NL + c;
   const bool     valid = kx < a.nxc;
-  const size_t   base  = static_cast<size_t>(blockIdx.y) * L * a.P + kx;
+  const uint32_t z     = blockIdx.y;
   if (j < R2)
   {
     float2 v[R1];
 #pragma unroll
     for (int n1 = 0; n1 < R1; n1++)
-      v[n1] = valid ? S[base + static_cast<size_t>(n1 * R2 + j) * a.P] : make_float2(0.f, 0.f);
+      v[n1] = valid ? Sin[a.ain.row(z, n1 * R2 + j) * a.P + kx] : make_float2(0.f, 0.f);
     step_a<L, DIR>(v, j, a.tw);
 #pragma unroll
     for (int k1 = 0; k1 < R1; k1++) lds[k1 * G::SF + j * NL + c] = v[k1];
@@ -98,7 +113,7 @@ template<int L, int DIR> __global__ __launch_bounds__(Geo<L>::THREADS) void k_yp
     if (valid)
     {
 #pragma unroll
-      for (int k2 = 0; k2 < R2; k2++) S[base + static_cast<size_t>(j + R1 * k2) * a.P] = w[k2];
+      for (int k2 = 0; k2 < R2; k2++) Sout[a.aout.row(z, j + R1 * k2) * a.P + kx] = w[k2];
     }
   }
 }
@@ -118,6 +133,7 @@ struct ZArgs
   float         divider;
   uint32_t      nxc, P, ny, nz;
   uint32_t      arr0; // index of the first array of this launch (per-array launches)
+  uint32_t      ky0;  // global ky of local row 0 (slab mode: rank * ny/nranks); ny above = number of LOCAL rows
 };
 
 // inverse along the line, started from the step-B register layout (thread (c,k1) holds X[k1 + R1*k2]); result:
@@ -200,7 +216,7 @@ template<int L, int MODE> __global__ __launch_bounds__(Geo<L>::THREADS) void k_z
     {
       if (MODE == Z_PGRAD)
       { // SolverCudaKernels.cu:1149-1155: e = X*kappa; out = e (x) dd{x,y,z}_pos
-        const float2 dxy = (o == 0) ? (valid ? a.dd[0][kx] : make_float2(0.f, 0.f)) : a.dd[1][ky];
+        const float2 dxy = (o == 0) ? (valid ? a.dd[0][kx] : make_float2(0.f, 0.f)) : a.dd[1][ky + a.ky0];
 #pragma unroll
         for (int k2 = 0; k2 < R2; k2++)
         {
@@ -211,7 +227,7 @@ template<int L, int MODE> __global__ __launch_bounds__(Geo<L>::THREADS) void k_z
       }
       else if (MODE == Z_VGRAD)
       { // :1220-1236: (X * (kappa*divider)) (x) dd_neg of this array's own axis
-        const float2 dxy = (arr == 0) ? (valid ? a.dd[0][kx] : make_float2(0.f, 0.f)) : a.dd[1][ky];
+        const float2 dxy = (arr == 0) ? (valid ? a.dd[0][kx] : make_float2(0.f, 0.f)) : a.dd[1][ky + a.ky0];
 #pragma unroll
         for (int k2 = 0; k2 < R2; k2++)
         {
@@ -642,17 +658,24 @@ kw_status launch_xfwd(kw_ctx* ctx, int narr, const float* const* in, float2* con
   return KW_OK;
 }
 
-kw_status launch_ypass(kw_ctx* ctx, int dir, int narr, float2* const* s)
+// y-pass.  pack_out / pack_in select the packed (per-peer-chunk) row layout on that side; with one rank both layouts
+// coincide and the pass may run in place.
+kw_status launch_ypass(kw_ctx* ctx, int dir, int narr, float2* const* in, float2* const* out, bool pack_in, bool pack_out)
 {
   const kw_constants& c = ctx->c;
+  const auto& f = ctx->fused;
   PassArgs a{};
-  for (int i = 0; i < narr; i++) a.s[i] = s[i];
-  a.tw  = ctx->fused.tw[1];
+  for (int i = 0; i < narr; i++) { a.in[i] = in[i]; a.out[i] = out[i]; }
+  a.tw  = f.tw[1];
   a.nxc = c.nx_complex;
-  a.P   = ctx->fused.P;
-  a.ny  = c.ny;
-  a.nz  = c.nz;
-  const dim3 grid(ctx->fused.P / NL, c.nz, narr);
+  a.P   = f.P;
+  uint32_t sh = 0;
+  while ((1u << sh) < f.nyl) sh++;
+  const RowAddr natural{31u, 0xffffffffu, 0u, c.ny};
+  const RowAddr packed{sh, f.nyl - 1u, c.nz * f.nyl, f.nyl};
+  a.ain  = pack_in ? packed : natural;
+  a.aout = pack_out ? packed : natural;
+  const dim3 grid(f.P / NL, c.nz, narr);
 #define M(LEN)                                                                                                         \
   if (dir < 0) LAUNCH((k_ypass<LEN, kFwd>), grid, dim3(Geo<LEN>::THREADS), a);                                         \
   else LAUNCH((k_ypass<LEN, kInv>), grid, dim3(Geo<LEN>::THREADS), a)
@@ -661,18 +684,21 @@ kw_status launch_ypass(kw_ctx* ctx, int dir, int narr, float2* const* s)
   return KW_OK;
 }
 
+// z-fused on the (possibly transposed) spectra: lines of nz_global elements, nyl local rows, stride nyl*P
 template<int MODE> kw_status launch_zfused(kw_ctx* ctx, int narr, ZArgs a)
 {
   const kw_constants& c = ctx->c;
-  a.tw      = ctx->fused.tw[2];
+  const auto& f = ctx->fused;
+  a.tw      = f.tw[2];
   a.divider = c.fft_divider;
   a.nxc     = c.nx_complex;
-  a.P       = ctx->fused.P;
-  a.ny      = c.ny;
-  a.nz      = c.nz;
-  const dim3 grid(ctx->fused.P / NL, c.ny, narr);
+  a.P       = f.P;
+  a.ny      = f.nyl;
+  a.nz      = f.nz_global;
+  a.ky0     = f.rank * f.nyl;
+  const dim3 grid(f.P / NL, f.nyl, narr);
 #define M(LEN) LAUNCH((k_zfused<LEN, MODE>), grid, dim3(Geo<LEN>::THREADS), a)
-  KW_LEN_SWITCH(c.nz, M)
+  KW_LEN_SWITCH(f.nz_global, M)
 #undef M
   return KW_OK;
 }
@@ -702,51 +728,85 @@ template<int EPI> kw_status launch_xinv(kw_ctx* ctx, int ncomp, XinvArgs a)
     if (st_ != KW_OK) return st_;                                                                                      \
   } while (0)
 
-} // namespace
-
-extern "C" {
-
-kw_status kw_fused_supported(kw_ctx* ctx, int* out)
+// all-to-all of one scratch array between the ranks (no-op with one rank): chunk q of `send` -> rank q
+kw_status exchange(kw_ctx* ctx, float2* send, float2* recv)
 {
-  KW_CHECK_CONSTS(ctx);
-  KW_REQUIRE(out != nullptr);
-  const kw_constants& c = ctx->c;
-  *out = supported_len(c.nx) && supported_len(c.ny) && supported_len(c.nz) && ((c.ny * c.nz) % (2 * NL) == 0);
+  const auto& f = ctx->fused;
+  if (f.nranks == 1) return KW_OK;
+  const size_t bytes_per_peer = static_cast<size_t>(ctx->c.nz) * f.nyl * f.P * sizeof(float2);
+  f.exchange(f.exchange_user, send, recv, bytes_per_peer);
   return KW_OK;
 }
 
-kw_status kw_fused_destroy(kw_ctx* ctx)
+// forward half of a 3-D transform for narr real arrays: x-forward, y-forward, transpose.  Spectra end up in S[]
+// ([nz][ny][P] with one rank, transposed [nz_global][nyl][P] in slab mode).
+kw_status forward_xy(kw_ctx* ctx, int narr, const float* const* in, int s0 = 0)
 {
-  KW_CHECK_CTX(ctx);
-  if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+  auto& f = ctx->fused;
+  KW_TRY(launch_xfwd(ctx, narr, in, f.s + s0));
+  if (f.nranks == 1) return launch_ypass(ctx, -1, narr, f.s + s0, f.s + s0, false, false);
+  KW_TRY(launch_ypass(ctx, -1, narr, f.s + s0, f.t + s0, false, true));
+  for (int i = 0; i < narr; i++) KW_TRY(exchange(ctx, f.t[s0 + i], f.s[s0 + i]));
+  return KW_OK;
+}
+
+// inverse half: transpose back, y-inverse; leaves [nz][ny][P] spectra (x still transformed) in S[]
+kw_status inverse_y(kw_ctx* ctx, int narr, int s0 = 0)
+{
+  auto& f = ctx->fused;
+  if (f.nranks == 1) return launch_ypass(ctx, +1, narr, f.s + s0, f.s + s0, false, false);
+  for (int i = 0; i < narr; i++) KW_TRY(exchange(ctx, f.s[s0 + i], f.t[s0 + i]));
+  return launch_ypass(ctx, +1, narr, f.t + s0, f.s + s0, true, false);
+}
+
+kw_status alloc_scratch(kw_ctx* ctx, void* const s[3], void* const t[3])
+{
+  auto& f = ctx->fused;
+  const kw_constants& c = ctx->c;
+  const size_t elems = static_cast<size_t>(f.P) * c.ny * c.nz;
+  f.owns_scratch     = (s == nullptr);
   for (int i = 0; i < 3; i++)
   {
-    if (ctx->fused.s[i]) (void)hipFree(ctx->fused.s[i]);
-    if (ctx->fused.tw[i]) (void)hipFree(ctx->fused.tw[i]);
-    ctx->fused.s[i]  = nullptr;
-    ctx->fused.tw[i] = nullptr;
+    if (f.owns_scratch)
+    {
+      KW_HIP(hipMalloc(reinterpret_cast<void**>(&f.s[i]), elems * sizeof(float2)));
+      if (f.nranks > 1) KW_HIP(hipMalloc(reinterpret_cast<void**>(&f.t[i]), elems * sizeof(float2)));
+    }
+    else
+    {
+      KW_REQUIRE(s[i] != nullptr && (f.nranks == 1 || (t != nullptr && t[i] != nullptr)));
+      f.s[i] = static_cast<float2*>(s[i]);
+      f.t[i] = (f.nranks > 1) ? static_cast<float2*>(t[i]) : nullptr;
+    }
+    KW_HIP(hipMemsetAsync(f.s[i], 0, elems * sizeof(float2), ctx->stream));
+    if (f.t[i]) KW_HIP(hipMemsetAsync(f.t[i], 0, elems * sizeof(float2), ctx->stream));
   }
-  ctx->fused.ready = false;
   return KW_OK;
 }
 
-kw_status kw_fused_create(kw_ctx* ctx)
+kw_status create_impl(kw_ctx* ctx, void* const s[3], void* const t[3])
 {
   KW_CHECK_CONSTS(ctx);
   int ok = 0;
   kw_fused_supported(ctx, &ok);
-  if (!ok) { kw_set_error("kw_fused_create: grid %ux%ux%u is not supported by the fused pipeline", ctx->c.nx, ctx->c.ny, ctx->c.nz); return KW_ERR_INVALID; }
+  if (!ok)
+  {
+    kw_set_error("kw_fused_create: grid %ux%ux%u (x %u ranks) is not supported by the fused pipeline", ctx->c.nx,
+                 ctx->c.ny, ctx->c.nz, ctx->fused.nranks);
+    return KW_ERR_INVALID;
+  }
+  // keep the slab description across the reset
+  const auto slab = ctx->fused;
   kw_fused_destroy(ctx);
+  auto& f = ctx->fused;
+  f.nranks = slab.nranks; f.rank = slab.rank; f.exchange = slab.exchange; f.exchange_user = slab.exchange_user;
   KW_HIP(hipSetDevice(ctx->device));
   const kw_constants& c = ctx->c;
-  ctx->fused.P          = (c.nx_complex + NL - 1) / NL * NL;
-  const size_t elems    = static_cast<size_t>(ctx->fused.P) * c.ny * c.nz;
-  for (int i = 0; i < 3; i++)
-  {
-    KW_HIP(hipMalloc(reinterpret_cast<void**>(&ctx->fused.s[i]), elems * sizeof(float2)));
-    KW_HIP(hipMemsetAsync(ctx->fused.s[i], 0, elems * sizeof(float2), ctx->stream));
-  }
-  const uint32_t lens[3] = { c.nx, c.ny, c.nz };
+  f.nz_global = (f.nranks > 1) ? slab.nz_global : c.nz;
+  f.nyl       = c.ny / f.nranks;
+  f.P         = (c.nx_complex + NL - 1) / NL * NL;
+  KW_TRY(alloc_scratch(ctx, s, t));
+  const uint32_t lens[3] = { c.nx, c.ny, f.nz_global };
   for (int i = 0; i < 3; i++)
   {
     std::vector<float2> tw(lens[i]);
@@ -755,15 +815,84 @@ kw_status kw_fused_create(kw_ctx* ctx)
       const double ph = -2.0 * M_PI * static_cast<double>(m) / static_cast<double>(lens[i]);
       tw[m]           = make_float2(static_cast<float>(std::cos(ph)), static_cast<float>(std::sin(ph)));
     }
-    KW_HIP(hipMalloc(reinterpret_cast<void**>(&ctx->fused.tw[i]), lens[i] * sizeof(float2)));
-    KW_HIP(hipMemcpyAsync(ctx->fused.tw[i], tw.data(), lens[i] * sizeof(float2), hipMemcpyHostToDevice, ctx->stream));
+    KW_HIP(hipMalloc(reinterpret_cast<void**>(&f.tw[i]), lens[i] * sizeof(float2)));
+    KW_HIP(hipMemcpyAsync(f.tw[i], tw.data(), lens[i] * sizeof(float2), hipMemcpyHostToDevice, ctx->stream));
     KW_HIP(hipStreamSynchronize(ctx->stream));
   }
   {
     const char* e = getenv("KW_FUSED_PER_ARRAY");
-    ctx->fused.per_array = (e != nullptr) && (e[0] != '0');
+    f.per_array   = (e != nullptr) && (e[0] != '0');
   }
-  ctx->fused.ready = true;
+  f.ready = true;
+  return KW_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+kw_status kw_fused_set_slab(kw_ctx* ctx, uint32_t nranks, uint32_t rank, uint32_t nz_global, kw_exchange_fn fn, void* user)
+{
+  KW_CHECK_CTX(ctx);
+  KW_REQUIRE(nranks >= 1 && rank < nranks);
+  KW_REQUIRE(nranks == 1 || fn != nullptr);
+  if (ctx->fused.ready) { kw_set_error("kw_fused_set_slab: must be called before kw_fused_create"); return KW_ERR_STATE; }
+  ctx->fused.nranks        = nranks;
+  ctx->fused.rank          = rank;
+  ctx->fused.nz_global     = nz_global;
+  ctx->fused.exchange      = fn;
+  ctx->fused.exchange_user = user;
+  return KW_OK;
+}
+
+kw_status kw_fused_supported(kw_ctx* ctx, int* out)
+{
+  KW_CHECK_CONSTS(ctx);
+  KW_REQUIRE(out != nullptr);
+  const kw_constants& c = ctx->c;
+  const auto& f         = ctx->fused;
+  const uint32_t nzg    = (f.nranks > 1) ? f.nz_global : c.nz;
+  bool ok = supported_len(c.nx) && supported_len(c.ny) && supported_len(nzg) && ((c.ny * c.nz) % (2 * NL) == 0);
+  if (f.nranks > 1) ok = ok && (nzg == c.nz * f.nranks) && (c.ny % f.nranks == 0);
+  *out = ok ? 1 : 0;
+  return KW_OK;
+}
+
+kw_status kw_fused_destroy(kw_ctx* ctx)
+{
+  KW_CHECK_CTX(ctx);
+  if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+  auto& f = ctx->fused;
+  for (int i = 0; i < 3; i++)
+  {
+    if (f.owns_scratch)
+    {
+      if (f.s[i]) (void)hipFree(f.s[i]);
+      if (f.t[i]) (void)hipFree(f.t[i]);
+    }
+    if (f.tw[i]) (void)hipFree(f.tw[i]);
+    f.s[i] = f.t[i] = nullptr;
+    f.tw[i] = nullptr;
+  }
+  f = kw_ctx::fused_plan();
+  return KW_OK;
+}
+
+kw_status kw_fused_create(kw_ctx* ctx) { return create_impl(ctx, nullptr, nullptr); }
+
+kw_status kw_fused_create_with_scratch(kw_ctx* ctx, void* const s[3], void* const t[3])
+{
+  KW_CHECK_CTX(ctx);
+  KW_REQUIRE(s != nullptr);
+  return create_impl(ctx, s, t);
+}
+
+kw_status kw_fused_scratch_bytes(kw_ctx* ctx, size_t* out)
+{
+  KW_CHECK_CONSTS(ctx);
+  KW_REQUIRE(out != nullptr);
+  const uint32_t P = (ctx->c.nx_complex + NL - 1) / NL * NL;
+  *out             = static_cast<size_t>(P) * ctx->c.ny * ctx->c.nz * sizeof(float2);
   return KW_OK;
 }
 
@@ -775,6 +904,7 @@ kw_status kw_fused_reduced_elems(kw_ctx* ctx, size_t* out)
   return KW_OK;
 }
 
+// src is [rows][nxc] with rows = ny*nz (one rank: [nz][ny]; slab mode: the transposed [nz_global][nyl]) — same count
 kw_status kw_fused_import_reduced(kw_ctx* ctx, float* dst_padded, const float* src)
 {
   KW_FUSED_READY(ctx);
@@ -796,8 +926,7 @@ kw_status kw_fused_velocity(kw_ctx* ctx, const float* p, float* ux, float* uy, f
   KW_REQUIRE((dtx == nullptr) == (dty == nullptr) && (dtx == nullptr) == (dtz == nullptr));
   float2** S = ctx->fused.s;
   const float* in1[1] = { p };
-  KW_TRY(launch_xfwd(ctx, 1, in1, S));
-  KW_TRY(launch_ypass(ctx, -1, 1, S));
+  KW_TRY(forward_xy(ctx, 1, in1));
   ZArgs z{};
   z.in[0] = S[0];
   for (int i = 0; i < 3; i++) z.out[i] = S[i];
@@ -810,17 +939,17 @@ kw_status kw_fused_velocity(kw_ctx* ctx, const float* p, float* ux, float* uy, f
   const float* pml[3] = { pmlx, pmly, pmlz };
   for (int i = 0; i < 3; i++) { x.in[i] = S[i]; x.out[i] = u[i]; x.m0[i] = dt[i]; x.m1[i] = pml[i]; }
   if (ctx->fused.per_array)
-  { // producer -> consumer back to back per array: the 64 MiB spectrum is still in the Infinity Cache when re-read
+  { // A/B knob: whole chain per array
     for (int i = 0; i < 3; i++)
     {
-      KW_TRY(launch_ypass(ctx, +1, 1, S + i));
+      KW_TRY(inverse_y(ctx, 1, i));
       x.comp0 = i;
       KW_TRY(launch_xinv<EPI_VELOCITY>(ctx, 1, x));
     }
   }
   else
   {
-    KW_TRY(launch_ypass(ctx, +1, 3, S));
+    KW_TRY(inverse_y(ctx, 3));
     KW_TRY(launch_xinv<EPI_VELOCITY>(ctx, 3, x));
   }
   return KW_OK;
@@ -836,15 +965,14 @@ kw_status kw_fused_initial_velocity(kw_ctx* ctx, const float* p, float* ux, floa
   KW_REQUIRE(p && ux && uy && uz && kappa_padded && ddx && ddy && ddz);
   float2** S = ctx->fused.s;
   const float* in1[1] = { p };
-  KW_TRY(launch_xfwd(ctx, 1, in1, S));
-  KW_TRY(launch_ypass(ctx, -1, 1, S));
+  KW_TRY(forward_xy(ctx, 1, in1));
   ZArgs z{};
   z.in[0] = S[0];
   for (int i = 0; i < 3; i++) z.out[i] = S[i];
   z.op[0] = kappa_padded;
   z.dd[0] = (const float2*)ddx; z.dd[1] = (const float2*)ddy; z.dd[2] = (const float2*)ddz;
   KW_TRY(launch_zfused<Z_PGRAD>(ctx, 1, z));
-  KW_TRY(launch_ypass(ctx, +1, 3, S));
+  KW_TRY(inverse_y(ctx, 3));
   XinvArgs x{};
   float* u[3] = { ux, uy, uz };
   const float* dt[3] = { dtx, dty, dtz };
@@ -876,19 +1004,17 @@ kw_status kw_fused_density(kw_ctx* ctx, int nonlinear, const float* ux, const fl
   {
     for (int i = 0; i < 3; i++)
     {
-      KW_TRY(launch_xfwd(ctx, 1, in3 + i, S + i));
-      KW_TRY(launch_ypass(ctx, -1, 1, S + i));
+      KW_TRY(forward_xy(ctx, 1, in3 + i, i));
       z.arr0 = i;
       KW_TRY(launch_zfused<Z_VGRAD>(ctx, 1, z));
-      KW_TRY(launch_ypass(ctx, +1, 1, S + i));
+      KW_TRY(inverse_y(ctx, 1, i));
     }
   }
   else
   {
-    KW_TRY(launch_xfwd(ctx, 3, in3, S));
-    KW_TRY(launch_ypass(ctx, -1, 3, S));
+    KW_TRY(forward_xy(ctx, 3, in3));
     KW_TRY(launch_zfused<Z_VGRAD>(ctx, 3, z));
-    KW_TRY(launch_ypass(ctx, +1, 3, S));
+    KW_TRY(inverse_y(ctx, 3));
   }
   XinvArgs x{};
   float* rho[3] = { rx, ry, rz };
@@ -923,19 +1049,17 @@ kw_status kw_fused_absorption_pressure(kw_ctx* ctx, float* p, const float* vel_g
   {
     for (int i = 0; i < 2; i++)
     {
-      KW_TRY(launch_xfwd(ctx, 1, in2 + i, S + i));
-      KW_TRY(launch_ypass(ctx, -1, 1, S + i));
+      KW_TRY(forward_xy(ctx, 1, in2 + i, i));
       z.arr0 = i;
       KW_TRY(launch_zfused<Z_ABSORB>(ctx, 1, z));
-      KW_TRY(launch_ypass(ctx, +1, 1, S + i));
+      KW_TRY(inverse_y(ctx, 1, i));
     }
   }
   else
   {
-    KW_TRY(launch_xfwd(ctx, 2, in2, S));
-    KW_TRY(launch_ypass(ctx, -1, 2, S));
+    KW_TRY(forward_xy(ctx, 2, in2));
     KW_TRY(launch_zfused<Z_ABSORB>(ctx, 2, z));
-    KW_TRY(launch_ypass(ctx, +1, 2, S));
+    KW_TRY(inverse_y(ctx, 2));
   }
   XinvArgs x{};
   x.in[0] = S[0]; x.in[1] = S[1];
@@ -954,13 +1078,12 @@ kw_status kw_fused_scale_source(kw_ctx* ctx, float* scaled, const float* source_
   KW_REQUIRE(scaled && source_kappa_padded);
   float2** S = ctx->fused.s;
   const float* in1[1] = { scaled };
-  KW_TRY(launch_xfwd(ctx, 1, in1, S));
-  KW_TRY(launch_ypass(ctx, -1, 1, S));
+  KW_TRY(forward_xy(ctx, 1, in1));
   ZArgs z{};
   z.in[0] = S[0]; z.out[0] = S[0];
   z.op[0] = source_kappa_padded;
   KW_TRY(launch_zfused<Z_SOURCE>(ctx, 1, z));
-  KW_TRY(launch_ypass(ctx, +1, 1, S));
+  KW_TRY(inverse_y(ctx, 1));
   XinvArgs x{};
   x.in[0] = S[0];
   x.out[0] = scaled;

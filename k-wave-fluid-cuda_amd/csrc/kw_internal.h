@@ -41,6 +41,13 @@ struct kw_ctx
     uint32_t P     = 0;                            // padded half-spectrum row pitch (complex), multiple of 16
     float2*  s[3]  = {nullptr, nullptr, nullptr};  // three padded complex scratch arrays [nz][ny][P]
     float2*  tw[3] = {nullptr, nullptr, nullptr};  // exp(-2 pi i m / n) for n = nx, ny, nz
+    // Z-slab decomposition (multi-GPU): this context owns nz = nz_global/nranks planes of the real-space arrays and,
+    // after the all-to-all transpose, nyl = ny/nranks rows of every spectrum with all nz_global planes.
+    uint32_t nranks = 1, rank = 0, nz_global = 0, nyl = 0;
+    float2*  t[3]  = {nullptr, nullptr, nullptr};  // exchange partners of s[] (slab mode only)
+    bool     owns_scratch = true;
+    kw_exchange_fn exchange = nullptr;             // all-to-all over the ranks (RCCL via the caller)
+    void*          exchange_user = nullptr;
   } fused;
   // profiling (kw_profile_enable)
   struct prof_rec { const char* name; hipEvent_t e0, e1; };

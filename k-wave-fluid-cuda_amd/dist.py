@@ -1,0 +1,173 @@
+"""Multi-GPU driver: Z-slab decomposition of the k-space step, one process per GPU.
+
+New with this build (the reference is single-GPU, /root/reference/Readme.md:12-13).  Real-space arrays are split into
+Z-slabs; every 3-D FFT of the fused pipeline (csrc/kw_fused.hip) does x- and y-passes locally, one all-to-all transpose,
+the fused z-pass on `Ny/P` rows with all `Nz` planes, and the mirror image on the way back.  The all-to-all is
+`torch.distributed.all_to_all_single` — RCCL over xGMI on a GPU node (`backend="nccl"`), gloo through host staging when
+ranks share one GPU (tests) — handed to the C++ solver as a callback (`kw_exchange_fn`, include/kwave_hip.h).
+
+partition_problem() cuts a global problem dict (HDF5 dataset names) into the slab of one rank:
+  * 3-D arrays, pml_z, pml_z_sgz         -> planes z0 <= z < z1
+  * source / sensor index masks (1-based) -> entries inside the slab, re-based to the slab, original order kept
+  * per-point source series, delay mask    -> the matching columns
+  * everything else (scalars, x/y PML, ddx/ddy/ddz operators) unchanged; "Nz" becomes the local plane count.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, Optional, Tuple
+
+import numpy as np
+
+from . import capi
+
+U64 = np.uint64
+
+
+def slab_range(nz: int, rank: int, nranks: int) -> Tuple[int, int]:
+    if nz % nranks:
+        raise ValueError(f"Nz={nz} is not divisible by {nranks} ranks")
+    nzl = nz // nranks
+    return rank * nzl, (rank + 1) * nzl
+
+
+def _sc(a) -> int:
+    return int(np.asarray(a).reshape(-1)[0])
+
+
+def partition_problem(pr: Dict[str, np.ndarray], rank: int, nranks: int, arrays_are_local: bool = False):
+    """Return (local problem dict, info).  info["sensor_positions"] = positions of this rank's sensor points in the
+    global sensor mask (to reassemble sampled series in the original order)."""
+    nx, ny, nz = _sc(pr["Nx"]), _sc(pr["Ny"]), _sc(pr["Nz"])
+    z0, z1 = slab_range(nz, rank, nranks)
+    if ny % nranks:
+        raise ValueError(f"Ny={ny} is not divisible by {nranks} ranks")
+    plane = nx * ny
+    lo, hi = z0 * plane, z1 * plane
+    out: Dict[str, np.ndarray] = {}
+    info = {"z0": z0, "z1": z1, "nz_global": nz}
+
+    def local_index(idx1: np.ndarray):
+        idx0 = idx1.reshape(-1).astype(np.int64) - 1
+        sel = np.nonzero((idx0 >= lo) & (idx0 < hi))[0]
+        return sel, (idx0[sel] - lo + 1).astype(U64)
+
+    p_sel = u_sel = None
+    if "p_source_index" in pr:
+        p_sel, p_loc = local_index(pr["p_source_index"])
+    if "u_source_index" in pr:
+        u_sel, u_loc = local_index(pr["u_source_index"])
+
+    for name, a in pr.items():
+        a = np.asarray(a)
+        if name == "Nz":
+            out[name] = np.array([[[z1 - z0]]], dtype=U64)
+        elif a.ndim == 3 and a.shape == (nz, ny, nx):
+            out[name] = np.ascontiguousarray(a[z0:z1])
+        elif arrays_are_local and a.ndim == 3 and a.shape == (z1 - z0, ny, nx):
+            out[name] = a
+        elif name in ("pml_z", "pml_z_sgz"):
+            out[name] = np.ascontiguousarray(a.reshape(-1)[z0:z1])
+        elif name == "p_source_index":
+            out[name] = p_loc.reshape(1, 1, -1)
+        elif name == "u_source_index":
+            out[name] = u_loc.reshape(1, 1, -1)
+        elif name == "p_source_input" and _sc(pr.get("p_source_many", 0)):
+            nt_src = _sc(pr["p_source_flag"])
+            out[name] = np.ascontiguousarray(a.reshape(nt_src, -1)[:, p_sel]).reshape(1, nt_src, -1)
+        elif name in ("ux_source_input", "uy_source_input", "uz_source_input") and _sc(pr.get("u_source_many", 0)):
+            nt_src = _sc(pr[name[:2] + "_source_flag"])
+            out[name] = np.ascontiguousarray(a.reshape(nt_src, -1)[:, u_sel]).reshape(1, nt_src, -1)
+        elif name == "delay_mask":
+            out[name] = np.ascontiguousarray(a.reshape(-1)[u_sel]).reshape(1, 1, -1)
+        elif name == "sensor_mask_index":
+            s_sel, s_loc = local_index(a)
+            out[name] = s_loc.reshape(1, 1, -1)
+            info["sensor_positions"] = s_sel
+        else:
+            out[name] = a
+    return out, info
+
+
+class SlabExchange:
+    """The all-to-all handed to the C++ solver.  nccl (= RCCL): device tensors allocated here double as the pipeline's
+    scratch, so the collective runs in place on them.  gloo: device -> pinned host, all-to-all on CPU, host -> device."""
+
+    CB = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t)
+
+    def __init__(self, nranks: int, device_index: int = 0):
+        import torch
+        import torch.distributed as dist
+        self.torch, self.dist = torch, dist
+        self.nranks = nranks
+        self.backend = dist.get_backend() if (dist.is_available() and dist.is_initialized()) else None
+        self.device_index = device_index
+        self.tensors: Dict[int, "torch.Tensor"] = {}
+        self.ctx = None
+        self.stream = None
+        self._host: Dict[int, tuple] = {}
+        self.callback = self.CB(self._exchange)
+        self.calls = 0
+
+    def alloc_scratch(self, nbytes: int):
+        """Six device buffers (s[3], t[3]) as torch tensors; returns their addresses (for HostSolver(scratch=...))."""
+        torch = self.torch
+        ptrs = []
+        for _ in range(6):
+            t = torch.zeros(nbytes // 4, dtype=torch.float32, device=f"cuda:{self.device_index}")
+            self.tensors[t.data_ptr()] = t
+            ptrs.append(t.data_ptr())
+        torch.cuda.synchronize()
+        return ptrs
+
+    def bind(self, ctx, stream=None):
+        """ctx: kw_ctx* of the solver; stream: torch stream every launch of the solver is moved to (nccl ordering)."""
+        self.ctx = ctx
+        self.stream = stream
+        if stream is not None:
+            capi.check(capi.load().kw_set_stream(ctx, C.c_void_p(stream.cuda_stream)))
+
+    def _exchange(self, user, send, recv, bytes_per_peer):
+        self.calls += 1
+        torch, dist = self.torch, self.dist
+        n = bytes_per_peer * self.nranks
+        if self.backend == "nccl":
+            src, dst = self.tensors[send], self.tensors[recv]
+            with torch.cuda.stream(self.stream):
+                dist.all_to_all_single(dst[: n // 4], src[: n // 4])
+            return
+        # gloo (ranks sharing one GPU, tests): stage through pinned host memory
+        hip = capi.load()
+        key = n
+        if key not in self._host:
+            self._host[key] = (torch.empty(n // 4, dtype=torch.float32).pin_memory() if torch.cuda.is_available()
+                               else torch.empty(n // 4, dtype=torch.float32),
+                               torch.empty(n // 4, dtype=torch.float32))
+        hin, hout = self._host[key]
+        capi.check(hip.kw_memcpy_d2h(self.ctx, C.c_void_p(hin.data_ptr()), C.c_void_p(send), n))
+        dist.all_to_all_single(hout, hin)
+        capi.check(hip.kw_memcpy_h2d(self.ctx, C.c_void_p(recv), C.c_void_p(hout.data_ptr()), n))
+
+
+class DistSolver:
+    """One rank of a slab-decomposed simulation (wraps solver.HostSolver)."""
+
+    def __init__(self, pr_local: Dict[str, np.ndarray], rank: int, nranks: int, nz_global: int, device_index: int = 0,
+                 **opts):
+        from .solver import HostSolver
+        import torch
+        self.rank, self.nranks = rank, nranks
+        self.exchange = SlabExchange(nranks, device_index)
+        nx, ny, nzl = (_sc(pr_local[k]) for k in ("Nx", "Ny", "Nz"))
+        scratch = None
+        if self.exchange.backend == "nccl":
+            torch.cuda.set_device(device_index)
+            pitch = (nx // 2 + 1 + 15) // 16 * 16
+            scratch = self.exchange.alloc_scratch(pitch * ny * nzl * 8)
+        self.sim = HostSolver(pr_local, slab_ranks=nranks, slab_rank=rank, nz_global=nz_global,
+                              exchange_fn=self.exchange.callback, scratch=scratch, device_idx=device_index, **opts)
+        stream = torch.cuda.Stream(device=device_index) if self.exchange.backend == "nccl" else None
+        self.exchange.bind(self.sim.ctx, stream)
+
+    def __getattr__(self, name):
+        return getattr(self.sim, name)

@@ -41,11 +41,18 @@ void KSpaceFirstOrderSolver::initializeFftPlans()
   const DimensionSizes dims = mParameters.getFullDimensionSizes();
   kw_ctx* ctx = mParameters.getHipParameters().getContext();
   int fusedOk = 0;
-  if (mParameters.getOptions().fusedKernels) kwCheck(kw_fused_supported(ctx, &fusedOk));
+  const Parameters::Options& opt = mParameters.getOptions();
+  if (mParameters.isSlabDecomposed())
+    kwCheck(kw_fused_set_slab(ctx, static_cast<uint32_t>(opt.slabRanks), static_cast<uint32_t>(opt.slabRank),
+                              static_cast<uint32_t>(opt.nzGlobal), opt.exchangeFn, opt.exchangeUser));
+  if (opt.fusedKernels || mParameters.isSlabDecomposed()) kwCheck(kw_fused_supported(ctx, &fusedOk));
   mFused = (fusedOk != 0);
+  if (mParameters.isSlabDecomposed() && !mFused)
+    throw std::invalid_argument("Z-slab decomposition needs the fused pipeline (power-of-two grid, Ny and Nz divisible by the rank count)");
   if (mFused)
-  {
-    kwCheck(kw_fused_create(ctx)); // hand-written FFT passes: no library plans needed for the 3-D transforms
+  { // hand-written FFT passes: no library plans needed for the 3-D transforms
+    if (opt.scratch[0] != nullptr) kwCheck(kw_fused_create_with_scratch(ctx, opt.scratch, opt.scratch + 3));
+    else kwCheck(kw_fused_create(ctx));
   }
   else
   {
@@ -449,20 +456,22 @@ void KSpaceFirstOrderSolver::generateKappa()
   const float dy2Rec = 1.0f / (mParameters.getDy() * mParameters.getDy());
   const float dz2Rec = 1.0f / (mParameters.getDz() * mParameters.getDz());
   const float cRefDtPi = mParameters.getCRef() * mParameters.getDt() * static_cast<float>(M_PI);
-  const DimensionSizes full = mParameters.getFullDimensionSizes(), red = mParameters.getReducedDimensionSizes();
+  const DimensionSizes full = mParameters.getGlobalDimensionSizes(), red = mParameters.getReducedDimensionSizes();
+  // one GPU: [nz][ny][nxc].  Z-slab mode: this rank's spectra live transposed, [nz_global][ny/ranks][nxc], rows ky0..
+  const size_t nzg = full.nz, nyl = full.ny / mParameters.getSlabRanks(), ky0 = mParameters.getSlabRank() * nyl;
   const float nxRec = 1.0f / static_cast<float>(full.nx);
   const float nyRec = 1.0f / static_cast<float>(full.ny);
   const float nzRec = 1.0f / static_cast<float>(full.nz);
   float* kappa = real(MI::kKappa).getHostData();
 #pragma omp parallel for schedule(static)
-  for (size_t z = 0; z < red.nz; z++)
+  for (size_t z = 0; z < nzg; z++)
   {
     const float zf = static_cast<float>(z);
     float zPart    = 0.5f - std::fabs(0.5f - zf * nzRec);
     zPart          = (zPart * zPart) * dz2Rec;
-    for (size_t y = 0; y < red.ny; y++)
+    for (size_t yl = 0; yl < nyl; yl++)
     {
-      const float yf = static_cast<float>(y);
+      const float yf = static_cast<float>(ky0 + yl);
       float yPart    = 0.5f - std::fabs(0.5f - yf * nyRec);
       yPart          = (yPart * yPart) * dy2Rec;
       const float yzPart = zPart + yPart;
@@ -472,7 +481,7 @@ void KSpaceFirstOrderSolver::generateKappa()
         float xPart    = 0.5f - std::fabs(0.5f - xf * nxRec);
         xPart          = (xPart * xPart) * dx2Rec;
         const float k  = cRefDtPi * std::sqrt(xPart + yzPart);
-        kappa[(z * red.ny + y) * red.nx + x] = (k == 0.0f) ? 1.0f : std::sin(k) / k;
+        kappa[(z * nyl + yl) * red.nx + x] = (k == 0.0f) ? 1.0f : std::sin(k) / k;
       }
     }
   }
@@ -484,20 +493,22 @@ void KSpaceFirstOrderSolver::generateSourceKappa()
   const float dy2Rec = 1.0f / (mParameters.getDy() * mParameters.getDy());
   const float dz2Rec = 1.0f / (mParameters.getDz() * mParameters.getDz());
   const float cRefDtPi = mParameters.getCRef() * mParameters.getDt() * static_cast<float>(M_PI);
-  const DimensionSizes full = mParameters.getFullDimensionSizes(), red = mParameters.getReducedDimensionSizes();
+  const DimensionSizes full = mParameters.getGlobalDimensionSizes(), red = mParameters.getReducedDimensionSizes();
+  // one GPU: [nz][ny][nxc].  Z-slab mode: this rank's spectra live transposed, [nz_global][ny/ranks][nxc], rows ky0..
+  const size_t nzg = full.nz, nyl = full.ny / mParameters.getSlabRanks(), ky0 = mParameters.getSlabRank() * nyl;
   const float nxRec = 1.0f / static_cast<float>(full.nx);
   const float nyRec = 1.0f / static_cast<float>(full.ny);
   const float nzRec = 1.0f / static_cast<float>(full.nz);
   float* sourceKappa = real(MI::kSourceKappa).getHostData();
 #pragma omp parallel for schedule(static)
-  for (size_t z = 0; z < red.nz; z++)
+  for (size_t z = 0; z < nzg; z++)
   {
     const float zf = static_cast<float>(z);
     float zPart    = 0.5f - std::fabs(0.5f - zf * nzRec);
     zPart          = (zPart * zPart) * dz2Rec;
-    for (size_t y = 0; y < red.ny; y++)
+    for (size_t yl = 0; yl < nyl; yl++)
     {
-      const float yf = static_cast<float>(y);
+      const float yf = static_cast<float>(ky0 + yl);
       float yPart    = 0.5f - std::fabs(0.5f - yf * nyRec);
       yPart          = (yPart * yPart) * dy2Rec;
       const float yzPart = zPart + yPart;
@@ -507,7 +518,7 @@ void KSpaceFirstOrderSolver::generateSourceKappa()
         float xPart    = 0.5f - std::fabs(0.5f - xf * nxRec);
         xPart          = (xPart * xPart) * dx2Rec;
         const float k  = cRefDtPi * std::sqrt(xPart + yzPart);
-        sourceKappa[(z * red.ny + y) * red.nx + x] = std::cos(k);
+        sourceKappa[(z * nyl + yl) * red.nx + x] = std::cos(k);
       }
     }
   }
@@ -520,7 +531,9 @@ void KSpaceFirstOrderSolver::generateKappaAndNablas()
   const float dzSqRec = 1.0f / (mParameters.getDz() * mParameters.getDz());
   const float cRefDt2 = mParameters.getCRef() * mParameters.getDt() * 0.5f;
   const float pi2     = static_cast<float>(M_PI) * 2.0f;
-  const DimensionSizes full = mParameters.getFullDimensionSizes(), red = mParameters.getReducedDimensionSizes();
+  const DimensionSizes full = mParameters.getGlobalDimensionSizes(), red = mParameters.getReducedDimensionSizes();
+  // one GPU: [nz][ny][nxc].  Z-slab mode: this rank's spectra live transposed, [nz_global][ny/ranks][nxc], rows ky0..
+  const size_t nzg = full.nz, nyl = full.ny / mParameters.getSlabRanks(), ky0 = mParameters.getSlabRank() * nyl;
   const float nxRec = 1.0f / static_cast<float>(full.nx);
   const float nyRec = 1.0f / static_cast<float>(full.ny);
   const float nzRec = 1.0f / static_cast<float>(full.nz);
@@ -529,14 +542,14 @@ void KSpaceFirstOrderSolver::generateKappaAndNablas()
   float* absorbNabla2 = real(MI::kAbsorbNabla2).getHostData();
   const float alphaPower = mParameters.getAlphaPower();
 #pragma omp parallel for schedule(static)
-  for (size_t z = 0; z < red.nz; z++)
+  for (size_t z = 0; z < nzg; z++)
   {
     const float zf = static_cast<float>(z);
     float zPart    = 0.5f - std::fabs(0.5f - zf * nzRec);
     zPart          = (zPart * zPart) * dzSqRec;
-    for (size_t y = 0; y < red.ny; y++)
+    for (size_t yl = 0; yl < nyl; yl++)
     {
-      const float yf = static_cast<float>(y);
+      const float yf = static_cast<float>(ky0 + yl);
       float yPart    = 0.5f - std::fabs(0.5f - yf * nyRec);
       yPart          = (yPart * yPart) * dySqRec;
       const float yzPart = zPart + yPart;
@@ -547,7 +560,7 @@ void KSpaceFirstOrderSolver::generateKappaAndNablas()
         xPart          = (xPart * xPart) * dxSqRec;
         const float k     = pi2 * std::sqrt(xPart + yzPart);
         const float cRefK = cRefDt2 * k;
-        const size_t i    = (z * red.ny + y) * red.nx + x;
+        const size_t i    = (z * nyl + yl) * red.nx + x;
         kappa[i]          = (cRefK == 0.0f) ? 1.0f : std::sin(cRefK) / cRefK;
         absorbNabla1[i]   = std::pow(k, alphaPower - 2.0f);
         absorbNabla2[i]   = std::pow(k, alphaPower - 1.0f);

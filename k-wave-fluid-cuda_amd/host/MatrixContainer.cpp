@@ -11,6 +11,7 @@ void MatrixContainer::init()
   using MI = MatrixContainer::MatrixIdx;
   const Parameters& params = Parameters::getInstance();
   const DimensionSizes fullDims = params.getFullDimensionSizes(), reducedDims = params.getReducedDimensionSizes();
+  const size_t nzGlobal = params.getGlobalDimensionSizes().nz; // 1-D z operators stay global on a slab
   constexpr bool kLoad = true, kNoLoad = false, kCheckpoint = true, kNoCheckpoint = false;
 
   mContainer[MI::kKappa].set(MT::kReal, reducedDims, kNoLoad, kNoCheckpoint, "kappa_r");
@@ -35,10 +36,10 @@ void MatrixContainer::init()
   }
   mContainer[MI::kDdxKShiftPosR].set(MT::kComplex, DimensionSizes(reducedDims.nx, 1, 1), kLoad, kNoCheckpoint, kDdxKShiftPosRName);
   mContainer[MI::kDdyKShiftPos].set(MT::kComplex, DimensionSizes(1, reducedDims.ny, 1), kLoad, kNoCheckpoint, kDdyKShiftPosName);
-  mContainer[MI::kDdzKShiftPos].set(MT::kComplex, DimensionSizes(1, 1, reducedDims.nz), kLoad, kNoCheckpoint, kDdzKShiftPosName);
+  mContainer[MI::kDdzKShiftPos].set(MT::kComplex, DimensionSizes(1, 1, nzGlobal), kLoad, kNoCheckpoint, kDdzKShiftPosName);
   mContainer[MI::kDdxKShiftNegR].set(MT::kComplex, DimensionSizes(reducedDims.nx, 1, 1), kLoad, kNoCheckpoint, kDdxKShiftNegRName);
   mContainer[MI::kDdyKShiftNeg].set(MT::kComplex, DimensionSizes(1, reducedDims.ny, 1), kLoad, kNoCheckpoint, kDdyKShiftNegName);
-  mContainer[MI::kDdzKShiftNeg].set(MT::kComplex, DimensionSizes(1, 1, reducedDims.nz), kLoad, kNoCheckpoint, kDdzKShiftNegName);
+  mContainer[MI::kDdzKShiftNeg].set(MT::kComplex, DimensionSizes(1, 1, nzGlobal), kLoad, kNoCheckpoint, kDdzKShiftNegName);
   mContainer[MI::kPmlXSgx].set(MT::kReal, DimensionSizes(fullDims.nx, 1, 1), kLoad, kNoCheckpoint, kPmlXSgxName);
   mContainer[MI::kPmlYSgy].set(MT::kReal, DimensionSizes(1, fullDims.ny, 1), kLoad, kNoCheckpoint, kPmlYSgyName);
   mContainer[MI::kPmlZSgz].set(MT::kReal, DimensionSizes(1, 1, fullDims.nz), kLoad, kNoCheckpoint, kPmlZSgzName);

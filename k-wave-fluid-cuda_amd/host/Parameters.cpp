@@ -26,6 +26,15 @@ void Parameters::init(const InputProvider& in, const Options& options)
   in.readScalarValue(kNzName, z);
   mFullDimensionSizes    = DimensionSizes(x, y, z);
   mReducedDimensionSizes = DimensionSizes((x / 2) + 1, y, z);
+  mGlobalDimensionSizes  = mFullDimensionSizes;
+  if (mOptions.slabRanks > 1)
+  {
+    if (mOptions.nzGlobal != z * mOptions.slabRanks || mOptions.slabRank >= mOptions.slabRanks || y % mOptions.slabRanks != 0)
+      throw std::invalid_argument("Z-slab decomposition: Nz_global must equal slabRanks * local Nz and Ny must divide by slabRanks");
+    mGlobalDimensionSizes.nz = mOptions.nzGlobal;
+    if (needsShiftedVelocity())
+      throw std::invalid_argument("Z-slab decomposition: non-staggered velocity / intensity streams are not supported yet");
+  }
   if (!isSimulation3D())
     throw std::invalid_argument("Only 3-D simulations are implemented in this build (2-D is a later scope row)");
 
@@ -165,10 +174,11 @@ void HipParameters::setUpDeviceConstants() const
   k.ny_complex = static_cast<uint32_t>(red.ny);
   k.nz_complex = static_cast<uint32_t>(red.nz);
   k.n_elements_complex = static_cast<uint32_t>(red.nElements());
-  k.fft_divider   = 1.0f / full.nElements();
-  k.fft_divider_x = 1.0f / full.nx;
-  k.fft_divider_y = 1.0f / full.ny;
-  k.fft_divider_z = 1.0f / full.nz;
+  const DimensionSizes global = params.getGlobalDimensionSizes();
+  k.fft_divider   = 1.0f / global.nElements(); // 1/N of the whole grid also on a slab
+  k.fft_divider_x = 1.0f / global.nx;
+  k.fft_divider_y = 1.0f / global.ny;
+  k.fft_divider_z = 1.0f / global.nz;
   k.dt      = params.getDt();
   k.dt_by_2 = params.getDt() * 2.0f;
   k.c2      = params.getC2Scalar();

@@ -56,6 +56,13 @@ class Parameters
     size_t mos = 1, harmonics = 1;
     bool   noCompressionOverlap = false;
     bool   fusedKernels = true; // MI355X fused per-step kernels (false: one launch per reference kernel)
+    // Z-slab decomposition over several GPUs (one process per GPU; new with this build — the reference is single-GPU).
+    // The input then describes the LOCAL slab: Nz = nzGlobal/slabRanks planes of every 3-D array, the local slice of
+    // pml_z / pml_z_sgz, local (re-based) source / sensor indices; 1-D k-space operators stay global.
+    size_t slabRanks = 1, slabRank = 0, nzGlobal = 0;
+    kw_exchange_fn exchangeFn = nullptr; // all-to-all provided by the driver (RCCL through torch.distributed)
+    void*  exchangeUser = nullptr;
+    void*  scratch[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}; // optional caller-owned pipeline scratch
   };
 
   static Parameters& getInstance();
@@ -67,10 +74,15 @@ class Parameters
   const HipParameters& getHipParameters() const { return mHipParameters; }
   const Options&       getOptions() const { return mOptions; }
 
+  /// local (this rank's slab) sizes; equal to the global ones on one GPU
   DimensionSizes getFullDimensionSizes() const { return mFullDimensionSizes; }
+  DimensionSizes getGlobalDimensionSizes() const { return mGlobalDimensionSizes; }
+  size_t getSlabRanks() const { return mOptions.slabRanks; }
+  size_t getSlabRank() const { return mOptions.slabRank; }
+  bool   isSlabDecomposed() const { return mOptions.slabRanks > 1; }
   DimensionSizes getReducedDimensionSizes() const { return mReducedDimensionSizes; }
-  bool           isSimulation3D() const { return mFullDimensionSizes.is3D(); }
-  bool           isSimulation2D() const { return mFullDimensionSizes.is2D(); }
+  bool           isSimulation3D() const { return mGlobalDimensionSizes.is3D(); }
+  bool           isSimulation2D() const { return mGlobalDimensionSizes.is2D(); }
   SimulationDimension getSimulationDimension() const
   {
     return isSimulation3D() ? SimulationDimension::k3D : SimulationDimension::k2D;
@@ -164,7 +176,7 @@ class Parameters
 
   HipParameters  mHipParameters;
   Options        mOptions;
-  DimensionSizes mFullDimensionSizes, mReducedDimensionSizes;
+  DimensionSizes mFullDimensionSizes, mReducedDimensionSizes, mGlobalDimensionSizes;
   size_t mNt = 0, mTimeIndex = 0;
   float  mDt = 0, mDx = 0, mDy = 0, mDz = 0, mCRef = 0;
   bool   mC0ScalarFlag = true;

@@ -56,6 +56,12 @@ int kwh_create(const kwh_dataset* datasets, size_t n, const kwh_options* o, kwh_
   opt.storePressureC = o->p_c; opt.storeVelocityNonStaggeredC = o->u_non_staggered_c;
   opt.storeIntensityAvgC = o->i_avg_c; opt.noCompressionOverlap = o->no_overlap;
   opt.period = o->period; opt.mos = o->mos ? o->mos : 1; opt.harmonics = o->harmonics ? o->harmonics : 1;
+  opt.slabRanks = o->slab_ranks ? o->slab_ranks : 1;
+  opt.slabRank  = o->slab_rank;
+  opt.nzGlobal  = o->nz_global;
+  opt.exchangeFn   = reinterpret_cast<kw_exchange_fn>(o->exchange_fn);
+  opt.exchangeUser = o->exchange_user;
+  for (int i = 0; i < 6; i++) opt.scratch[i] = o->scratch[i];
 
   Parameters& params = Parameters::getInstance();
   params.init(s->input, opt);

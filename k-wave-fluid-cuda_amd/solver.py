@@ -36,7 +36,9 @@ class Options(C.Structure):
                [(n, C.c_int32) for n in ("p_raw", "p_rms", "p_max", "p_min", "p_max_all", "p_min_all", "p_final",
                                          "u_raw", "u_rms", "u_max", "u_min", "u_max_all", "u_min_all", "u_final",
                                          "u_non_staggered_raw", "p_c", "u_non_staggered_c", "i_avg_c", "no_overlap")] + \
-               [("period", C.c_float), ("mos", C.c_uint64), ("harmonics", C.c_uint64)]
+               [("period", C.c_float), ("mos", C.c_uint64), ("harmonics", C.c_uint64),
+                ("slab_ranks", C.c_uint64), ("slab_rank", C.c_uint64), ("nz_global", C.c_uint64),
+                ("exchange_fn", C.c_void_p), ("exchange_user", C.c_void_p), ("scratch", C.c_void_p * 6)]
 
 
 _hlib: Optional[C.CDLL] = None
@@ -112,6 +114,18 @@ class HostSolver:
         o.period = float(opts.pop("period", 0.0))
         o.mos = int(opts.pop("mos", 1))
         o.harmonics = int(opts.pop("harmonics", 1))
+        # Z-slab decomposition (see dist.py): the problem dict is this rank's slab
+        o.slab_ranks = int(opts.pop("slab_ranks", 1))
+        o.slab_rank = int(opts.pop("slab_rank", 0))
+        o.nz_global = int(opts.pop("nz_global", 0))
+        fn = opts.pop("exchange_fn", None)
+        if fn is not None:
+            self._keep.append(fn)  # keep the ctypes callback alive
+            o.exchange_fn = C.cast(fn, C.c_void_p)
+        scratch = opts.pop("scratch", None)
+        if scratch is not None:
+            for i, ptr in enumerate(scratch):
+                o.scratch[i] = ptr
         for k, v in opts.items():
             if not hasattr(o, k):
                 raise TypeError(f"unknown option {k}")

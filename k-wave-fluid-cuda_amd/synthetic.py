@@ -77,10 +77,19 @@ def pml_vectors(n: int, d: float, dt: float, c_ref: float, size: int, alpha: flo
     return pml.astype(F32)
 
 
-def _grid(nx, ny, nz):
-    z, y, x = np.meshgrid(np.arange(nz, dtype=np.float64), np.arange(ny, dtype=np.float64),
+def _grid(nx, ny, nz, zlo=0, zhi=None):
+    zhi = nz if zhi is None else zhi
+    z, y, x = np.meshgrid(np.arange(zlo, zhi, dtype=np.float64), np.arange(ny, dtype=np.float64),
                           np.arange(nx, dtype=np.float64), indexing="ij")
     return x, y, z
+
+
+def _c0_field(x, y, z, nx, ny, nz):
+    two_pi = 2.0 * math.pi
+    n = max(nx, ny, nz)
+    c0 = 1500.0 * (1.0 + 0.05 * np.sin(two_pi * 3 * x / nx) * np.cos(two_pi * 2 * y / ny) * np.cos(two_pi * z / nz))
+    r2 = (x - nx // 2) ** 2 + (y - ny // 2) ** 2 + (z - nz // 2) ** 2
+    return np.where(r2 <= (n / 6.0) ** 2, 1600.0, c0)
 
 
 def _sg_mean(a: np.ndarray, axis: int) -> np.ndarray:
@@ -96,7 +105,7 @@ def make_problem(nx: int, ny: Optional[int] = None, nz: Optional[int] = None, *,
                  pml_off: bool = False, dx: float = 2.0e-4, cfl: float = 0.3,
                  source_mode: int = 0, source_many: int = 0, sensor: str = "plane",
                  hetero_subset: Optional[dict] = None, seed: int = 0x5EED1234,
-                 nt_src: Optional[int] = None) -> Dict[str, np.ndarray]:
+                 nt_src: Optional[int] = None, zslab: Optional[tuple] = None) -> Dict[str, np.ndarray]:
     """Build one synthetic problem.
 
     source: "p0" (1 MPa Gaussian ball), "p_source" (1 MHz tone burst on plane x=12),
@@ -104,12 +113,17 @@ def make_problem(nx: int, ny: Optional[int] = None, nz: Optional[int] = None, *,
     hetero_subset: optionally {"c0": bool, "rho0": bool, "BonA": bool, "alpha_coeff": bool} to mix
             scalar / array medium parameters (detected per dataset by shape in the reference:
             /root/reference/Parameters/Parameters.cpp:426-459).
+    zslab:  (z_lo, z_hi): build the 3-D arrays only for planes z_lo <= z < z_hi (multi-GPU runs generate their own
+            slab; every other dataset — scalars, operators, PML vectors, index masks — stays global and is cut to
+            the slab by dist.partition_problem(..., arrays_are_local=True)).
     """
     ny = nx if ny is None else ny
     nz = nx if nz is None else nz
     dy = dz = dx
-    n = max(nx, ny, nz)
-    x, y, z = _grid(nx, ny, nz)
+    zlo, zhi = (0, nz) if zslab is None else (int(zslab[0]), int(zslab[1]))
+    zext = min(zhi + 1, nz)  # one extra plane for the staggered-grid mean along z
+    x, y, z = _grid(nx, ny, nz, zlo, zext)
+    nzl = zhi - zlo
     two_pi = 2.0 * math.pi
     het = {"c0": heterogeneous, "rho0": heterogeneous, "BonA": heterogeneous, "alpha_coeff": heterogeneous}
     if hetero_subset:
@@ -125,26 +139,31 @@ def make_problem(nx: int, ny: Optional[int] = None, nz: Optional[int] = None, *,
 
     # ---- medium -------------------------------------------------------------------------------
     if het["c0"]:
-        c0 = 1500.0 * (1.0 + 0.05 * np.sin(two_pi * 3 * x / nx) * np.cos(two_pi * 2 * y / ny) * np.cos(two_pi * z / nz))
-        r2 = (x - nx // 2) ** 2 + (y - ny // 2) ** 2 + (z - nz // 2) ** 2
-        c0 = np.where(r2 <= (n / 6.0) ** 2, 1600.0, c0)
-        pr["c0"] = c0.astype(F32)
+        c0 = _c0_field(x, y, z, nx, ny, nz)
+        pr["c0"] = c0[:nzl].astype(F32)
+        if zslab is None:
+            c_ref = float(pr["c0"].max())
+        else:  # c_ref is the global maximum: evaluate the closed form plane by plane
+            c_ref = 0.0
+            for zz in range(nz):
+                xp, yp, zp = _grid(nx, ny, nz, zz, zz + 1)
+                c_ref = max(c_ref, float(_c0_field(xp, yp, zp, nx, ny, nz).astype(F32).max()))
     else:
         pr["c0"] = scalar_f(1500.0)
-    c_ref = float(pr["c0"].max())
+        c_ref = 1500.0
     if het["rho0"]:
         rho0 = 1000.0 * (1.0 + 0.04 * np.cos(two_pi * 2 * x / nx) * np.sin(two_pi * 3 * z / nz))
-        pr["rho0"] = rho0.astype(F32)
-        pr["rho0_sgx"] = _sg_mean(rho0, 2).astype(F32)
-        pr["rho0_sgy"] = _sg_mean(rho0, 1).astype(F32)
-        pr["rho0_sgz"] = _sg_mean(rho0, 0).astype(F32)
+        pr["rho0"] = rho0[:nzl].astype(F32)
+        pr["rho0_sgx"] = _sg_mean(rho0, 2)[:nzl].astype(F32)
+        pr["rho0_sgy"] = _sg_mean(rho0, 1)[:nzl].astype(F32)
+        pr["rho0_sgz"] = _sg_mean(rho0, 0)[:nzl].astype(F32)
     else:
         for nm in ("rho0", "rho0_sgx", "rho0_sgy", "rho0_sgz"):
             pr[nm] = scalar_f(1000.0)
     if nonlinear:
-        pr["BonA"] = (6.0 + 2.0 * np.sin(two_pi * y / ny)).astype(F32) if het["BonA"] else scalar_f(6.0)
+        pr["BonA"] = (6.0 + 2.0 * np.sin(two_pi * y / ny))[:nzl].astype(F32) if het["BonA"] else scalar_f(6.0)
     if absorbing:
-        pr["alpha_coeff"] = ((0.75 + 0.25 * np.cos(two_pi * x / nx)).astype(F32)
+        pr["alpha_coeff"] = ((0.75 + 0.25 * np.cos(two_pi * x / nx))[:nzl].astype(F32)
                              if het["alpha_coeff"] else scalar_f(0.75))
         pr["alpha_power"] = scalar_f(1.5)
 
@@ -176,7 +195,7 @@ def make_problem(nx: int, ny: Optional[int] = None, nz: Optional[int] = None, *,
     if source == "p0":
         sigma = 4.0
         r2 = (x - nx // 2) ** 2 + (y - ny // 2) ** 2 + (z - nz // 2) ** 2
-        pr["p0_source_input"] = (1.0e6 * np.exp(-r2 / (2.0 * sigma * sigma))).astype(F32)
+        pr["p0_source_input"] = (1.0e6 * np.exp(-r2 / (2.0 * sigma * sigma)))[:nzl].astype(F32)
         pr["p0_source_flag"] = scalar_u(1)
     elif source in ("p_source", "u_source", "transducer"):
         xs = min(12, nx - 1)

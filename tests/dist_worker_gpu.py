@@ -1,0 +1,57 @@
+"""Worker for tests/test_gpu_dist.py: P ranks share one MI355X, all-to-all through gloo (host staging); with
+backend nccl (one GPU per rank) the same code runs the RCCL path.  Rank 0 writes the gathered fields to --out."""
+import argparse
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import kwave_amd  # noqa: E402,F401
+from kwave_amd import synthetic  # noqa: E402
+from kwave_amd.dist import DistSolver, partition_problem  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--dims", type=int, nargs=3, default=[32, 32, 32])
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--source", default="p0")
+    ap.add_argument("--mode", type=int, default=0)
+    ap.add_argument("--backend", default="gloo")
+    ap.add_argument("--out", required=True)
+    a = ap.parse_args()
+    dist.init_process_group(a.backend)
+    rank, P = dist.get_rank(), dist.get_world_size()
+    dev = int(os.environ.get("LOCAL_RANK", "0")) if a.backend == "nccl" else 0
+    nx, ny, nz = a.dims
+    pr = synthetic.make_problem(nx, ny, nz, heterogeneous=True, nonlinear=True, absorbing=True, source=a.source,
+                                source_mode=a.mode, source_many=1, nt=a.steps, pml_size=4, sensor="random")
+    loc, info = partition_problem(pr, rank, P)
+    sim = DistSolver(loc, rank, P, nz, device_index=dev, p_raw=1, p_max=1)
+    sim.run(a.steps)
+    sim.finish()
+    fields = {k: sim.field(k) for k in ("p", "ux", "uz", "rhoy")}
+    series = sim.stream("p") if info["sensor_positions"].size else np.zeros((a.steps, 0), dtype=np.float32)
+    gathered = [None] * P if rank == 0 else None
+    dist.gather_object({"fields": fields, "series": series, "pos": info["sensor_positions"]}, gathered, dst=0)
+    if rank == 0:
+        out = {k: np.concatenate([g["fields"][k] for g in gathered], axis=0) for k in fields}
+        n_sens = pr["sensor_mask_index"].size
+        full = np.zeros((a.steps, n_sens), dtype=np.float32)
+        for g in gathered:
+            if g["pos"].size:
+                full[:, g["pos"]] = g["series"]
+        out["series"] = full
+        out["exchanges"] = np.array([sim.exchange.calls])
+        np.savez(a.out, **out)
+    sim.close()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
