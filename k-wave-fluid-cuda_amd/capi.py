@@ -119,6 +119,19 @@ _SIG: Dict[str, list] = {
     "kw_sum_pressure_nonlinear_lossless": [_P] + [_P] * 7,
     "kw_sum_pressure_linear_lossless": [_P] + [_P] * 5,
     "kw_compute_velocity_shift": [_P, C.c_int, _P, _P],
+    "kw_fused_set_slab": [_P, C.c_uint32, C.c_uint32, C.c_uint32, _P, _P],
+    "kw_fused_scratch_bytes": [_P, C.POINTER(C.c_size_t)],
+    "kw_fused_create_with_scratch": [_P, _P, _P],
+    "kw_fused_supported": [_P, C.POINTER(C.c_int)],
+    "kw_fused_create": [_P],
+    "kw_fused_destroy": [_P],
+    "kw_fused_reduced_elems": [_P, C.POINTER(C.c_size_t)],
+    "kw_fused_import_reduced": [_P, _P, _P],
+    "kw_fused_velocity": [_P] + [_P] * 14,
+    "kw_fused_initial_velocity": [_P] + [_P] * 11,
+    "kw_fused_density": [_P, C.c_int] + [_P] * 14 + [_P] * 3 + [C.c_int, _P, _P, _P, _P],
+    "kw_fused_absorption_pressure": [_P] + [_P] * 9,
+    "kw_fused_scale_source": [_P, _P, _P],
     "kw_sample_index": [_P, C.c_int, _P, _P, _P, _U64],
     "kw_sample_cuboid": [_P, C.c_int, _P, _P, _P, _P, _P, _U64],
     "kw_sample_all": [_P, C.c_int, _P, _P, _U64],
