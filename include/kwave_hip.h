@@ -135,6 +135,11 @@ KW_API kw_status kw_memcpy_d2h(kw_ctx* ctx, void* dst, const void* src, size_t b
 KW_API kw_status kw_memcpy_d2d(kw_ctx* ctx, void* dst, const void* src, size_t bytes);
 KW_API kw_status kw_memcpy_d2h_async(kw_ctx* ctx, void* dst, const void* src, size_t bytes);
 KW_API kw_status kw_memset(kw_ctx* ctx, void* dptr, int value, size_t bytes);
+/* device -> pinned host on the context's COPY stream, ordered after everything enqueued so far on the compute stream;
+ * `event` (kw_event_create) is recorded when the copy has landed.  The compute stream is not blocked: this is how raw
+ * sensor series leave the device while the next step computes (reference: zero-copy mapped buffer + cudaEvent,
+ * BaseOutputStream.cpp:369-388, IndexOutputStream.cpp:263,354). */
+KW_API kw_status kw_memcpy_d2h_overlapped(kw_ctx* ctx, void* dst, const void* src, size_t bytes, void* event);
 /* pinned host memory (reference: cudaHostRegister / mapped buffers, BaseOutputStream.cpp:369-388) */
 KW_API kw_status kw_host_alloc(kw_ctx* ctx, size_t bytes, void** out_hptr);
 KW_API kw_status kw_host_free(kw_ctx* ctx, void* hptr);
@@ -281,7 +286,14 @@ KW_API kw_status kw_fused_velocity(kw_ctx* ctx, const float* p, float* ux_sgx, f
                                    const float* dt_rho0_sgx, const float* dt_rho0_sgy, const float* dt_rho0_sgz,
                                    const float* pml_x_sgx, const float* pml_y_sgy, const float* pml_z_sgz,
                                    const float* kappa_padded, const float* ddx_k_shift_pos,
-                                   const float* ddy_k_shift_pos, const float* ddz_k_shift_pos);
+                                   const float* ddy_k_shift_pos, const float* ddz_k_shift_pos, int chain_u_spectra);
+/* chain_u_spectra != 0: the kernel that updates u also forward-transforms the updated rows along x into the pipeline's
+ * scratch, so kw_fused_density(flags & KW_FUSED_U_IN_SCRATCH) skips re-reading u.  Only valid when nothing else
+ * (velocity / transducer source injection) writes u in between. */
+#define KW_FUSED_U_IN_SCRATCH 1 /* kw_fused_density: x-spectra of ux,uy,uz are already in scratch */
+#define KW_FUSED_CHAIN_TERMS  2 /* kw_fused_density: chain the x-spectra of rho0*sum(du) and sum(rho) into scratch for
+                                   kw_fused_absorption_pressure(terms_in_scratch = 1); only the term the pressure sum
+                                   re-reads (t1 nonlinear / t0 linear) is stored, the other t arrays are left untouched */
 /* second half of addInitialPressureSource (KSpaceFirstOrderSolver.cpp:2368-2395; .cu:949-982) */
 KW_API kw_status kw_fused_initial_velocity(kw_ctx* ctx, const float* p, float* ux_sgx, float* uy_sgy, float* uz_sgz,
                                            const float* dt_rho0_sgx, const float* dt_rho0_sgy,
@@ -298,13 +310,13 @@ KW_API kw_status kw_fused_density(kw_ctx* ctx, int nonlinear, const float* ux_sg
                                   const float* kappa_padded, const float* ddx_k_shift_neg,
                                   const float* ddy_k_shift_neg, const float* ddz_k_shift_neg, float* duxdx,
                                   float* duydy, float* duzdz, int terms, const float* b_on_a, float* t0, float* t1,
-                                  float* t2);
+                                  float* t2, int flags);
 /* absorbing branch of computePressure{Nonlinear,Linear} after the terms (KSpaceFirstOrderSolver.cpp:2196-2204,
  * 2231-2239; .cu:1812-1820,1865-1879,1966-1980): first = nonlinear term or density sum */
 KW_API kw_status kw_fused_absorption_pressure(kw_ctx* ctx, float* p, const float* velocity_gradient_term,
                                               const float* density_sum, const float* first,
                                               const float* nabla1_padded, const float* nabla2_padded, const float* c2,
-                                              const float* absorb_tau, const float* absorb_eta);
+                                              const float* absorb_tau, const float* absorb_eta, int terms_in_scratch);
 /* FFT part of scaleSource (KSpaceFirstOrderSolver.cpp:2346-2351; .cu:740-745), in place on scaled_source */
 KW_API kw_status kw_fused_scale_source(kw_ctx* ctx, float* scaled_source, const float* source_kappa_padded);
 

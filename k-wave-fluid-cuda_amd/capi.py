@@ -86,6 +86,7 @@ _SIG: Dict[str, list] = {
     "kw_memcpy_d2d": [_P, _P, _P, C.c_size_t],
     "kw_memcpy_d2h_async": [_P, _P, _P, C.c_size_t],
     "kw_memset": [_P, _P, C.c_int, C.c_size_t],
+    "kw_memcpy_d2h_overlapped": [_P, _P, _P, C.c_size_t, _P],
     "kw_host_alloc": [_P, C.c_size_t, C.POINTER(_P)],
     "kw_host_free": [_P, _P],
     "kw_set_constants": [_P, C.POINTER(Constants)],
@@ -127,10 +128,10 @@ _SIG: Dict[str, list] = {
     "kw_fused_destroy": [_P],
     "kw_fused_reduced_elems": [_P, C.POINTER(C.c_size_t)],
     "kw_fused_import_reduced": [_P, _P, _P],
-    "kw_fused_velocity": [_P] + [_P] * 14,
+    "kw_fused_velocity": [_P] + [_P] * 14 + [C.c_int],
     "kw_fused_initial_velocity": [_P] + [_P] * 11,
-    "kw_fused_density": [_P, C.c_int] + [_P] * 14 + [_P] * 3 + [C.c_int, _P, _P, _P, _P],
-    "kw_fused_absorption_pressure": [_P] + [_P] * 9,
+    "kw_fused_density": [_P, C.c_int] + [_P] * 14 + [_P] * 3 + [C.c_int, _P, _P, _P, _P, C.c_int],
+    "kw_fused_absorption_pressure": [_P] + [_P] * 9 + [C.c_int],
     "kw_fused_scale_source": [_P, _P, _P],
     "kw_sample_index": [_P, C.c_int, _P, _P, _P, _U64],
     "kw_sample_cuboid": [_P, C.c_int, _P, _P, _P, _P, _P, _U64],

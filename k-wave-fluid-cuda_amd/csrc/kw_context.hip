@@ -67,6 +67,13 @@ kw_status kw_init(int device_id, kw_ctx** out_ctx)
     return KW_ERR_HIP;
   }
   ctx->stream = ctx->own_stream;
+  if (hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking) != hipSuccess ||
+      hipEventCreateWithFlags(&ctx->copy_fence, hipEventDisableTiming) != hipSuccess)
+  {
+    kw_set_error("GPU error: cannot create the copy stream (kw_init)");
+    delete ctx;
+    return KW_ERR_HIP;
+  }
   *out_ctx    = ctx;
   return KW_OK;
 }
@@ -77,6 +84,8 @@ kw_status kw_destroy(kw_ctx* ctx)
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
   kw_fft_destroy_plans(ctx);
+  if (ctx->copy_stream) { (void)hipStreamSynchronize(ctx->copy_stream); (void)hipStreamDestroy(ctx->copy_stream); }
+  if (ctx->copy_fence) (void)hipEventDestroy(ctx->copy_fence);
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
   delete ctx;
   return KW_OK;
@@ -249,6 +258,20 @@ kw_status kw_memcpy_d2h_async(kw_ctx* ctx, void* dst, const void* src, size_t by
   if (bytes == 0) return KW_OK;
   KW_REQUIRE(dst != nullptr && src != nullptr);
   KW_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+  return KW_OK;
+}
+kw_status kw_memcpy_d2h_overlapped(kw_ctx* ctx, void* dst, const void* src, size_t bytes, void* event)
+{
+  KW_CHECK_CTX(ctx);
+  KW_REQUIRE(event != nullptr);
+  if (bytes > 0)
+  {
+    KW_REQUIRE(dst != nullptr && src != nullptr);
+    KW_HIP(hipEventRecord(ctx->copy_fence, ctx->stream));
+    KW_HIP(hipStreamWaitEvent(ctx->copy_stream, ctx->copy_fence, 0));
+    KW_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->copy_stream));
+  }
+  KW_HIP(hipEventRecord((hipEvent_t)event, (bytes > 0) ? ctx->copy_stream : ctx->stream));
   return KW_OK;
 }
 kw_status kw_memcpy_d2d(kw_ctx* ctx, void* dst, const void* src, size_t bytes)

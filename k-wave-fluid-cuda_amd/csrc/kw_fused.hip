@@ -275,23 +275,18 @@ struct XfwdArgs
   uint32_t      nx, P;
 };
 
-template<int L> __global__ __launch_bounds__(Geo<L>::THREADS) void k_xfwd(XfwdArgs a)
+// forward line FFT of this block's 16 complex lines (= 32 real rows) from the step-A registers v (valid for f < R2),
+// split into the two half-spectra and stored to rows tile_row0.. of `out`.  Called by every thread of the block; the
+// exchange buffer must be free on entry and is free again on exit (trailing barrier).
+template<int L>
+__device__ __forceinline__ void xfwd_tail(float2 (&v)[Fac<L>::R1], float2* lds, int c, int f,
+                                          const float2* __restrict__ tw, float2* __restrict__ out, uint32_t P)
 {
   using G = Geo<L>;
   constexpr int R1 = G::R1, R2 = G::R2, HALF = L / 2 + 1;
-  __shared__ float2 lds[G::LDSX];
-  const int    f   = threadIdx.x % G::TPL;
-  const int    c   = threadIdx.x / G::TPL;
-  const float* __restrict__ in = a.in[blockIdx.y];
-  const size_t row0 = (static_cast<size_t>(blockIdx.x) * NL + c) * 2;
   if (f < R2)
   {
-    float2 v[R1];
-    const float* __restrict__ ra = in + row0 * L;
-    const float* __restrict__ rb = ra + L;
-#pragma unroll
-    for (int n1 = 0; n1 < R1; n1++) v[n1] = make_float2(ra[n1 * R2 + f], rb[n1 * R2 + f]);
-    step_a<L, kFwd>(v, f, a.tw);
+    step_a<L, kFwd>(v, f, tw);
 #pragma unroll
     for (int k1 = 0; k1 < R1; k1++) lds[c * G::LP + k1 * (R2 + 1) + f] = v[k1];
   }
@@ -310,7 +305,6 @@ template<int L> __global__ __launch_bounds__(Geo<L>::THREADS) void k_xfwd(XfwdAr
     for (int k2 = 0; k2 < R2; k2++) lds[c * G::ZP + f + R1 * k2] = w[k2];
   }
   __syncthreads();
-  float2* __restrict__ out = a.out[blockIdx.y];
   const size_t tile_row0 = static_cast<size_t>(blockIdx.x) * NL * 2;
   for (int e = threadIdx.x; e < NL * HALF; e += G::THREADS)
   {
@@ -321,9 +315,30 @@ template<int L> __global__ __launch_bounds__(Geo<L>::THREADS) void k_xfwd(XfwdAr
     const float2 xa = make_float2(0.5f * (zk.x + zn.x), 0.5f * (zk.y - zn.y));
     const float2 xb = make_float2(0.5f * (zk.y + zn.y), 0.5f * (zn.x - zk.x));
     const size_t r  = tile_row0 + 2 * cc;
-    out[r * a.P + k]       = xa;
-    out[(r + 1) * a.P + k] = xb;
+    out[r * P + k]       = xa;
+    out[(r + 1) * P + k] = xb;
   }
+  __syncthreads();
+}
+
+template<int L> __global__ __launch_bounds__(Geo<L>::THREADS) void k_xfwd(XfwdArgs a)
+{
+  using G = Geo<L>;
+  constexpr int R1 = G::R1, R2 = G::R2;
+  __shared__ float2 lds[G::LDSX];
+  const int    f   = threadIdx.x % G::TPL;
+  const int    c   = threadIdx.x / G::TPL;
+  const float* __restrict__ in = a.in[blockIdx.y];
+  const size_t row0 = (static_cast<size_t>(blockIdx.x) * NL + c) * 2;
+  float2 v[R1];
+  if (f < R2)
+  {
+    const float* __restrict__ ra = in + row0 * L;
+    const float* __restrict__ rb = ra + L;
+#pragma unroll
+    for (int n1 = 0; n1 < R1; n1++) v[n1] = make_float2(ra[n1 * R2 + f], rb[n1 * R2 + f]);
+  }
+  xfwd_tail<L>(v, lds, c, f, a.tw, a.out[blockIdx.y], a.P);
 }
 
 // =====================================================================================================================
@@ -348,6 +363,7 @@ struct XinvArgs
   int           nonlinear;
   int           terms; // 0 none, 1 linear (t0 = sum rho, t1 = rho0*sum du), 2 nonlinear (t0, t1 = nonlinear term, t2)
   uint32_t      comp0; // first component of this launch (per-array launches)
+  float2*       fout[3]; // CHAIN: where the forward x-transform of the epilogue's result goes (scratch rows)
 };
 
 // standalone inverse of one array for this block's 32 rows; thread (c, f<R1) ends with x[f + R1*k2] of rows (2c, 2c+1)
@@ -404,7 +420,7 @@ __device__ __forceinline__ void   st4(float* p, const float4& v) { *reinterpret_
 // The inverse leaves each thread with x = f + R1*k2 of two rows — a 64-B-segment pattern.  The results are restaged
 // through LDS as a plain real tile [32 rows][L] and re-read as float4 in a row-contiguous mapping, so that every
 // epilogue access to the state / medium arrays is a 16-B-per-lane coalesced access.
-template<int L, int EPI> __global__ __launch_bounds__(Geo<L>::THREADS) void k_xinv(XinvArgs a)
+template<int L, int EPI, bool CHAIN> __global__ __launch_bounds__(Geo<L>::THREADS) void k_xinv(XinvArgs a)
 {
   using G = Geo<L>;
   constexpr int R1 = G::R1, R2 = G::R2;
@@ -419,6 +435,9 @@ template<int L, int EPI> __global__ __launch_bounds__(Geo<L>::THREADS) void k_xi
   const int c = threadIdx.x / G::TPL;
   const uint32_t comp = (NA == 1) ? blockIdx.y + a.comp0 : 0; // component / array index for single-array epilogues
   float4 res[NA][NQ];
+  constexpr int NF = CHAIN ? ((EPI == EPI_DENSITY) ? 2 : 1) : 1; // chained forward transforms
+  float4 fw[NF][NQ];
+  static_assert(!CHAIN || EPI == EPI_DENSITY || EPI == EPI_VELOCITY, "chain only after velocity / density");
 #pragma unroll
   for (int i = 0; i < NA; i++)
   {
@@ -496,6 +515,7 @@ template<int L, int EPI> __global__ __launch_bounds__(Geo<L>::THREADS) void k_xi
         }
       }
       st4(u + i, vu);
+      if constexpr (CHAIN) fw[0][q] = vu;
     }
     else if (EPI == EPI_INITVEL)
     { // :957-980: u = ifft * (dtRho0Sg * (fftDivider*0.5)) | u = ifft * (fftDivider*0.5*dtRho0Sg)
@@ -571,9 +591,9 @@ template<int L, int EPI> __global__ __launch_bounds__(Geo<L>::THREADS) void k_xi
           f4put(o1, t, ((eBonA * eRhoSum * eRhoSum) / (2.0f * r0)) + eRhoSum);
           f4put(o2, t, r0 * eDuSum);
         }
-        st4(a.t[0] + i, o0);
-        st4(a.t[1] + i, o1);
-        st4(a.t[2] + i, o2);
+        st4(a.t[1] + i, o1); // the nonlinear term is read again by the pressure sum
+        if constexpr (CHAIN) { fw[0][q] = o2; fw[1][q] = o0; }
+        else { st4(a.t[0] + i, o0); st4(a.t[2] + i, o2); }
       }
       else if (a.terms == 1)
       { // :1733-1741
@@ -585,8 +605,9 @@ template<int L, int EPI> __global__ __launch_bounds__(Geo<L>::THREADS) void k_xi
           const float duSum = f4get(dux, t) + f4get(duy, t) + f4get(duz, t);
           f4put(o1, t, f4get(r04, t) * duSum);
         }
-        st4(a.t[0] + i, o0);
-        st4(a.t[1] + i, o1);
+        st4(a.t[0] + i, o0); // the density sum is read again by the pressure sum
+        if constexpr (CHAIN) { fw[0][q] = o1; fw[1][q] = o0; }
+        else st4(a.t[1] + i, o1);
       }
     }
     else if (EPI == EPI_PSUM)
@@ -604,6 +625,35 @@ template<int L, int EPI> __global__ __launch_bounds__(Geo<L>::THREADS) void k_xi
       for (int t = 0; t < 4; t++)
         f4put(o, t, f4get(c24, t) * (f4get(fi, t) + (k.fft_divider * ((f4get(tt, t) * f4get(tau4, t)) - (f4get(et, t) * f4get(eta4, t))))));
       st4(a.out[0] + i, o);
+    }
+  }
+
+  // ---- chained forward x-transform of what the epilogue just produced (rows are still in registers): the consumer
+  // stage finds the spectra in the scratch arrays and skips its own x-forward pass and the HBM round trip ----
+  if constexpr (CHAIN)
+  {
+    constexpr int R1c = G::R1, R2c = G::R2;
+#pragma unroll
+    for (int jf = 0; jf < NF; jf++)
+    {
+#pragma unroll
+      for (int q = 0; q < NQ; q++)
+      {
+        const int e   = threadIdx.x + q * G::THREADS;
+        const int row = e / Q4;
+        const int x4  = e - row * Q4;
+        *reinterpret_cast<float4*>(&ldsr[row * RP + 4 * x4]) = fw[jf][q];
+      }
+      __syncthreads();
+      float2 v[R1c];
+      if (f < R2c)
+      {
+#pragma unroll
+        for (int n1 = 0; n1 < R1c; n1++)
+          v[n1] = make_float2(ldsr[(2 * c) * RP + n1 * R2c + f], ldsr[(2 * c + 1) * RP + n1 * R2c + f]);
+      }
+      __syncthreads(); // the real tile aliases the exchange buffer
+      xfwd_tail<L>(v, lds, c, f, a.tw, a.fout[(NA == 1) ? comp : jf], a.P);
     }
   }
 }
@@ -703,14 +753,14 @@ template<int MODE> kw_status launch_zfused(kw_ctx* ctx, int narr, ZArgs a)
   return KW_OK;
 }
 
-template<int EPI> kw_status launch_xinv(kw_ctx* ctx, int ncomp, XinvArgs a)
+template<int EPI, bool CHAIN = false> kw_status launch_xinv(kw_ctx* ctx, int ncomp, XinvArgs a)
 {
   const kw_constants& c = ctx->c;
   a.tw = ctx->fused.tw[0];
   a.c  = c;
   a.P  = ctx->fused.P;
   const dim3 grid(c.ny * c.nz / (2 * NL), ncomp, 1);
-#define M(LEN) LAUNCH((k_xinv<LEN, EPI>), grid, dim3(Geo<LEN>::THREADS), a)
+#define M(LEN) LAUNCH((k_xinv<LEN, EPI, CHAIN>), grid, dim3(Geo<LEN>::THREADS), a)
   KW_LEN_SWITCH(c.nx, M)
 #undef M
   return KW_OK;
@@ -743,7 +793,7 @@ kw_status exchange(kw_ctx* ctx, float2* send, float2* recv)
 kw_status forward_xy(kw_ctx* ctx, int narr, const float* const* in, int s0 = 0)
 {
   auto& f = ctx->fused;
-  KW_TRY(launch_xfwd(ctx, narr, in, f.s + s0));
+  if (in != nullptr) KW_TRY(launch_xfwd(ctx, narr, in, f.s + s0)); // nullptr: x-spectra were chained into S[] already
   if (f.nranks == 1) return launch_ypass(ctx, -1, narr, f.s + s0, f.s + s0, false, false);
   KW_TRY(launch_ypass(ctx, -1, narr, f.s + s0, f.t + s0, false, true));
   for (int i = 0; i < narr; i++) KW_TRY(exchange(ctx, f.t[s0 + i], f.s[s0 + i]));
@@ -918,7 +968,8 @@ kw_status kw_fused_import_reduced(kw_ctx* ctx, float* dst_padded, const float* s
 // A1-A4: u <- pml_sg*(pml_sg*u - dt/rho0_sg * ifftn(ddk_pos * kappa * fftn(p)) / N)
 kw_status kw_fused_velocity(kw_ctx* ctx, const float* p, float* ux, float* uy, float* uz, const float* dtx,
                             const float* dty, const float* dtz, const float* pmlx, const float* pmly, const float* pmlz,
-                            const float* kappa_padded, const float* ddx, const float* ddy, const float* ddz)
+                            const float* kappa_padded, const float* ddx, const float* ddy, const float* ddz,
+                            int chain_u_spectra)
 {
   KW_FUSED_READY(ctx);
   KW_PROF(ctx, "fused_velocity");
@@ -937,8 +988,8 @@ kw_status kw_fused_velocity(kw_ctx* ctx, const float* p, float* ux, float* uy, f
   float* u[3] = { ux, uy, uz };
   const float* dt[3] = { dtx, dty, dtz };
   const float* pml[3] = { pmlx, pmly, pmlz };
-  for (int i = 0; i < 3; i++) { x.in[i] = S[i]; x.out[i] = u[i]; x.m0[i] = dt[i]; x.m1[i] = pml[i]; }
-  if (ctx->fused.per_array)
+  for (int i = 0; i < 3; i++) { x.in[i] = S[i]; x.out[i] = u[i]; x.m0[i] = dt[i]; x.m1[i] = pml[i]; x.fout[i] = S[i]; }
+  if (ctx->fused.per_array && !chain_u_spectra)
   { // A/B knob: whole chain per array
     for (int i = 0; i < 3; i++)
     {
@@ -950,7 +1001,10 @@ kw_status kw_fused_velocity(kw_ctx* ctx, const float* p, float* ux, float* uy, f
   else
   {
     KW_TRY(inverse_y(ctx, 3));
-    KW_TRY(launch_xinv<EPI_VELOCITY>(ctx, 3, x));
+    // chained: the updated velocity rows are forward-transformed along x on the spot (valid as long as nothing else
+    // writes u before kw_fused_density(..., KW_FUSED_U_IN_SCRATCH))
+    if (chain_u_spectra) KW_TRY((launch_xinv<EPI_VELOCITY, true>(ctx, 3, x)));
+    else KW_TRY(launch_xinv<EPI_VELOCITY>(ctx, 3, x));
   }
   return KW_OK;
 }
@@ -986,10 +1040,13 @@ kw_status kw_fused_density(kw_ctx* ctx, int nonlinear, const float* ux, const fl
                            float* ry, float* rz, const float* pmlx, const float* pmly, const float* pmlz,
                            const float* rho0, const float* kappa_padded, const float* ddx, const float* ddy,
                            const float* ddz, float* duxdx, float* duydy, float* duzdz, int terms, const float* bona,
-                           float* t0, float* t1, float* t2)
+                           float* t0, float* t1, float* t2, int flags)
 {
   KW_FUSED_READY(ctx);
   KW_PROF(ctx, "fused_density");
+  const bool u_in_scratch = (flags & KW_FUSED_U_IN_SCRATCH) != 0;
+  const bool chain_terms  = (flags & KW_FUSED_CHAIN_TERMS) != 0;
+  KW_REQUIRE(!chain_terms || terms != 0);
   KW_REQUIRE(ux && uy && uz && rx && ry && rz && pmlx && pmly && pmlz && kappa_padded && ddx && ddy && ddz);
   KW_REQUIRE((duxdx == nullptr) == (duydy == nullptr) && (duxdx == nullptr) == (duzdz == nullptr));
   KW_REQUIRE(terms >= 0 && terms <= 2);
@@ -1004,7 +1061,7 @@ kw_status kw_fused_density(kw_ctx* ctx, int nonlinear, const float* ux, const fl
   {
     for (int i = 0; i < 3; i++)
     {
-      KW_TRY(forward_xy(ctx, 1, in3 + i, i));
+      KW_TRY(forward_xy(ctx, 1, u_in_scratch ? nullptr : in3 + i, i));
       z.arr0 = i;
       KW_TRY(launch_zfused<Z_VGRAD>(ctx, 1, z));
       KW_TRY(inverse_y(ctx, 1, i));
@@ -1012,7 +1069,7 @@ kw_status kw_fused_density(kw_ctx* ctx, int nonlinear, const float* ux, const fl
   }
   else
   {
-    KW_TRY(forward_xy(ctx, 3, in3));
+    KW_TRY(forward_xy(ctx, 3, u_in_scratch ? nullptr : in3));
     KW_TRY(launch_zfused<Z_VGRAD>(ctx, 3, z));
     KW_TRY(inverse_y(ctx, 3));
   }
@@ -1026,18 +1083,22 @@ kw_status kw_fused_density(kw_ctx* ctx, int nonlinear, const float* ux, const fl
   x.m0[1]     = bona;
   x.nonlinear = nonlinear;
   x.terms     = terms;
-  KW_TRY(launch_xinv<EPI_DENSITY>(ctx, 1, x));
+  x.fout[0]   = S[0]; // chained: x-spectrum of rho0 * sum(du)
+  x.fout[1]   = S[1]; //          x-spectrum of sum(rho)
+  if (chain_terms) KW_TRY((launch_xinv<EPI_DENSITY, true>(ctx, 1, x)));
+  else KW_TRY(launch_xinv<EPI_DENSITY>(ctx, 1, x));
   return KW_OK;
 }
 
 // A11 absorbing branch after the terms: p = c2*(first + d*(tau*ifftn(nabla1*fftn(vel_grad_term)) - eta*ifftn(nabla2*fftn(density_sum))))
 kw_status kw_fused_absorption_pressure(kw_ctx* ctx, float* p, const float* vel_grad_term, const float* density_sum,
                                        const float* first, const float* nabla1_padded, const float* nabla2_padded,
-                                       const float* c2, const float* tau, const float* eta)
+                                       const float* c2, const float* tau, const float* eta, int terms_in_scratch)
 {
   KW_FUSED_READY(ctx);
   KW_PROF(ctx, "fused_absorption_pressure");
-  KW_REQUIRE(p && vel_grad_term && density_sum && first && nabla1_padded && nabla2_padded);
+  KW_REQUIRE(p && first && nabla1_padded && nabla2_padded);
+  KW_REQUIRE(terms_in_scratch || (vel_grad_term && density_sum));
   KW_REQUIRE((tau == nullptr) == (eta == nullptr));
   float2** S = ctx->fused.s;
   const float* in2[2] = { vel_grad_term, density_sum };
@@ -1049,7 +1110,7 @@ kw_status kw_fused_absorption_pressure(kw_ctx* ctx, float* p, const float* vel_g
   {
     for (int i = 0; i < 2; i++)
     {
-      KW_TRY(forward_xy(ctx, 1, in2 + i, i));
+      KW_TRY(forward_xy(ctx, 1, terms_in_scratch ? nullptr : in2 + i, i));
       z.arr0 = i;
       KW_TRY(launch_zfused<Z_ABSORB>(ctx, 1, z));
       KW_TRY(inverse_y(ctx, 1, i));
@@ -1057,7 +1118,7 @@ kw_status kw_fused_absorption_pressure(kw_ctx* ctx, float* p, const float* vel_g
   }
   else
   {
-    KW_TRY(forward_xy(ctx, 2, in2));
+    KW_TRY(forward_xy(ctx, 2, terms_in_scratch ? nullptr : in2));
     KW_TRY(launch_zfused<Z_ABSORB>(ctx, 2, z));
     KW_TRY(inverse_y(ctx, 2));
   }

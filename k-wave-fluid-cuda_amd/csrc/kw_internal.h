@@ -24,6 +24,8 @@ struct kw_ctx
   int          device      = 0;
   hipStream_t  own_stream  = nullptr;
   hipStream_t  stream      = nullptr; // stream every launch goes to
+  hipStream_t  copy_stream = nullptr; // D2H of sampled series, overlapped with compute
+  hipEvent_t   copy_fence  = nullptr; // compute -> copy stream ordering
   bool         have_consts = false;
   kw_constants c{};
   int          cu_count    = 256;

@@ -139,6 +139,12 @@ void KSpaceFirstOrderSolver::runTimeSteps(size_t nSteps)
   for (size_t s = 0; s < nSteps && mParameters.getTimeIndex() < mParameters.getNt(); s++)
   {
     const size_t timeIndex = mParameters.getTimeIndex();
+    // fused pipeline: the velocity stage may hand the x-spectra of u straight to the density stage when no velocity /
+    // transducer source writes u in between this step
+    mVelocityChained = mFused && !(mParameters.getVelocityXSourceFlag() > timeIndex) &&
+                       !(mParameters.getVelocityYSourceFlag() > timeIndex) &&
+                       !(mParameters.getVelocityZSourceFlag() > timeIndex) &&
+                       !(mParameters.getTransducerSourceFlag() > timeIndex);
     computeVelocity<SD::k3D>();
     addVelocitySource();
     if (mParameters.getTransducerSourceFlag() > timeIndex) SolverHipKernels::addTransducerSource(mMatrixContainer);
@@ -185,7 +191,7 @@ template<SD sd> void KSpaceFirstOrderSolver::computeVelocity()
                               real(MI::kPmlZSgz).getDeviceData(), mKappaPadded,
                               c.getMatrix<ComplexMatrix>(MI::kDdxKShiftPosR).getDeviceData(),
                               c.getMatrix<ComplexMatrix>(MI::kDdyKShiftPos).getDeviceData(),
-                              c.getMatrix<ComplexMatrix>(MI::kDdzKShiftPos).getDeviceData()));
+                              c.getMatrix<ComplexMatrix>(MI::kDdzKShiftPos).getDeviceData(), mVelocityChained ? 1 : 0));
     return;
   }
   getTempHipFftX().computeR2CFftND(getP());
@@ -218,6 +224,7 @@ void KSpaceFirstOrderSolver::fusedDensity(bool nonlinear)
   mTermsFused              = absorbing && !pSourceActive;
   const bool storeDu       = absorbing && pSourceActive; // the stand-alone terms kernel will need the gradients
   const int  terms         = mTermsFused ? (nonlinear ? 2 : 1) : 0;
+  const int  flags         = (mVelocityChained ? KW_FUSED_U_IN_SCRATCH : 0) | (mTermsFused ? KW_FUSED_CHAIN_TERMS : 0);
   // aliasing of the temporaries as in :2184-2190 (nonlinear) / :2221-2225 (linear)
   float* t0 = getTemp1RealND().getDeviceData();
   float* t1 = getTemp2RealND().getDeviceData();
@@ -234,7 +241,7 @@ void KSpaceFirstOrderSolver::fusedDensity(bool nonlinear)
                            storeDu ? real(MI::kDuxdx).getDeviceData() : nullptr,
                            storeDu ? real(MI::kDuydy).getDeviceData() : nullptr,
                            storeDu ? real(MI::kDuzdz).getDeviceData() : nullptr, terms, c.realDeviceOrNull(MI::kBOnA),
-                           t0, t1, t2));
+                           t0, t1, t2, flags));
 }
 
 template<SD sd> void KSpaceFirstOrderSolver::computeDensityNonliner()
@@ -266,7 +273,7 @@ template<SD sd> void KSpaceFirstOrderSolver::computePressureNonlinear()
                                            nonlinearTerm.getDeviceData(), mNabla1Padded, mNabla2Padded,
                                            mMatrixContainer.realDeviceOrNull(MI::kC2),
                                            mMatrixContainer.realDeviceOrNull(MI::kAbsorbTau),
-                                           mMatrixContainer.realDeviceOrNull(MI::kAbsorbEta)));
+                                           mMatrixContainer.realDeviceOrNull(MI::kAbsorbEta), mTermsFused ? 1 : 0));
       return;
     }
     getTempHipFftX().computeR2CFftND(velocityGradientSum);
@@ -299,7 +306,7 @@ template<SD sd> void KSpaceFirstOrderSolver::computePressureLinear()
                                            densitySum.getDeviceData(), mNabla1Padded, mNabla2Padded,
                                            mMatrixContainer.realDeviceOrNull(MI::kC2),
                                            mMatrixContainer.realDeviceOrNull(MI::kAbsorbTau),
-                                           mMatrixContainer.realDeviceOrNull(MI::kAbsorbEta)));
+                                           mMatrixContainer.realDeviceOrNull(MI::kAbsorbEta), mTermsFused ? 1 : 0));
       return;
     }
     getTempHipFftX().computeR2CFftND(velocityGradientTerm);

@@ -86,6 +86,7 @@ class KSpaceFirstOrderSolver
   bool                  mPrepared = false;
   bool                  mFused    = false;   // fused pipeline active for this grid
   bool                  mTermsFused = false; // pressure terms of this step already produced by the density stage
+  bool                  mVelocityChained = false; // x-spectra of u handed over by the velocity stage this step
   float*                mKappaPadded = nullptr;
   float*                mNabla1Padded = nullptr;
   float*                mNabla2Padded = nullptr;

@@ -58,6 +58,10 @@ void BaseOutputStream::allocateMemory()
   kwCheck(kw_memcpy_h2d(ctx(), mDeviceBuffer, init.data(), mSize * sizeof(float)));
   if (mReduceOp == ReduceOperator::kNone)
   {
+    mDeviceRaw[0] = mDeviceBuffer;
+    void* d2 = nullptr;
+    kwCheck(kw_malloc(ctx(), mSize * sizeof(float), &d2));
+    mDeviceRaw[1] = static_cast<float*>(d2);
     for (int b = 0; b < 2; b++)
     {
       void* h = nullptr;
@@ -72,7 +76,9 @@ void BaseOutputStream::freeMemory()
 {
   if (!ctx()) return;
   if (mDeviceBuffer) kw_free(ctx(), mDeviceBuffer);
+  if (mDeviceRaw[1]) kw_free(ctx(), mDeviceRaw[1]);
   mDeviceBuffer = nullptr;
+  mDeviceRaw[0] = mDeviceRaw[1] = nullptr;
   for (int b = 0; b < 2; b++)
   {
     if (mPinned[b]) kw_host_free(ctx(), mPinned[b]);
@@ -102,8 +108,7 @@ void BaseOutputStream::postProcess()
 // ---- raw helpers ----------------------------------------------------------------------------------------------------
 static void rawSampleTail(kw_ctx* c, float* dev, float* pinned, void* event, size_t n)
 {
-  kwCheck(kw_memcpy_d2h_async(c, pinned, dev, n * sizeof(float)));
-  kwCheck(kw_event_record(c, event));
+  kwCheck(kw_memcpy_d2h_overlapped(c, pinned, dev, n * sizeof(float), event));
 }
 
 // ---- IndexOutputStream ----------------------------------------------------------------------------------------------
@@ -114,13 +119,10 @@ void IndexOutputStream::create()
 }
 void IndexOutputStream::sample()
 {
-  OutputStreamsHipKernels::sampleIndex(kernelOp(), mDeviceBuffer, mSourceMatrix.getDeviceData(),
-                                       mSensorMask.getDeviceData(), mSize);
-  if (mReduceOp == ReduceOperator::kNone)
-  {
-    const int b = mSampledSteps & 1;
-    rawSampleTail(ctx(), mDeviceBuffer, mPinned[b], mEvent[b], mSize);
-  }
+  const int b   = mSampledSteps & 1;
+  float*    dst = (mReduceOp == ReduceOperator::kNone) ? mDeviceRaw[b] : mDeviceBuffer;
+  OutputStreamsHipKernels::sampleIndex(kernelOp(), dst, mSourceMatrix.getDeviceData(), mSensorMask.getDeviceData(), mSize);
+  if (mReduceOp == ReduceOperator::kNone) rawSampleTail(ctx(), dst, mPinned[b], mEvent[b], mSize);
   mSampledSteps++;
 }
 void IndexOutputStream::flushRaw()
@@ -142,18 +144,16 @@ void CuboidOutputStream::sample()
 {
   const DimensionSizes dims = mSourceMatrix.getDimensionSizes();
   size_t offset = 0;
+  const int bb  = mSampledSteps & 1;
+  float*    dst = (mReduceOp == ReduceOperator::kNone) ? mDeviceRaw[bb] : mDeviceBuffer;
   for (size_t c = 0; c < mSensorMask.getDimensionSizes().ny; c++)
   {
     const size_t n = mSensorMask.getSizeOfCuboid(c);
-    OutputStreamsHipKernels::sampleCuboid(kernelOp(), mDeviceBuffer + offset, mSourceMatrix.getDeviceData(),
+    OutputStreamsHipKernels::sampleCuboid(kernelOp(), dst + offset, mSourceMatrix.getDeviceData(),
                                           mSensorMask.getTopLeftCorner(c), mSensorMask.getBottomRightCorner(c), dims, n);
     offset += n;
   }
-  if (mReduceOp == ReduceOperator::kNone)
-  {
-    const int b = mSampledSteps & 1;
-    rawSampleTail(ctx(), mDeviceBuffer, mPinned[b], mEvent[b], mSize);
-  }
+  if (mReduceOp == ReduceOperator::kNone) rawSampleTail(ctx(), dst, mPinned[bb], mEvent[bb], mSize);
   mSampledSteps++;
 }
 void CuboidOutputStream::flushRaw()

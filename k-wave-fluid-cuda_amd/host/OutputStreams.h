@@ -55,7 +55,8 @@ class BaseOutputStream
   const RealMatrix& mSourceMatrix;
   ReduceOperator    mReduceOp;
   size_t            mSize = 0;
-  float*            mDeviceBuffer = nullptr;       // aggregate or raw staging (device)
+  float*            mDeviceBuffer = nullptr;       // aggregate, or raw staging buffer 0 (device)
+  float*            mDeviceRaw[2] = {nullptr, nullptr}; // raw: double-buffered device staging (copy overlaps compute)
   float*            mPinned[2]    = {nullptr, nullptr}; // raw: pinned double buffer
   void*             mEvent[2]     = {nullptr, nullptr};
   size_t            mSampledSteps = 0, mFlushedSteps = 0;
