@@ -333,6 +333,20 @@ KW_API kw_status kw_sample_cuboid(kw_ctx* ctx, kw_reduce_op op, float* sampling_
 /* sampleAll<op> (.cuh:91-95, .cu:297-332) */
 KW_API kw_status kw_sample_all(kw_ctx* ctx, kw_reduce_op op, float* sampling_buffer, const float* source_data,
                                uint64_t n_samples);
+/* Compression streams (config 5).  The reference samples on the GPU (sampleIndex<kNone>) and correlates with the
+ * basis on the CPU one step later (OutputStreams/IndexOutputStream.cpp:373-470); here gather + correlation are one
+ * kernel and the accumulators c1/c2 ([n_samples][harmonics] complex) stay on the device:
+ *   c1[i,h] += bE[h*b_size+step_local] * x[i];  c2[i,h] += bE_1[h*b_size+step_local] * x[i];
+ *   mirror_first_half_frame: c2[i,h] += c1[i,h]  (first saved frame, :388,462-466).  c1 may equal c2 (--no_overlap). */
+KW_API kw_status kw_sample_index_compress(kw_ctx* ctx, float* c1, float* c2, const float* source_data,
+                                          const uint64_t* sensor_data, uint64_t n_samples, uint32_t harmonics,
+                                          const float* bE, const float* bE_1, uint32_t b_size, uint32_t step_local,
+                                          int mirror_first_half_frame);
+/* IndexOutputStream::postSample for kIAvgC (IndexOutputStream.cpp:299-342): iavg[i] += sum_h Re(P[i,h]*conj(U[i,h]))/2 */
+KW_API kw_status kw_intensity_avg_c_accumulate(kw_ctx* ctx, float* iavg, const float* frame_p, const float* frame_u,
+                                               uint64_t n_samples, uint32_t harmonics);
+/* buf[i] /= divisor — final division of I_avg_c by the frame count (IndexOutputStream.cpp:482-490) */
+KW_API kw_status kw_divide(kw_ctx* ctx, float* buf, float divisor, uint64_t n);
 /* postProcessingRms (.cuh:103-105, .cu:359-378) */
 KW_API kw_status kw_post_processing_rms(kw_ctx* ctx, float* sampling_buffer, float scaling_coeff, uint64_t n_samples);
 

@@ -61,6 +61,67 @@ __global__ __launch_bounds__(256) void k_post_rms(float* __restrict__ buf, float
     buf[i] = sqrtf(buf[i] * scale);
 }
 
+// Compression sampling (config 5): gather + correlation with the windowed complex-exponential basis in one kernel.
+// The reference gathers on the GPU and correlates on the CPU one step later (IndexOutputStream.cpp:373-470); the
+// arithmetic per (point, harmonic) is the same: c1 += bE*x; c2 += bE_1*x; first saved frame: c2 += c1.
+// c1 and c2 may alias (--no_overlap: mHostBuffer2 == mHostBuffer1, BaseOutputStream.cpp:246-249) -> no __restrict__.
+__global__ __launch_bounds__(256) void k_sample_index_compress(float2* c1, float2* c2, const float* __restrict__ src,
+                                                                const uint64_t* __restrict__ mask, uint64_t n,
+                                                                uint32_t harmonics, const float2* __restrict__ bE,
+                                                                const float2* __restrict__ bE_1, uint32_t b_size,
+                                                                uint32_t step_local, int mirror)
+{
+  for (uint64_t i = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n;
+       i += static_cast<uint64_t>(gridDim.x) * blockDim.x)
+  {
+    const float x = src[mask[i]];
+    for (uint32_t h = 0; h < harmonics; h++)
+    {
+      const uint64_t ph = harmonics * i + h;
+      const float2   b0 = bE[static_cast<size_t>(h) * b_size + step_local];
+      const float2   b1 = bE_1[static_cast<size_t>(h) * b_size + step_local];
+      float2 v1 = c1[ph];
+      v1.x += b0.x * x;
+      v1.y += b0.y * x;
+      c1[ph] = v1;
+      float2 v2 = c2[ph]; // after the store above: c2 may be c1
+      v2.x += b1.x * x;
+      v2.y += b1.y * x;
+      if (mirror)
+      {
+        v2.x += v1.x;
+        v2.y += v1.y;
+      }
+      c2[ph] = v2;
+    }
+  }
+}
+
+// I_avg_c accumulation from one emitted pair of coefficient frames (IndexOutputStream.cpp:315-339):
+// iavg[i] += sum_h real(P * conj(U)) / 2
+__global__ __launch_bounds__(256) void k_intensity_avg_c(float* __restrict__ iavg, const float2* __restrict__ P,
+                                                          const float2* __restrict__ U, uint64_t n, uint32_t harmonics)
+{
+  for (uint64_t i = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n;
+       i += static_cast<uint64_t>(gridDim.x) * blockDim.x)
+  {
+    float acc = iavg[i];
+    for (uint32_t h = 0; h < harmonics; h++)
+    {
+      const float2 p = P[harmonics * i + h], u = U[harmonics * i + h];
+      acc += (p.x * u.x + p.y * u.y) / 2.0f;
+    }
+    iavg[i] = acc;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_divide(float* __restrict__ buf, float divisor, uint64_t n)
+{
+  for (uint64_t i = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n;
+       i += static_cast<uint64_t>(gridDim.x) * blockDim.x)
+    buf[i] = buf[i] / divisor;
+}
+
 inline unsigned sampler_grid(const kw_ctx* ctx, uint64_t n)
 {
   // CU count x 8 blocks, shrunk to the work size (reference: SM count x 8, CudaParameters.cpp:218-231)
@@ -126,6 +187,41 @@ kw_status kw_sample_all(kw_ctx* ctx, kw_reduce_op op, float* buf, const float* s
   if (n == 0) return KW_OK;
   KW_REQUIRE(buf && src);
   DISPATCH_OP(op, k_sample_all, dim3(sampler_grid(ctx, n)), buf, src, n);
+  return KW_OK;
+}
+
+kw_status kw_sample_index_compress(kw_ctx* ctx, float* c1, float* c2, const float* src, const uint64_t* mask, uint64_t n,
+                                   uint32_t harmonics, const float* bE, const float* bE_1, uint32_t b_size,
+                                   uint32_t step_local, int mirror_first_half_frame)
+{
+  KW_CHECK_CTX(ctx);
+  KW_PROF(ctx, "sample_index_compress");
+  if (n == 0) return KW_OK;
+  KW_REQUIRE(c1 && c2 && src && mask && bE && bE_1);
+  KW_REQUIRE(harmonics >= 1 && b_size >= 3 && step_local < b_size);
+  LAUNCH(k_sample_index_compress, dim3(sampler_grid(ctx, n)), dim3(256), (float2*)c1, (float2*)c2, src, mask, n,
+         harmonics, (const float2*)bE, (const float2*)bE_1, b_size, step_local, mirror_first_half_frame);
+  return KW_OK;
+}
+
+kw_status kw_intensity_avg_c_accumulate(kw_ctx* ctx, float* iavg, const float* frame_p, const float* frame_u, uint64_t n,
+                                        uint32_t harmonics)
+{
+  KW_CHECK_CTX(ctx);
+  KW_PROF(ctx, "intensity_avg_c_accumulate");
+  if (n == 0) return KW_OK;
+  KW_REQUIRE(iavg && frame_p && frame_u && harmonics >= 1);
+  LAUNCH(k_intensity_avg_c, dim3(sampler_grid(ctx, n)), dim3(256), iavg, (const float2*)frame_p, (const float2*)frame_u,
+         n, harmonics);
+  return KW_OK;
+}
+
+kw_status kw_divide(kw_ctx* ctx, float* buf, float divisor, uint64_t n)
+{
+  KW_CHECK_CTX(ctx);
+  if (n == 0) return KW_OK;
+  KW_REQUIRE(buf != nullptr);
+  LAUNCH(k_divide, dim3(sampler_grid(ctx, n)), dim3(256), buf, divisor, n);
   return KW_OK;
 }
 

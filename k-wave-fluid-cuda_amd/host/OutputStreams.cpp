@@ -4,6 +4,7 @@
 #include <cstring>
 #include <limits>
 
+#include "CompressHelper.h"
 #include "HipError.h"
 #include "MatrixNames.h"
 #include "Parameters.h"
@@ -102,7 +103,7 @@ void BaseOutputStream::postProcess()
     const float scalingCoeff = 1.0f / (p.getNt() - p.getSamplingStartTimeIndex());
     OutputStreamsHipKernels::postProcessingRms(mDeviceBuffer, scalingCoeff, mSize);
   }
-  if (mReduceOp != ReduceOperator::kNone) copyAggregateFromDevice();
+  if (mReduceOp != ReduceOperator::kNone && mReduceOp != ReduceOperator::kC) copyAggregateFromDevice();
 }
 
 // ---- raw helpers ----------------------------------------------------------------------------------------------------
@@ -132,6 +133,86 @@ void IndexOutputStream::flushRaw()
   kwCheck(kw_event_synchronize(ctx(), mEvent[b])); // IndexOutputStream.cpp:354
   mDataset.insert(mDataset.end(), mPinned[b], mPinned[b] + mSize);
   mFlushedSteps++;
+}
+
+// ---- CompressedIndexOutputStream ------------------------------------------------------------------------------------
+CompressedIndexOutputStream::~CompressedIndexOutputStream()
+{
+  if (!ctx()) return;
+  float* bufs[] = { mC1, mC2, mBE, mBE_1 };
+  if (mC2 == mC1) bufs[1] = nullptr;
+  for (float* b : bufs)
+    if (b) kw_free(ctx(), b);
+}
+void CompressedIndexOutputStream::create()
+{
+  const CompressHelper& ch = CompressHelper::getInstance();
+  mSize = mSensorMask.size() * ch.getHarmonics() * 2; // floats per frame (BaseOutputStream: mSize for kC streams)
+  auto dalloc = [&](size_t floats) {
+    void* d = nullptr;
+    kwCheck(kw_malloc(ctx(), floats * sizeof(float), &d));
+    kwCheck(kw_memset(ctx(), d, 0, floats * sizeof(float)));
+    return static_cast<float*>(d);
+  };
+  mC1 = dalloc(mSize);
+  mC2 = Parameters::getInstance().getNoCompressionOverlapFlag() ? mC1 : dalloc(mSize); // BaseOutputStream.cpp:246-256
+  const size_t bFloats = ch.getHarmonics() * ch.getBSize() * 2;
+  mBE   = dalloc(bFloats);
+  mBE_1 = dalloc(bFloats);
+  kwCheck(kw_memcpy_h2d(ctx(), mBE, mShifted ? ch.getBEShifted() : ch.getBE(), bFloats * sizeof(float)));
+  kwCheck(kw_memcpy_h2d(ctx(), mBE_1, mShifted ? ch.getBE_1Shifted() : ch.getBE_1(), bFloats * sizeof(float)));
+  mFrameHost.resize(mSize);
+}
+void CompressedIndexOutputStream::sample()
+{ // IndexOutputStream.cpp:380-389 (flags) and :403-452 (correlation), at sampling time
+  const CompressHelper& ch = CompressHelper::getInstance();
+  const Parameters& params = Parameters::getInstance();
+  const size_t stepLocal   = mSampledSteps % (ch.getBSize() - 1);
+  mSavingFlag              = ((stepLocal + 1) % ch.getOSize() == 0);
+  const bool oddFrameFlag  = ((mCompressedTimeStep + 1) % 2 == 0);
+  const bool mirror = (mCompressedTimeStep == 0 && mSavingFlag && !params.getNoCompressionOverlapFlag());
+  kwCheck(kw_sample_index_compress(ctx(), mC1, mC2, mSourceMatrix.getDeviceData(),
+                                   (const uint64_t*)mSensorMask.getDeviceData(), mSensorMask.size(),
+                                   static_cast<uint32_t>(ch.getHarmonics()), mBE, mBE_1,
+                                   static_cast<uint32_t>(ch.getBSize()), static_cast<uint32_t>(stepLocal), mirror ? 1 : 0));
+  const size_t steps  = params.getNt() - params.getSamplingStartTimeIndex();
+  const bool lastStep = ((steps - mSampledSteps == 1) && steps <= ch.getOSize());
+  mCurrent = (mSavingFlag || lastStep) ? (oddFrameFlag ? mC1 : mC2) : nullptr; // :456-459
+  mSampledSteps++;
+}
+void CompressedIndexOutputStream::postSample2()
+{
+  if (mCurrent == nullptr) return;
+  kwCheck(kw_memcpy_d2h(ctx(), mFrameHost.data(), mCurrent, mSize * sizeof(float)));
+  mDataset.insert(mDataset.end(), mFrameHost.begin(), mFrameHost.end());
+  mFlushedSteps++;
+  mCompressedTimeStep++;
+  if (mSavingFlag) kwCheck(kw_memset(ctx(), mCurrent, 0, mSize * sizeof(float))); // BaseOutputStream.cpp:117-132
+  mCurrent = nullptr;
+}
+
+// ---- IntensityAvgCOutputStream --------------------------------------------------------------------------------------
+void IntensityAvgCOutputStream::create()
+{
+  mSize = mP.points();
+  allocateMemory(); // zero-initialised device buffer
+}
+void IntensityAvgCOutputStream::postSample()
+{
+  const float* bufferP = mP.getCurrentStoreBuffer();
+  const float* bufferU = mU.getCurrentStoreBuffer();
+  if (bufferP && bufferU)
+  {
+    kwCheck(kw_intensity_avg_c_accumulate(ctx(), mDeviceBuffer, bufferP, bufferU, mSize,
+                                          static_cast<uint32_t>(CompressHelper::getInstance().getHarmonics())));
+    mCompressedTimeStep++;
+  }
+}
+void IntensityAvgCOutputStream::postProcess()
+{ // IndexOutputStream.cpp:482-490
+  if (mCompressedTimeStep > 0) kwCheck(kw_divide(ctx(), mDeviceBuffer, static_cast<float>(mCompressedTimeStep), mSize));
+  mCompressedTimeStep = 0;
+  copyAggregateFromDevice();
 }
 
 // ---- CuboidOutputStream ---------------------------------------------------------------------------------------------
@@ -234,6 +315,30 @@ void OutputStreamContainer::init(MatrixContainer& mc)
         mContainer[a.z] = createOutputStream(mc, MI::kUzSgz, kUzName + a.suffix, a.op);
       }
   }
+  // ---- compression streams (OutputStreamContainer.cpp:92-96,157-168,272-316); index masks only ----
+  const bool wantIAvgC = params.getStoreIntensityAvgCFlag();
+  if (mc.has(MI::kSensorMaskIndex) && (params.getStorePressureCFlag() || params.getStoreVelocityNonStaggeredCFlag() || wantIAvgC))
+  {
+    IndexMatrix& mask = mc.getMatrix<IndexMatrix>(MI::kSensorMaskIndex);
+    if (params.getStorePressureCFlag() || wantIAvgC)
+      mContainer[OI::kPressureC] = new CompressedIndexOutputStream(kPName + "_c", mc.getMatrix<RealMatrix>(MI::kP), mask, false);
+    if (params.getStoreVelocityNonStaggeredCFlag() || wantIAvgC)
+    {
+      mContainer[OI::kVelocityXNonStaggeredC] = new CompressedIndexOutputStream(kUxNonStaggeredName + "_c", mc.getMatrix<RealMatrix>(MI::kUxShifted), mask, true);
+      mContainer[OI::kVelocityYNonStaggeredC] = new CompressedIndexOutputStream(kUyNonStaggeredName + "_c", mc.getMatrix<RealMatrix>(MI::kUyShifted), mask, true);
+      mContainer[OI::kVelocityZNonStaggeredC] = new CompressedIndexOutputStream(kUzNonStaggeredName + "_c", mc.getMatrix<RealMatrix>(MI::kUzShifted), mask, true);
+    }
+    if (wantIAvgC)
+    {
+      auto& pc = *static_cast<CompressedIndexOutputStream*>(mContainer[OI::kPressureC]);
+      const OI us[3] = {OI::kVelocityXNonStaggeredC, OI::kVelocityYNonStaggeredC, OI::kVelocityZNonStaggeredC};
+      const OI is[3] = {OI::kIntensityXAvgC, OI::kIntensityYAvgC, OI::kIntensityZAvgC};
+      const char* names[3] = {"Ix_avg_c", "Iy_avg_c", "Iz_avg_c"};
+      for (int a = 0; a < 3; a++)
+        mContainer[is[a]] = new IntensityAvgCOutputStream(names[a], mc.getMatrix<RealMatrix>(MI::kP), pc,
+                                                          *static_cast<CompressedIndexOutputStream*>(mContainer[us[a]]));
+    }
+  }
   if (params.getStoreVelocityMaxAllFlag())
   {
     mContainer[OI::kVelocityXMaxAll] = new WholeDomainOutputStream(kUxName + "_max_all", mc.getMatrix<RealMatrix>(MI::kUxSgx), RO::kMax);
@@ -255,6 +360,12 @@ void OutputStreamContainer::createStreams()
 void OutputStreamContainer::sampleStreams()
 {
   for (auto& it : mContainer) it.second->sample();
+  // the reference runs these two passes inside the next step's flushRawStreams (OutputStreamContainer.cpp:380-403);
+  // with device-resident accumulators they can follow the sampling immediately, in the same order
+  for (auto& it : mContainer)
+    if (auto* s = dynamic_cast<IntensityAvgCOutputStream*>(it.second)) s->postSample();
+  for (auto& it : mContainer)
+    if (auto* s = dynamic_cast<CompressedIndexOutputStream*>(it.second)) s->postSample2();
 }
 void OutputStreamContainer::flushRawStreams()
 {

@@ -75,6 +75,53 @@ class IndexOutputStream : public BaseOutputStream
   const IndexMatrix& mSensorMask;
 };
 
+/// kC streams: on-the-fly compression of the sampled series (IndexOutputStream.cpp:373-470), accumulators on the device.
+class CompressedIndexOutputStream : public BaseOutputStream
+{
+ public:
+  CompressedIndexOutputStream(const std::string& name, const RealMatrix& source, const IndexMatrix& sensorMask,
+                              bool shiftedBasis)
+    : BaseOutputStream(name, source, ReduceOperator::kC), mSensorMask(sensorMask), mShifted(shiftedBasis) {}
+  ~CompressedIndexOutputStream() override;
+  void create() override;
+  void sample() override;       // gather + correlate (flushRaw's kC branch, done at sampling time on the device)
+  void postSample2();           // emit the finished frame, zero its accumulator (BaseOutputStream.cpp:117-132)
+  /// device buffer holding the frame finished at this sampled step, or nullptr (getCurrentStoreBuffer)
+  const float* getCurrentStoreBuffer() const { return mCurrent; }
+  size_t frames() const { return mCompressedTimeStep; }
+  size_t points() const { return mSensorMask.size(); }
+
+ private:
+  const IndexMatrix& mSensorMask;
+  bool    mShifted;
+  float*  mC1 = nullptr;
+  float*  mC2 = nullptr;
+  float*  mBE = nullptr;
+  float*  mBE_1 = nullptr;
+  float*  mCurrent = nullptr;
+  bool    mSavingFlag = false;
+  size_t  mCompressedTimeStep = 0;
+  std::vector<float> mFrameHost;
+};
+
+/// kIAvgC streams: time-averaged intensity from the compression coefficients (IndexOutputStream.cpp:299-342,482-490)
+class IntensityAvgCOutputStream : public BaseOutputStream
+{
+ public:
+  IntensityAvgCOutputStream(const std::string& name, const RealMatrix& source, const CompressedIndexOutputStream& p,
+                            const CompressedIndexOutputStream& u)
+    : BaseOutputStream(name, source, ReduceOperator::kIAvgC), mP(p), mU(u) {}
+  void create() override;
+  void sample() override {}
+  void postSample();
+  void postProcess() override;
+
+ private:
+  const CompressedIndexOutputStream& mP;
+  const CompressedIndexOutputStream& mU;
+  size_t mCompressedTimeStep = 0;
+};
+
 class CuboidOutputStream : public BaseOutputStream
 {
  public:
@@ -106,7 +153,9 @@ class OutputStreamContainer
     kVelocityXRaw, kVelocityYRaw, kVelocityZRaw, kVelocityXNonStaggeredRaw, kVelocityYNonStaggeredRaw,
     kVelocityZNonStaggeredRaw, kVelocityXRms, kVelocityYRms, kVelocityZRms, kVelocityXMax, kVelocityYMax,
     kVelocityZMax, kVelocityXMin, kVelocityYMin, kVelocityZMin, kVelocityXMaxAll, kVelocityYMaxAll, kVelocityZMaxAll,
-    kVelocityXMinAll, kVelocityYMinAll, kVelocityZMinAll
+    kVelocityXMinAll, kVelocityYMinAll, kVelocityZMinAll,
+    kPressureC, kVelocityXNonStaggeredC, kVelocityYNonStaggeredC, kVelocityZNonStaggeredC,
+    kIntensityXAvgC, kIntensityYAvgC, kIntensityZAvgC
   };
   ~OutputStreamContainer() { freeStreams(); }
   void init(MatrixContainer& matrixContainer); // OutputStreamContainer.cpp:70-325

@@ -5,6 +5,7 @@
 #include <ios>
 #include <stdexcept>
 
+#include "CompressHelper.h"
 #include "HipError.h"
 #include "MatrixNames.h"
 
@@ -126,6 +127,11 @@ void Parameters::init(const InputProvider& in, const Options& options)
   {
     mBOnAScalarFlag = in.getDatasetDimensionSizes(kBonAName) == scalarSizes;
     if (mBOnAScalarFlag) in.readScalarValue(kBonAName, mBOnAScalar);
+  }
+  if (mOptions.storePressureC || mOptions.storeVelocityNonStaggeredC || mOptions.storeIntensityAvgC)
+  { // Parameters.cpp:462-551: the period (in time steps) must be known; the automatic period finder is a later row
+    if (!(mOptions.period > 0.0f)) throw std::ios_base::failure("Error: compression streams need --period (> 0)");
+    CompressHelper::getInstance().init(mOptions.period, mOptions.mos, mOptions.harmonics, true);
   }
   mRho0ScalarFlag = in.getDatasetDimensionSizes(kRho0Name) == scalarSizes;
   if (mRho0ScalarFlag)

@@ -168,7 +168,9 @@ int kwh_stream_info(kwh_solver* s, const char* name, uint64_t* size, uint64_t* s
   BaseOutputStream* st = s->solver->getOutputStreamContainer().find(name);
   if (!st) throw std::invalid_argument(std::string("no output stream named ") + name);
   *size  = st->size();
-  *steps = (st->reduceOp() == BaseOutputStream::ReduceOperator::kNone) ? st->sampledSteps() : 1;
+  const bool series = st->reduceOp() == BaseOutputStream::ReduceOperator::kNone ||
+                      st->reduceOp() == BaseOutputStream::ReduceOperator::kC;
+  *steps = series ? st->sampledSteps() : 1; // raw: sampled steps; compressed: emitted frames
   KWH_CATCH
 }
 

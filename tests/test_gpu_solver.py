@@ -176,3 +176,44 @@ def test_runs_stop_at_nt(syn):
     g.run(50)
     assert g.t == 5
     g.close()
+
+
+def test_config5_compression_and_intensity_streams(orc, syn):
+    """BASELINE config 5 at test size: p_c / u_non_staggered_c / I_avg_c streams (CompressHelper basis + correlation,
+    IndexOutputStream.cpp:299-470) against the oracle's compressor fed with the GPU's own raw series, and the
+    non-staggered velocity against the oracle's shifted-velocity restatement."""
+    n, nt = 32, 130
+    pr = syn.make_problem(n, heterogeneous=True, nonlinear=False, absorbing=False, source="p_source", source_mode=1,
+                          nt=nt, pml_size=4, sensor="random")
+    dt = float(pr["dt"].ravel()[0])
+    period, mos, harm = 1.0 / (1.0e6 * dt), 1, 2
+    g = make_gpu(pr, p_raw=1, u_non_staggered_raw=1, p_c=1, u_non_staggered_c=1, i_avg_c=1, period=period, mos=mos,
+                 harmonics=harm)
+    g.run(nt)
+    g.finish()
+    mask = pr["sensor_mask_index"].reshape(-1).astype(np.int64) - 1
+    # non-staggered velocity of the last step (KSpaceFirstOrderSolver.cpp:2714-2735)
+    for axis, nm in enumerate(("ux", "uy", "uz")):
+        shifted = orc.shifted_velocity(g.field(nm), pr["xyz"[axis] + "_shift_neg_r"], axis)
+        assert rel_l2(g.field(nm + "_shifted"), shifted) < 1e-5
+        assert np.array_equal(g.stream(nm + "_non_staggered")[-1], g.field(nm + "_shifted").reshape(-1)[mask])
+    # compression frames
+    raw = {"p_c": (g.stream("p"), False)}
+    for nm in ("ux", "uy", "uz"):
+        raw[nm + "_non_staggered_c"] = (g.stream(nm + "_non_staggered"), True)
+    frames = {}
+    for name, (series, shifted) in raw.items():
+        comp = orc.Compressor(mask.size, period, mos, harm, shifted)
+        for row in series:
+            comp.step(row)
+        got = g.stream(name).reshape(-1, mask.size, harm, 2)
+        ref = np.array(comp.frames)
+        assert got.shape == ref.shape and got.shape[0] == nt // int(period * mos)
+        assert rel_l2(got, ref) < 2e-6, name
+        frames[name] = got[..., 0] + 1j * got[..., 1]
+    # time-averaged intensity from the coefficients: mean over frames of sum_h Re(P conj(U)) / 2
+    for nm in ("x", "y", "z"):
+        P, U = frames["p_c"], frames[f"u{nm}_non_staggered_c"]
+        ref = (np.real(P * np.conj(U)).sum(axis=2) / 2.0).mean(axis=0)
+        assert rel_l2(g.stream(f"I{nm}_avg_c"), ref) < 1e-5
+    g.close()
