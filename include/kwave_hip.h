@@ -317,6 +317,8 @@ KW_API kw_status kw_fused_absorption_pressure(kw_ctx* ctx, float* p, const float
                                               const float* density_sum, const float* first,
                                               const float* nabla1_padded, const float* nabla2_padded, const float* c2,
                                               const float* absorb_tau, const float* absorb_eta, int terms_in_scratch);
+/* tuning probe: one pass of the pipeline over its scratch (0 y-pass, 1 line pass along z, 2 z-fused, 3 y-pass x3) */
+KW_API kw_status kw_fused_probe(kw_ctx* ctx, int which, const float* padded_reduced_operator);
 /* FFT part of scaleSource (KSpaceFirstOrderSolver.cpp:2346-2351; .cu:740-745), in place on scaled_source */
 KW_API kw_status kw_fused_scale_source(kw_ctx* ctx, float* scaled_source, const float* source_kappa_padded);
 

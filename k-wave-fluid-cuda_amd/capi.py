@@ -133,6 +133,7 @@ _SIG: Dict[str, list] = {
     "kw_fused_density": [_P, C.c_int] + [_P] * 14 + [_P] * 3 + [C.c_int, _P, _P, _P, _P, C.c_int],
     "kw_fused_absorption_pressure": [_P] + [_P] * 9 + [C.c_int],
     "kw_fused_scale_source": [_P, _P, _P],
+    "kw_fused_probe": [_P, C.c_int, _P],
     "kw_sample_index": [_P, C.c_int, _P, _P, _P, _U64],
     "kw_sample_cuboid": [_P, C.c_int, _P, _P, _P, _P, _P, _U64],
     "kw_sample_all": [_P, C.c_int, _P, _P, _U64],

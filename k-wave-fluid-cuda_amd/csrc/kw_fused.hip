@@ -66,9 +66,11 @@ template<int L, int DIR> __device__ __forceinline__ void step_a(float2 (&v)[Fac<
 struct RowAddr
 {
   uint32_t sh, mask, qstride, zmul;
+  uint32_t estride; // 1 for y-lines; ny for lines along z (probe / plain z transform)
   __device__ __forceinline__ size_t row(uint32_t z, uint32_t ky) const
   {
-    return static_cast<size_t>(ky >> sh) * qstride + (ky & mask) + static_cast<size_t>(z) * zmul;
+    return static_cast<size_t>(ky >> sh) * qstride + static_cast<size_t>(ky & mask) * estride +
+           static_cast<size_t>(z) * zmul;
   }
 };
 
@@ -721,8 +723,8 @@ kw_status launch_ypass(kw_ctx* ctx, int dir, int narr, float2* const* in, float2
   a.P   = f.P;
   uint32_t sh = 0;
   while ((1u << sh) < f.nyl) sh++;
-  const RowAddr natural{31u, 0xffffffffu, 0u, c.ny};
-  const RowAddr packed{sh, f.nyl - 1u, c.nz * f.nyl, f.nyl};
+  const RowAddr natural{31u, 0xffffffffu, 0u, c.ny, 1u};
+  const RowAddr packed{sh, f.nyl - 1u, c.nz * f.nyl, f.nyl, 1u};
   a.ain  = pack_in ? packed : natural;
   a.aout = pack_out ? packed : natural;
   const dim3 grid(f.P / NL, c.nz, narr);
@@ -1150,6 +1152,45 @@ kw_status kw_fused_scale_source(kw_ctx* ctx, float* scaled, const float* source_
   x.out[0] = scaled;
   KW_TRY(launch_xinv<EPI_STORE>(ctx, 1, x));
   return KW_OK;
+}
+
+// Pass-level probe for tuning (tools/probe_passes.py): launches ONE pass over the scratch arrays, no physics.
+//   0: y-pass forward on s[0] (in place)          1: the same line kernel along z (stride ny*P) on s[0]
+//   2: z-fused (forward, x sourceKappa-style multiply with op, inverse) on s[0]   3: y-pass on s[0..2] (3 arrays)
+// `op` = a padded reduced real array (e.g. kappa).  Single rank only.
+kw_status kw_fused_probe(kw_ctx* ctx, int which, const float* op)
+{
+  KW_FUSED_READY(ctx);
+  auto& f = ctx->fused;
+  KW_REQUIRE(f.nranks == 1);
+  const kw_constants& c = ctx->c;
+  if (which == 0) return launch_ypass(ctx, -1, 1, f.s, f.s, false, false);
+  if (which == 3) return launch_ypass(ctx, -1, 3, f.s, f.s, false, false);
+  if (which == 1)
+  {
+    KW_REQUIRE(c.nz == c.ny); // same line-length template
+    PassArgs a{};
+    a.in[0] = f.s[0]; a.out[0] = f.s[0];
+    a.tw  = f.tw[2];
+    a.nxc = c.nx_complex;
+    a.P   = f.P;
+    a.ain = a.aout = RowAddr{31u, 0xffffffffu, 0u, 1u, c.ny}; // element k of line (ky = blockIdx.y): row k*ny + ky
+    const dim3 grid(f.P / NL, c.ny, 1);
+#define M(LEN) LAUNCH((k_ypass<LEN, kFwd>), grid, dim3(Geo<LEN>::THREADS), a)
+    KW_LEN_SWITCH(c.nz, M)
+#undef M
+    return KW_OK;
+  }
+  if (which == 2)
+  {
+    KW_REQUIRE(op != nullptr);
+    ZArgs z{};
+    z.in[0] = f.s[0]; z.out[0] = f.s[0];
+    z.op[0] = op;
+    return launch_zfused<Z_SOURCE>(ctx, 1, z);
+  }
+  kw_set_error("kw_fused_probe: unknown probe %d", which);
+  return KW_ERR_INVALID;
 }
 
 } // extern "C"
