@@ -28,17 +28,20 @@ using namespace kwfft;
 
 namespace {
 
-constexpr int NL = 16; // lines per tile (16 complex = 128 B segments)
+constexpr int NLMAX = 16; // widest tile: 16 complex = 128-B segments (also the row-pitch granule)
+// lines per tile: 16 up to L = 256; 8 for L = 512, whose 32-point register DFT needs the VGPR budget of a 256-thread block
+constexpr int nl_of(int L) { return L >= 512 ? 8 : 16; }
 
 constexpr int cmax(int a, int b) { return a > b ? a : b; }
 
 template<int L> struct Geo
 {
   static constexpr int R1 = Fac<L>::R1, R2 = Fac<L>::R2;
+  static constexpr int NL      = nl_of(L);
   static constexpr int TPL     = cmax(R1, R2);
   static constexpr int THREADS = NL * TPL;
   // y/z passes: LDS[k1][n2][c]; +16 complex per k1 block keeps the step-B reads conflict-free
-  static constexpr int PADB    = 16;
+  static constexpr int PADB    = NL;
   static constexpr int SF      = R2 * NL + PADB; // stride per k1 (forward / standalone inverse)
   static constexpr int SI      = R1 * NL + PADB; // stride per q1 (inverse started from registers)
   static constexpr int LDSB    = cmax(R1 * SF, R2 * SI);
@@ -90,9 +93,9 @@ template<int L, int DIR> __global__ __launch_bounds__(Geo<L>::THREADS) void k_yp
   __shared__ float2 lds[G::LDSB];
   const float2* __restrict__ Sin = a.in[blockIdx.z];
   float2* __restrict__ Sout      = a.out[blockIdx.z];
-  const int      c     = threadIdx.x % NL;
-  const int      j     = threadIdx.x / NL;
-  const uint32_t kx    = blockIdx.x * NL + c;
+  const int      c     = threadIdx.x % G::NL;
+  const int      j     = threadIdx.x / G::NL;
+  const uint32_t kx    = blockIdx.x * G::NL + c;
   const bool     valid = kx < a.nxc;
   const uint32_t z     = blockIdx.y;
   if (j < R2)
@@ -103,14 +106,14 @@ template<int L, int DIR> __global__ __launch_bounds__(Geo<L>::THREADS) void k_yp
       v[n1] = valid ? Sin[a.ain.row(z, n1 * R2 + j) * a.P + kx] : make_float2(0.f, 0.f);
     step_a<L, DIR>(v, j, a.tw);
 #pragma unroll
-    for (int k1 = 0; k1 < R1; k1++) lds[k1 * G::SF + j * NL + c] = v[k1];
+    for (int k1 = 0; k1 < R1; k1++) lds[k1 * G::SF + j * G::NL + c] = v[k1];
   }
   __syncthreads();
   if (j < R1)
   {
     float2 w[R2];
 #pragma unroll
-    for (int n2 = 0; n2 < R2; n2++) w[n2] = lds[j * G::SF + n2 * NL + c];
+    for (int n2 = 0; n2 < R2; n2++) w[n2] = lds[j * G::SF + n2 * G::NL + c];
     Dft<R2, DIR>::run(w);
     if (valid)
     {
@@ -153,14 +156,14 @@ __device__ __forceinline__ void inverse_from_regs(float2 (&w)[Fac<L>::R2], float
     for (int q1 = 0; q1 < R2; q1++)
     {
       const float2 t = (q1 == 0) ? w[0] : apply_tw<kInv>(w[q1], tw[j * q1]);
-      lds[q1 * G::SI + j * NL + c] = t;
+      lds[q1 * G::SI + j * G::NL + c] = t;
     }
   }
   __syncthreads();
   if (j < R2)
   {
 #pragma unroll
-    for (int k1 = 0; k1 < R1; k1++) v[k1] = lds[j * G::SI + k1 * NL + c];
+    for (int k1 = 0; k1 < R1; k1++) v[k1] = lds[j * G::SI + k1 * G::NL + c];
     Dft<R1, kInv>::run(v);
   }
 }
@@ -170,9 +173,9 @@ template<int L, int MODE> __global__ __launch_bounds__(Geo<L>::THREADS) void k_z
   using G = Geo<L>;
   constexpr int R1 = G::R1, R2 = G::R2;
   __shared__ float2 lds[G::LDSB];
-  const int      c      = threadIdx.x % NL;
-  const int      j      = threadIdx.x / NL;
-  const uint32_t kx     = blockIdx.x * NL + c;
+  const int      c      = threadIdx.x % G::NL;
+  const int      j      = threadIdx.x / G::NL;
+  const uint32_t kx     = blockIdx.x * G::NL + c;
   const uint32_t ky     = blockIdx.y;
   const bool     valid  = kx < a.nxc;
   const size_t   zstr   = static_cast<size_t>(a.ny) * a.P;
@@ -188,14 +191,14 @@ template<int L, int MODE> __global__ __launch_bounds__(Geo<L>::THREADS) void k_z
       v[n1] = valid ? in[base + static_cast<size_t>(n1 * R2 + j) * zstr] : make_float2(0.f, 0.f);
     step_a<L, kFwd>(v, j, a.tw);
 #pragma unroll
-    for (int k1 = 0; k1 < R1; k1++) lds[k1 * G::SF + j * NL + c] = v[k1];
+    for (int k1 = 0; k1 < R1; k1++) lds[k1 * G::SF + j * G::NL + c] = v[k1];
   }
   __syncthreads();
   float2 X[R2];
   if (j < R1)
   {
 #pragma unroll
-    for (int n2 = 0; n2 < R2; n2++) X[n2] = lds[j * G::SF + n2 * NL + c];
+    for (int n2 = 0; n2 < R2; n2++) X[n2] = lds[j * G::SF + n2 * G::NL + c];
     Dft<R2, kFwd>::run(X);
   }
   __syncthreads(); // forward exchange buffer is free again
@@ -307,8 +310,8 @@ __device__ __forceinline__ void xfwd_tail(float2 (&v)[Fac<L>::R1], float2* lds, 
     for (int k2 = 0; k2 < R2; k2++) lds[c * G::ZP + f + R1 * k2] = w[k2];
   }
   __syncthreads();
-  const size_t tile_row0 = static_cast<size_t>(blockIdx.x) * NL * 2;
-  for (int e = threadIdx.x; e < NL * HALF; e += G::THREADS)
+  const size_t tile_row0 = static_cast<size_t>(blockIdx.x) * G::NL * 2;
+  for (int e = threadIdx.x; e < G::NL * HALF; e += G::THREADS)
   {
     const int    cc = e / HALF;
     const int    k  = e - cc * HALF;
@@ -331,7 +334,7 @@ template<int L> __global__ __launch_bounds__(Geo<L>::THREADS) void k_xfwd(XfwdAr
   const int    f   = threadIdx.x % G::TPL;
   const int    c   = threadIdx.x / G::TPL;
   const float* __restrict__ in = a.in[blockIdx.y];
-  const size_t row0 = (static_cast<size_t>(blockIdx.x) * NL + c) * 2;
+  const size_t row0 = (static_cast<size_t>(blockIdx.x) * G::NL + c) * 2;
   float2 v[R1];
   if (f < R2)
   {
@@ -375,8 +378,8 @@ __device__ __forceinline__ void xinv_lines(const float2* __restrict__ src, uint3
 {
   using G = Geo<L>;
   constexpr int R1 = G::R1, R2 = G::R2, HALF = L / 2 + 1;
-  const size_t tile_row0 = static_cast<size_t>(blockIdx.x) * NL * 2;
-  for (int e = threadIdx.x; e < NL * HALF; e += G::THREADS)
+  const size_t tile_row0 = static_cast<size_t>(blockIdx.x) * G::NL * 2;
+  for (int e = threadIdx.x; e < G::NL * HALF; e += G::THREADS)
   {
     const int    cc = e / HALF;
     const int    k  = e - cc * HALF;
@@ -429,8 +432,8 @@ template<int L, int EPI, bool CHAIN> __global__ __launch_bounds__(Geo<L>::THREAD
   constexpr int NA  = (EPI == EPI_DENSITY) ? 3 : (EPI == EPI_PSUM) ? 2 : 1;
   constexpr int RP  = L + 8;                       // real-tile row pitch (floats): conflict-free 4-B scatter
   constexpr int Q4  = L / 4;                       // float4 per row
-  constexpr int NQ  = (2 * NL * Q4) / G::THREADS;  // float4 per thread
-  static_assert((2 * NL * Q4) % G::THREADS == 0, "tile must divide evenly");
+  constexpr int NQ  = (2 * G::NL * Q4) / G::THREADS;  // float4 per thread
+  static_assert((2 * G::NL * Q4) % G::THREADS == 0, "tile must divide evenly");
   __shared__ float2 lds[G::LDSX];
   float* ldsr = reinterpret_cast<float*>(lds);
   const int f = threadIdx.x % G::TPL;
@@ -467,7 +470,7 @@ template<int L, int EPI, bool CHAIN> __global__ __launch_bounds__(Geo<L>::THREAD
   }
 
   const kw_constants& k = a.c;
-  const size_t tile_row0 = static_cast<size_t>(blockIdx.x) * NL * 2;
+  const size_t tile_row0 = static_cast<size_t>(blockIdx.x) * G::NL * 2;
 #pragma unroll
   for (int q = 0; q < NQ; q++)
   {
@@ -703,7 +706,7 @@ kw_status launch_xfwd(kw_ctx* ctx, int narr, const float* const* in, float2* con
   a.tw = ctx->fused.tw[0];
   a.nx = c.nx;
   a.P  = ctx->fused.P;
-  const dim3 grid(c.ny * c.nz / (2 * NL), narr, 1);
+  const dim3 grid(c.ny * c.nz / (2 * nl_of(c.nx)), narr, 1);
 #define M(LEN) LAUNCH((k_xfwd<LEN>), grid, dim3(Geo<LEN>::THREADS), a)
   KW_LEN_SWITCH(c.nx, M)
 #undef M
@@ -727,7 +730,7 @@ kw_status launch_ypass(kw_ctx* ctx, int dir, int narr, float2* const* in, float2
   const RowAddr packed{sh, f.nyl - 1u, c.nz * f.nyl, f.nyl, 1u};
   a.ain  = pack_in ? packed : natural;
   a.aout = pack_out ? packed : natural;
-  const dim3 grid(f.P / NL, c.nz, narr);
+  const dim3 grid(f.P / nl_of(c.ny), c.nz, narr);
 #define M(LEN)                                                                                                         \
   if (dir < 0) LAUNCH((k_ypass<LEN, kFwd>), grid, dim3(Geo<LEN>::THREADS), a);                                         \
   else LAUNCH((k_ypass<LEN, kInv>), grid, dim3(Geo<LEN>::THREADS), a)
@@ -748,7 +751,7 @@ template<int MODE> kw_status launch_zfused(kw_ctx* ctx, int narr, ZArgs a)
   a.ny      = f.nyl;
   a.nz      = f.nz_global;
   a.ky0     = f.rank * f.nyl;
-  const dim3 grid(f.P / NL, f.nyl, narr);
+  const dim3 grid(f.P / nl_of(f.nz_global), f.nyl, narr);
 #define M(LEN) LAUNCH((k_zfused<LEN, MODE>), grid, dim3(Geo<LEN>::THREADS), a)
   KW_LEN_SWITCH(f.nz_global, M)
 #undef M
@@ -761,7 +764,7 @@ template<int EPI, bool CHAIN = false> kw_status launch_xinv(kw_ctx* ctx, int nco
   a.tw = ctx->fused.tw[0];
   a.c  = c;
   a.P  = ctx->fused.P;
-  const dim3 grid(c.ny * c.nz / (2 * NL), ncomp, 1);
+  const dim3 grid(c.ny * c.nz / (2 * nl_of(c.nx)), ncomp, 1);
 #define M(LEN) LAUNCH((k_xinv<LEN, EPI, CHAIN>), grid, dim3(Geo<LEN>::THREADS), a)
   KW_LEN_SWITCH(c.nx, M)
 #undef M
@@ -856,7 +859,7 @@ kw_status create_impl(kw_ctx* ctx, void* const s[3], void* const t[3])
   const kw_constants& c = ctx->c;
   f.nz_global = (f.nranks > 1) ? slab.nz_global : c.nz;
   f.nyl       = c.ny / f.nranks;
-  f.P         = (c.nx_complex + NL - 1) / NL * NL;
+  f.P         = (c.nx_complex + NLMAX - 1) / NLMAX * NLMAX;
   KW_TRY(alloc_scratch(ctx, s, t));
   const uint32_t lens[3] = { c.nx, c.ny, f.nz_global };
   for (int i = 0; i < 3; i++)
@@ -904,7 +907,7 @@ kw_status kw_fused_supported(kw_ctx* ctx, int* out)
   const kw_constants& c = ctx->c;
   const auto& f         = ctx->fused;
   const uint32_t nzg    = (f.nranks > 1) ? f.nz_global : c.nz;
-  bool ok = supported_len(c.nx) && supported_len(c.ny) && supported_len(nzg) && ((c.ny * c.nz) % (2 * NL) == 0);
+  bool ok = supported_len(c.nx) && supported_len(c.ny) && supported_len(nzg) && ((c.ny * c.nz) % (2 * NLMAX) == 0);
   if (f.nranks > 1) ok = ok && (nzg == c.nz * f.nranks) && (c.ny % f.nranks == 0);
   *out = ok ? 1 : 0;
   return KW_OK;
@@ -943,7 +946,7 @@ kw_status kw_fused_scratch_bytes(kw_ctx* ctx, size_t* out)
 {
   KW_CHECK_CONSTS(ctx);
   KW_REQUIRE(out != nullptr);
-  const uint32_t P = (ctx->c.nx_complex + NL - 1) / NL * NL;
+  const uint32_t P = (ctx->c.nx_complex + NLMAX - 1) / NLMAX * NLMAX;
   *out             = static_cast<size_t>(P) * ctx->c.ny * ctx->c.nz * sizeof(float2);
   return KW_OK;
 }
@@ -1175,7 +1178,7 @@ kw_status kw_fused_probe(kw_ctx* ctx, int which, const float* op)
     a.nxc = c.nx_complex;
     a.P   = f.P;
     a.ain = a.aout = RowAddr{31u, 0xffffffffu, 0u, 1u, c.ny}; // element k of line (ky = blockIdx.y): row k*ny + ky
-    const dim3 grid(f.P / NL, c.ny, 1);
+    const dim3 grid(f.P / nl_of(c.nz), c.ny, 1);
 #define M(LEN) LAUNCH((k_ypass<LEN, kFwd>), grid, dim3(Geo<LEN>::THREADS), a)
     KW_LEN_SWITCH(c.nz, M)
 #undef M

@@ -110,6 +110,14 @@ def test_fused_mixed_power_of_two_dims(orc, syn):
     assert max(errs.values()) < TOL, errs
 
 
+@pytest.mark.parametrize("dims", [(512, 16, 32), (16, 512, 16), (16, 32, 512)])
+def test_fused_line_length_512(orc, syn, dims):
+    """512-point lines use the 8-lines-per-tile geometry (32-point register DFTs) in each of the three pass types."""
+    pr = syn.make_problem(*dims, heterogeneous=True, nonlinear=True, absorbing=True, source="p0", pml_size=4)
+    errs = compare(orc, pr, 20, fused_kernels=True)
+    assert max(errs.values()) < TOL, (dims, errs)
+
+
 def test_transducer_source(orc, syn):
     pr = syn.make_problem(24, heterogeneous=True, nonlinear=True, absorbing=True, source="transducer", nt=40,
                           pml_size=4)
