@@ -271,6 +271,13 @@ KW_API kw_status kw_compute_velocity_shift(kw_ctx* ctx, int axis, float* spectru
 typedef void (*kw_exchange_fn)(void* user, void* send, void* recv, size_t bytes_per_peer);
 KW_API kw_status kw_fused_set_slab(kw_ctx* ctx, uint32_t nranks, uint32_t rank, uint32_t nz_global,
                                    kw_exchange_fn exchange, void* user);   /* before kw_fused_create */
+/* Optional split-phase form of the same all-to-all, so that transposes overlap with compute: start(user, send, recv,
+ * bytes_per_peer, slot) begins the exchange (ordered after the work enqueued so far on the context's stream) and
+ * returns; wait(user, slot) makes the context's stream wait for that exchange (slot in 0..2, one exchange in flight per
+ * slot).  E.g. all_to_all_single(async_op=True) / work.wait().  Without it the blocking callback is used. */
+typedef void (*kw_exchange_start_fn)(void* user, void* send, void* recv, size_t bytes_per_peer, int slot);
+typedef void (*kw_exchange_wait_fn)(void* user, int slot);
+KW_API kw_status kw_fused_set_slab_async(kw_ctx* ctx, kw_exchange_start_fn start, kw_exchange_wait_fn wait);
 KW_API kw_status kw_fused_scratch_bytes(kw_ctx* ctx, size_t* out_bytes_per_array);
 /* like kw_fused_create but with caller-owned scratch (each of kw_fused_scratch_bytes bytes): s[3], and t[3] when
  * nranks > 1 — lets the caller register the buffers with its communication library */

@@ -50,6 +50,8 @@ typedef struct kwh_options
   uint64_t slab_ranks, slab_rank, nz_global;
   void*    exchange_fn;
   void*    exchange_user;
+  void*    exchange_start_fn; /* optional kw_exchange_start_fn / kw_exchange_wait_fn pair (both or neither) */
+  void*    exchange_wait_fn;
   void*    scratch[6]; /* optional caller-owned pipeline scratch (kw_fused_create_with_scratch), else all NULL */
 } kwh_options;
 

@@ -783,13 +783,46 @@ template<int EPI, bool CHAIN = false> kw_status launch_xinv(kw_ctx* ctx, int nco
     if (st_ != KW_OK) return st_;                                                                                      \
   } while (0)
 
-// all-to-all of one scratch array between the ranks (no-op with one rank): chunk q of `send` -> rank q
-kw_status exchange(kw_ctx* ctx, float2* send, float2* recv)
+// split-phase exchange of scratch array `slot`: start is ordered after the work enqueued so far; wait orders later
+// work after its completion.  Without asynchronous callbacks, start is the blocking exchange and wait a no-op.
+kw_status xstart(kw_ctx* ctx, int slot, float2* send, float2* recv)
 {
   const auto& f = ctx->fused;
-  if (f.nranks == 1) return KW_OK;
   const size_t bytes_per_peer = static_cast<size_t>(ctx->c.nz) * f.nyl * f.P * sizeof(float2);
-  f.exchange(f.exchange_user, send, recv, bytes_per_peer);
+  if (f.exchange_start != nullptr) f.exchange_start(f.exchange_user, send, recv, bytes_per_peer, slot);
+  else f.exchange(f.exchange_user, send, recv, bytes_per_peer);
+  return KW_OK;
+}
+kw_status xwait(kw_ctx* ctx, int slot)
+{
+  const auto& f = ctx->fused;
+  if (f.exchange_start != nullptr) f.exchange_wait(f.exchange_user, slot);
+  return KW_OK;
+}
+
+// Slab mode, narr independent arrays (velocity gradient, absorption, source scaling): software-pipelined per array so
+// that the all-to-all of one array is in flight while the y / z passes of the others run.
+template<int MODE> kw_status slab_chain(kw_ctx* ctx, int narr, const float* const* in, ZArgs z)
+{
+  auto& f = ctx->fused;
+  for (int a = 0; a < narr; a++)
+  {
+    if (in != nullptr) KW_TRY(launch_xfwd(ctx, 1, in + a, f.s + a));
+    KW_TRY(launch_ypass(ctx, -1, 1, f.s + a, f.t + a, false, true));
+    KW_TRY(xstart(ctx, a, f.t[a], f.s[a]));
+  }
+  for (int a = 0; a < narr; a++)
+  {
+    KW_TRY(xwait(ctx, a));
+    z.arr0 = a;
+    KW_TRY(launch_zfused<MODE>(ctx, 1, z));
+    KW_TRY(xstart(ctx, a, f.s[a], f.t[a]));
+  }
+  for (int a = 0; a < narr; a++)
+  {
+    KW_TRY(xwait(ctx, a));
+    KW_TRY(launch_ypass(ctx, +1, 1, f.t + a, f.s + a, true, false));
+  }
   return KW_OK;
 }
 
@@ -801,7 +834,8 @@ kw_status forward_xy(kw_ctx* ctx, int narr, const float* const* in, int s0 = 0)
   if (in != nullptr) KW_TRY(launch_xfwd(ctx, narr, in, f.s + s0)); // nullptr: x-spectra were chained into S[] already
   if (f.nranks == 1) return launch_ypass(ctx, -1, narr, f.s + s0, f.s + s0, false, false);
   KW_TRY(launch_ypass(ctx, -1, narr, f.s + s0, f.t + s0, false, true));
-  for (int i = 0; i < narr; i++) KW_TRY(exchange(ctx, f.t[s0 + i], f.s[s0 + i]));
+  for (int i = 0; i < narr; i++) KW_TRY(xstart(ctx, s0 + i, f.t[s0 + i], f.s[s0 + i]));
+  for (int i = 0; i < narr; i++) KW_TRY(xwait(ctx, s0 + i));
   return KW_OK;
 }
 
@@ -810,7 +844,8 @@ kw_status inverse_y(kw_ctx* ctx, int narr, int s0 = 0)
 {
   auto& f = ctx->fused;
   if (f.nranks == 1) return launch_ypass(ctx, +1, narr, f.s + s0, f.s + s0, false, false);
-  for (int i = 0; i < narr; i++) KW_TRY(exchange(ctx, f.s[s0 + i], f.t[s0 + i]));
+  for (int i = 0; i < narr; i++) KW_TRY(xstart(ctx, s0 + i, f.s[s0 + i], f.t[s0 + i]));
+  for (int i = 0; i < narr; i++) KW_TRY(xwait(ctx, s0 + i));
   return launch_ypass(ctx, +1, narr, f.t + s0, f.s + s0, true, false);
 }
 
@@ -855,6 +890,7 @@ kw_status create_impl(kw_ctx* ctx, void* const s[3], void* const t[3])
   kw_fused_destroy(ctx);
   auto& f = ctx->fused;
   f.nranks = slab.nranks; f.rank = slab.rank; f.exchange = slab.exchange; f.exchange_user = slab.exchange_user;
+  f.exchange_start = slab.exchange_start; f.exchange_wait = slab.exchange_wait;
   KW_HIP(hipSetDevice(ctx->device));
   const kw_constants& c = ctx->c;
   f.nz_global = (f.nranks > 1) ? slab.nz_global : c.nz;
@@ -897,6 +933,16 @@ kw_status kw_fused_set_slab(kw_ctx* ctx, uint32_t nranks, uint32_t rank, uint32_
   ctx->fused.nz_global     = nz_global;
   ctx->fused.exchange      = fn;
   ctx->fused.exchange_user = user;
+  return KW_OK;
+}
+
+kw_status kw_fused_set_slab_async(kw_ctx* ctx, kw_exchange_start_fn start, kw_exchange_wait_fn wait)
+{
+  KW_CHECK_CTX(ctx);
+  KW_REQUIRE((start == nullptr) == (wait == nullptr));
+  if (ctx->fused.ready) { kw_set_error("kw_fused_set_slab_async: must be called before kw_fused_create"); return KW_ERR_STATE; }
+  ctx->fused.exchange_start = start;
+  ctx->fused.exchange_wait  = wait;
   return KW_OK;
 }
 
@@ -994,6 +1040,20 @@ kw_status kw_fused_velocity(kw_ctx* ctx, const float* p, float* ux, float* uy, f
   const float* dt[3] = { dtx, dty, dtz };
   const float* pml[3] = { pmlx, pmly, pmlz };
   for (int i = 0; i < 3; i++) { x.in[i] = S[i]; x.out[i] = u[i]; x.m0[i] = dt[i]; x.m1[i] = pml[i]; x.fout[i] = S[i]; }
+  if (ctx->fused.nranks > 1)
+  { // slab mode: the three transposes back are pipelined against the y-inverse / x-inverse of the previous component
+    auto& f = ctx->fused;
+    for (int i = 0; i < 3; i++) KW_TRY(xstart(ctx, i, f.s[i], f.t[i]));
+    for (int i = 0; i < 3; i++)
+    {
+      KW_TRY(xwait(ctx, i));
+      KW_TRY(launch_ypass(ctx, +1, 1, f.t + i, f.s + i, true, false));
+      x.comp0 = i;
+      if (chain_u_spectra) KW_TRY((launch_xinv<EPI_VELOCITY, true>(ctx, 1, x)));
+      else KW_TRY(launch_xinv<EPI_VELOCITY>(ctx, 1, x));
+    }
+    return KW_OK;
+  }
   if (ctx->fused.per_array && !chain_u_spectra)
   { // A/B knob: whole chain per array
     for (int i = 0; i < 3; i++)
@@ -1062,7 +1122,11 @@ kw_status kw_fused_density(kw_ctx* ctx, int nonlinear, const float* ux, const fl
   for (int i = 0; i < 3; i++) { z.in[i] = S[i]; z.out[i] = S[i]; }
   z.op[0] = kappa_padded;
   z.dd[0] = (const float2*)ddx; z.dd[1] = (const float2*)ddy; z.dd[2] = (const float2*)ddz;
-  if (ctx->fused.per_array)
+  if (ctx->fused.nranks > 1)
+  {
+    KW_TRY(slab_chain<Z_VGRAD>(ctx, 3, u_in_scratch ? nullptr : in3, z));
+  }
+  else if (ctx->fused.per_array)
   {
     for (int i = 0; i < 3; i++)
     {
@@ -1111,7 +1175,11 @@ kw_status kw_fused_absorption_pressure(kw_ctx* ctx, float* p, const float* vel_g
   for (int i = 0; i < 2; i++) { z.in[i] = S[i]; z.out[i] = S[i]; }
   z.op[0] = nabla1_padded;
   z.op[1] = nabla2_padded;
-  if (ctx->fused.per_array)
+  if (ctx->fused.nranks > 1)
+  {
+    KW_TRY(slab_chain<Z_ABSORB>(ctx, 2, terms_in_scratch ? nullptr : in2, z));
+  }
+  else if (ctx->fused.per_array)
   {
     for (int i = 0; i < 2; i++)
     {

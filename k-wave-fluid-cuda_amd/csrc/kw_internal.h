@@ -50,6 +50,8 @@ struct kw_ctx
     bool     owns_scratch = true;
     kw_exchange_fn exchange = nullptr;             // all-to-all over the ranks (RCCL via the caller)
     void*          exchange_user = nullptr;
+    kw_exchange_start_fn exchange_start = nullptr; // optional split-phase pair (overlap with compute)
+    kw_exchange_wait_fn  exchange_wait  = nullptr;
   } fused;
   // profiling (kw_profile_enable)
   struct prof_rec { const char* name; hipEvent_t e0, e1; };

@@ -94,6 +94,8 @@ class SlabExchange:
     scratch, so the collective runs in place on them.  gloo: device -> pinned host, all-to-all on CPU, host -> device."""
 
     CB = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t)
+    CB_START = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int)
+    CB_WAIT = C.CFUNCTYPE(None, C.c_void_p, C.c_int)
 
     def __init__(self, nranks: int, device_index: int = 0):
         import torch
@@ -108,6 +110,10 @@ class SlabExchange:
         self._host: Dict[int, tuple] = {}
         self.callback = self.CB(self._exchange)
         self.calls = 0
+        # split-phase form (RCCL only): the transpose of one array is in flight while other arrays compute
+        self.works: Dict[int, object] = {}
+        self.start_callback = self.CB_START(self._start) if self.backend == "nccl" else None
+        self.wait_callback = self.CB_WAIT(self._wait) if self.backend == "nccl" else None
 
     def alloc_scratch(self, nbytes: int):
         """Six device buffers (s[3], t[3]) as torch tensors; returns their addresses (for HostSolver(scratch=...))."""
@@ -126,6 +132,21 @@ class SlabExchange:
         self.stream = stream
         if stream is not None:
             capi.check(capi.load().kw_set_stream(ctx, C.c_void_p(stream.cuda_stream)))
+
+    def _start(self, user, send, recv, bytes_per_peer, slot):
+        """all_to_all_single(async_op=True): the RCCL stream waits for the work enqueued so far on the solver's stream
+        and the call returns; later launches on the solver's stream overlap with the collective."""
+        self.calls += 1
+        torch, dist = self.torch, self.dist
+        n = bytes_per_peer * self.nranks
+        src, dst = self.tensors[send], self.tensors[recv]
+        with torch.cuda.stream(self.stream):
+            self.works[slot] = dist.all_to_all_single(dst[: n // 4], src[: n // 4], async_op=True)
+
+    def _wait(self, user, slot):
+        """work.wait(): the solver's stream waits for the collective (the host does not block)."""
+        with self.torch.cuda.stream(self.stream):
+            self.works.pop(slot).wait()
 
     def _exchange(self, user, send, recv, bytes_per_peer):
         self.calls += 1
@@ -165,7 +186,9 @@ class DistSolver:
             pitch = (nx // 2 + 1 + 15) // 16 * 16
             scratch = self.exchange.alloc_scratch(pitch * ny * nzl * 8)
         self.sim = HostSolver(pr_local, slab_ranks=nranks, slab_rank=rank, nz_global=nz_global,
-                              exchange_fn=self.exchange.callback, scratch=scratch, device_idx=device_index, **opts)
+                              exchange_fn=self.exchange.callback, exchange_start_fn=self.exchange.start_callback,
+                              exchange_wait_fn=self.exchange.wait_callback, scratch=scratch, device_idx=device_index,
+                              **opts)
         stream = torch.cuda.Stream(device=device_index) if self.exchange.backend == "nccl" else None
         self.exchange.bind(self.sim.ctx, stream)
 

@@ -45,6 +45,8 @@ void KSpaceFirstOrderSolver::initializeFftPlans()
   if (mParameters.isSlabDecomposed())
     kwCheck(kw_fused_set_slab(ctx, static_cast<uint32_t>(opt.slabRanks), static_cast<uint32_t>(opt.slabRank),
                               static_cast<uint32_t>(opt.nzGlobal), opt.exchangeFn, opt.exchangeUser));
+  if (mParameters.isSlabDecomposed() && opt.exchangeStartFn != nullptr)
+    kwCheck(kw_fused_set_slab_async(ctx, opt.exchangeStartFn, opt.exchangeWaitFn));
   if (opt.fusedKernels || mParameters.isSlabDecomposed()) kwCheck(kw_fused_supported(ctx, &fusedOk));
   mFused = (fusedOk != 0);
   if (mParameters.isSlabDecomposed() && !mFused)

@@ -62,6 +62,8 @@ class Parameters
     size_t slabRanks = 1, slabRank = 0, nzGlobal = 0;
     kw_exchange_fn exchangeFn = nullptr; // all-to-all provided by the driver (RCCL through torch.distributed)
     void*  exchangeUser = nullptr;
+    kw_exchange_start_fn exchangeStartFn = nullptr; // optional split-phase pair: transposes overlap with compute
+    kw_exchange_wait_fn  exchangeWaitFn  = nullptr;
     void*  scratch[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}; // optional caller-owned pipeline scratch
   };
 

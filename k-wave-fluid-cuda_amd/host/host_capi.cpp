@@ -61,6 +61,8 @@ int kwh_create(const kwh_dataset* datasets, size_t n, const kwh_options* o, kwh_
   opt.nzGlobal  = o->nz_global;
   opt.exchangeFn   = reinterpret_cast<kw_exchange_fn>(o->exchange_fn);
   opt.exchangeUser = o->exchange_user;
+  opt.exchangeStartFn = reinterpret_cast<kw_exchange_start_fn>(o->exchange_start_fn);
+  opt.exchangeWaitFn  = reinterpret_cast<kw_exchange_wait_fn>(o->exchange_wait_fn);
   for (int i = 0; i < 6; i++) opt.scratch[i] = o->scratch[i];
 
   Parameters& params = Parameters::getInstance();

@@ -38,7 +38,8 @@ class Options(C.Structure):
                                          "u_non_staggered_raw", "p_c", "u_non_staggered_c", "i_avg_c", "no_overlap")] + \
                [("period", C.c_float), ("mos", C.c_uint64), ("harmonics", C.c_uint64),
                 ("slab_ranks", C.c_uint64), ("slab_rank", C.c_uint64), ("nz_global", C.c_uint64),
-                ("exchange_fn", C.c_void_p), ("exchange_user", C.c_void_p), ("scratch", C.c_void_p * 6)]
+                ("exchange_fn", C.c_void_p), ("exchange_user", C.c_void_p),
+                ("exchange_start_fn", C.c_void_p), ("exchange_wait_fn", C.c_void_p), ("scratch", C.c_void_p * 6)]
 
 
 _hlib: Optional[C.CDLL] = None
@@ -122,6 +123,11 @@ class HostSolver:
         if fn is not None:
             self._keep.append(fn)  # keep the ctypes callback alive
             o.exchange_fn = C.cast(fn, C.c_void_p)
+        for key in ("exchange_start_fn", "exchange_wait_fn"):
+            fn = opts.pop(key, None)
+            if fn is not None:
+                self._keep.append(fn)
+                setattr(o, key, C.cast(fn, C.c_void_p))
         scratch = opts.pop("scratch", None)
         if scratch is not None:
             for i, ptr in enumerate(scratch):
