@@ -71,9 +71,36 @@ def build_host(force: bool = False) -> str:
     return HOST_LIB
 
 
+HOST_H5_LIB = os.path.join(LIB_DIR, "libkwave_host_h5.so")
+CLI_BIN = os.path.join(LIB_DIR, "kspaceFirstOrder-HIP")
+HDF5_ROOT = os.environ.get("HDF5_ROOT", "/opt/conda")
+
+
+def build_host_h5(force: bool = False) -> str:
+    """Optional HDF5 component: the host layer + Hdf5File/Hdf5Input/output writer, and the command-line program."""
+    if not os.path.exists(os.path.join(HDF5_ROOT, "include", "hdf5.h")):
+        return ""
+    srcs = sorted(glob.glob(os.path.join(HOST, "*.cpp"))) + [os.path.join(HOST, "h5", "Hdf5File.cpp"),
+                                                               os.path.join(HOST, "h5", "h5_capi.cpp")]
+    deps = srcs + glob.glob(os.path.join(HOST, "*.h")) + glob.glob(os.path.join(HOST, "h5", "*"))
+    common = ["-O2", "-std=c++17", "-fPIC", "-fopenmp", "-I" + INCLUDE, "-I" + HOST, "-I" + os.path.join(HDF5_ROOT, "include")]
+    # HDF5 by full path and the system library directory ahead of conda's in the run path: /opt/conda/lib also holds an
+    # older libstdc++ that must not shadow the system one (rocFFT needs GLIBCXX_3.4.30)
+    h5lib = os.path.join(HDF5_ROOT, "lib")
+    link = ["-L" + LIB_DIR, "-lkwave_hip", os.path.join(h5lib, "libhdf5_hl.so"), os.path.join(h5lib, "libhdf5.so"),
+            "-Wl,-rpath,$ORIGIN", "-Wl,-rpath,/usr/lib/x86_64-linux-gnu", "-Wl,-rpath," + h5lib, "-ldl"]
+    if force or _newer(HOST_H5_LIB, deps) or _newer(HOST_H5_LIB, [HIP_LIB]):
+        _run(["g++"] + common + ["-shared", "-o", HOST_H5_LIB] + srcs + link)
+    if force or _newer(CLI_BIN, deps + [HOST_H5_LIB]):
+        _run(["g++"] + common + ["-o", CLI_BIN, os.path.join(HOST, "h5", "main.cpp")] +
+             ["-L" + LIB_DIR, "-lkwave_host_h5"] + link)
+    return HOST_H5_LIB
+
+
 def build_all(force: bool = False, verbose: bool = False):
     build_hip(force, verbose)
     build_host(force)
+    build_host_h5(force)
 
 
 if __name__ == "__main__":

@@ -1,0 +1,130 @@
+"""k-Wave HDF5 files (file format 1.1) on either side of the hot path: optional component backed by
+lib/libkwave_host_h5.so (C++ `Hdf5File`, k-wave-fluid-cuda_amd/host/h5/).
+
+  write_input_file(problem_dict, path)   synthetic problem -> input file the reference could read (main.cpp:446-563)
+  FileSolver(path, **options)            the C++ time loop driven from an input file (kwh_create_from_file)
+  FileSolver.write_output(path)          sampled streams / final fields -> output file
+  read_dataset / dataset_info / read_attribute   small readers for tests and post-processing
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Dict
+
+import numpy as np
+
+from . import capi
+from .solver import Dataset, HostSolver, Options, _check, load_host
+
+H5_LIB_PATH = os.path.join(capi.PKG, "lib", "libkwave_host_h5.so")
+_h5 = None
+
+# datasets stored as interleaved complex (domain_type "complex")
+COMPLEX_DATASETS = {"ddx_k_shift_pos_r", "ddx_k_shift_neg_r", "ddy_k_shift_pos", "ddy_k_shift_neg", "ddz_k_shift_pos",
+                    "ddz_k_shift_neg", "x_shift_neg_r", "y_shift_neg_r", "z_shift_neg_r"}
+
+
+def load_h5() -> C.CDLL:
+    global _h5
+    if _h5 is None:
+        capi.load()
+        if not os.path.exists(H5_LIB_PATH):
+            raise capi.KWaveError(f"{H5_LIB_PATH} is missing (HDF5 component not built)")
+        L = C.CDLL(H5_LIB_PATH)
+        L.kwh_last_error.restype = C.c_char_p
+        L.kwh_create_from_file.argtypes = [C.c_char_p, C.POINTER(Options), C.POINTER(C.c_void_p)]
+        L.kwh_write_output_file.argtypes = [C.c_void_p, C.c_char_p]
+        L.kwh_write_input_file.argtypes = [C.c_char_p, C.POINTER(Dataset), C.c_size_t, C.POINTER(C.c_int32)]
+        L.kwh_h5_dataset_info.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(C.c_uint64 * 3), C.POINTER(C.c_int32),
+                                          C.POINTER(C.c_int32)]
+        L.kwh_h5_read.argtypes = [C.c_char_p, C.c_char_p, C.c_void_p, C.c_uint64, C.c_int32]
+        L.kwh_h5_read_attribute.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_uint64]
+        _h5 = L
+    return _h5
+
+
+def _h5check(rc: int):
+    if rc != 0:
+        raise capi.KWaveError(load_h5().kwh_last_error().decode(errors="replace"))
+
+
+def write_input_file(pr: Dict[str, np.ndarray], path: str) -> None:
+    """Write a problem dict (HDF5 dataset names, 1-based indices) as a k-Wave input file."""
+    L = load_h5()
+    keep = []
+    sets = (Dataset * len(pr))()
+    cplx = (C.c_int32 * len(pr))()
+    for i, (name, a) in enumerate(pr.items()):
+        arr = np.ascontiguousarray(a, dtype=np.uint64 if a.dtype == np.uint64 else np.float32)
+        keep.append(arr)
+        is_c = name in COMPLEX_DATASETS
+        shp = list(arr.shape)
+        if is_c:  # (n, 2) pairs -> (x = 2n, 1, 1) / (2, n) like the file format's doubled fastest dimension
+            shp = [shp[0] * 2] if name.startswith(("ddx", "x_shift")) else [shp[0], 2]
+        shp = shp[::-1]
+        while len(shp) < 3:
+            shp.append(1)
+        nm = name.encode()
+        keep.append(nm)
+        sets[i].name, sets[i].data, sets[i].dtype = nm, arr.ctypes.data, (1 if arr.dtype == np.uint64 else 0)
+        sets[i].nx, sets[i].ny, sets[i].nz = shp
+        cplx[i] = int(is_c)
+    _h5check(L.kwh_write_input_file(path.encode(), sets, len(pr), cplx))
+
+
+def dataset_info(path: str, name: str):
+    dims = (C.c_uint64 * 3)()
+    dt, cx = C.c_int32(), C.c_int32()
+    _h5check(load_h5().kwh_h5_dataset_info(path.encode(), name.encode(), C.byref(dims), C.byref(dt), C.byref(cx)))
+    return tuple(int(d) for d in dims), ("long" if dt.value else "float"), ("complex" if cx.value else "real")
+
+
+def read_dataset(path: str, name: str) -> np.ndarray:
+    (nx, ny, nz), dtype, _ = dataset_info(path, name)
+    out = np.empty((nz, ny, nx), dtype=np.uint64 if dtype == "long" else np.float32)
+    _h5check(load_h5().kwh_h5_read(path.encode(), name.encode(), out.ctypes.data, out.size, 1 if dtype == "long" else 0))
+    return out
+
+
+def read_attribute(path: str, dataset: str, attr: str) -> str:
+    buf = C.create_string_buffer(256)
+    _h5check(load_h5().kwh_h5_read_attribute(path.encode(), dataset.encode(), attr.encode(), buf, 256))
+    return buf.value.decode()
+
+
+class FileSolver(HostSolver):
+    """HostSolver created from a k-Wave HDF5 input file instead of in-memory datasets."""
+
+    def __init__(self, path: str, **opts):
+        L = load_h5()
+        self._keep = []
+        o = Options()
+        o.device_idx = opts.pop("device_idx", -1)
+        o.fused_kernels = int(opts.pop("fused_kernels", True))
+        o.sampling_start_time_index = opts.pop("sampling_start", 0)
+        o.benchmark_time_steps = opts.pop("benchmark_steps", 0)
+        o.period = float(opts.pop("period", 0.0))
+        o.mos = int(opts.pop("mos", 1))
+        o.harmonics = int(opts.pop("harmonics", 1))
+        for k, v in opts.items():
+            setattr(o, k, int(v))
+        self.nx, self.ny, self.nz = (int(read_dataset(path, k).ravel()[0]) for k in ("Nx", "Ny", "Nz"))
+        h = C.c_void_p()
+        _h5check(L.kwh_create_from_file(path.encode(), C.byref(o), C.byref(h)))
+        self._h = h
+        self.L = L  # the h5 library exports the whole kwh_* API
+        for fn, res, args in (("kwh_time_index", C.c_uint64, [C.c_void_p]), ("kwh_context", C.c_void_p, [C.c_void_p])):
+            getattr(L, fn).restype = res
+            getattr(L, fn).argtypes = args
+        L.kwh_run.argtypes = [C.c_void_p, C.c_uint64]
+        L.kwh_get_matrix.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_uint64]
+        L.kwh_matrix_size.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_uint64)]
+        L.kwh_get_scalar.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_float)]
+        L.kwh_stream_info.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+        L.kwh_stream_read.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_uint64]
+        for fn in ("kwh_destroy", "kwh_finish", "kwh_sync"):
+            getattr(L, fn).argtypes = [C.c_void_p]
+
+    def write_output(self, path: str):
+        _h5check(self.L.kwh_write_output_file(self._h, path.encode()))

@@ -1,0 +1,21 @@
+// HostSolverHandle.h — the object behind the opaque kwh_solver* of include/kwave_host.h (shared by host_capi.cpp and
+// the optional HDF5 entry points in h5/h5_capi.cpp).
+#ifndef KW_HOST_SOLVER_HANDLE_H
+#define KW_HOST_SOLVER_HANDLE_H
+#include <memory>
+#include <string>
+
+#include "KSpaceFirstOrderSolver.h"
+#include "kwave_host.h"
+
+struct kwh_solver
+{
+  MemoryInput                             input;       // datasets handed over in memory (kwh_create)
+  std::unique_ptr<InputProvider>          file_input;  // or an input file (kwh_create_from_file)
+  std::unique_ptr<KSpaceFirstOrderSolver> solver;
+};
+
+void kwh_set_error(const std::string& e);
+Parameters::Options kwh_convert_options(const kwh_options* o);
+void kwh_build_solver(kwh_solver& s, const InputProvider& input, const Parameters::Options& opt);
+#endif

@@ -1,0 +1,145 @@
+// Hdf5File.cpp — see Hdf5File.h.
+#include "Hdf5File.h"
+
+#include <ctime>
+#include <ios>
+#include <stdexcept>
+
+const std::string Hdf5File::kMatrixDomainTypeName = "domain_type";
+const std::string Hdf5File::kMatrixDataTypeName   = "data_type";
+static const char* kDomainNames[] = {"real", "complex"};
+static const char* kDataNames[]   = {"float", "long"};
+
+static void fail(const std::string& what) { throw std::ios_base::failure(what); }
+
+Hdf5File::~Hdf5File() { close(); }
+
+void Hdf5File::create(const std::string& fileName)
+{
+  close();
+  mFile = H5Fcreate(fileName.c_str(), H5F_ACC_TRUNC, H5P_DEFAULT, H5P_DEFAULT);
+  if (mFile < 0) fail("Error: File \"" + fileName + "\" could not be created");
+  mName = fileName;
+}
+void Hdf5File::open(const std::string& fileName, bool readOnly)
+{
+  close();
+  if (H5Fis_hdf5(fileName.c_str()) <= 0) fail("Error: File \"" + fileName + "\" is not a valid HDF5 file or does not exist");
+  mFile = H5Fopen(fileName.c_str(), readOnly ? H5F_ACC_RDONLY : H5F_ACC_RDWR, H5P_DEFAULT);
+  if (mFile < 0) fail("Error: File \"" + fileName + "\" could not be opened");
+  mName = fileName;
+}
+void Hdf5File::close()
+{
+  if (mFile >= 0) H5Fclose(mFile);
+  mFile = -1;
+}
+bool Hdf5File::datasetExists(const std::string& name) const { return H5Lexists(mFile, name.c_str(), H5P_DEFAULT) > 0; }
+
+DimensionSizes Hdf5File::getDatasetDimensionSizes(const std::string& name) const
+{
+  int rank = 0;
+  if (H5LTget_dataset_ndims(mFile, name.c_str(), &rank) < 0) fail("Error: cannot read dimension sizes of dataset \"" + name + "\"");
+  std::vector<hsize_t> dims(rank, 1);
+  if (H5LTget_dataset_info(mFile, name.c_str(), dims.data(), nullptr, nullptr) < 0)
+    fail("Error: cannot read dimension sizes of dataset \"" + name + "\"");
+  if (rank == 3) return DimensionSizes(dims[2], dims[1], dims[0]);
+  if (rank == 4) return DimensionSizes(dims[3], dims[2], dims[1], dims[0]);
+  fail("Error: dataset \"" + name + "\" is not 3-D / 4-D");
+  return DimensionSizes();
+}
+size_t Hdf5File::getDatasetSize(const std::string& name) const { return getDatasetDimensionSizes(name).nElements(); }
+
+std::string Hdf5File::readStringAttribute(const std::string& dataset, const std::string& attr) const
+{
+  char buf[256] = {0};
+  if (H5LTget_attribute_string(mFile, dataset.c_str(), attr.c_str(), buf) < 0)
+    fail("Error: cannot read attribute \"" + attr + "\" of \"" + dataset + "\"");
+  return std::string(buf);
+}
+void Hdf5File::writeStringAttribute(const std::string& dataset, const std::string& attr, const std::string& value)
+{
+  if (H5LTset_attribute_string(mFile, dataset.c_str(), attr.c_str(), value.c_str()) < 0)
+    fail("Error: cannot write attribute \"" + attr + "\" of \"" + dataset + "\"");
+}
+Hdf5File::MatrixDataType Hdf5File::readMatrixDataType(const std::string& name) const
+{
+  const std::string v = readStringAttribute(name, kMatrixDataTypeName);
+  if (v == kDataNames[0]) return MatrixDataType::kFloat;
+  if (v == kDataNames[1]) return MatrixDataType::kLong;
+  fail("Error: bad data_type attribute of dataset \"" + name + "\"");
+  return MatrixDataType::kFloat;
+}
+Hdf5File::MatrixDomainType Hdf5File::readMatrixDomainType(const std::string& name) const
+{
+  const std::string v = readStringAttribute(name, kMatrixDomainTypeName);
+  if (v == kDomainNames[0]) return MatrixDomainType::kReal;
+  if (v == kDomainNames[1]) return MatrixDomainType::kComplex;
+  fail("Error: bad domain_type attribute of dataset \"" + name + "\"");
+  return MatrixDomainType::kReal;
+}
+void Hdf5File::readCompleteDataset(const std::string& name, size_t nElements, float* data) const
+{
+  if (getDatasetSize(name) != nElements) fail("Error: dataset \"" + name + "\" has wrong dimension sizes");
+  if (nElements == 0) return;
+  if (H5LTread_dataset(mFile, name.c_str(), H5T_NATIVE_FLOAT, data) < 0) fail("Error: cannot read dataset \"" + name + "\"");
+}
+void Hdf5File::readCompleteDataset(const std::string& name, size_t nElements, size_t* data) const
+{
+  if (getDatasetSize(name) != nElements) fail("Error: dataset \"" + name + "\" has wrong dimension sizes");
+  if (nElements == 0) return;
+  if (H5LTread_dataset(mFile, name.c_str(), H5T_NATIVE_UINT64, data) < 0) fail("Error: cannot read dataset \"" + name + "\"");
+}
+static void writeDataset(hid_t file, const std::string& name, const DimensionSizes& d, hid_t fileType, hid_t memType,
+                         const void* data)
+{
+  hsize_t dims[3] = {d.nz, d.ny, d.nx};
+  hid_t space = H5Screate_simple(3, dims, nullptr);
+  hid_t set   = H5Dcreate2(file, name.c_str(), fileType, space, H5P_DEFAULT, H5P_DEFAULT, H5P_DEFAULT);
+  herr_t st   = -1;
+  if (set >= 0) st = (d.nx * d.ny * d.nz == 0) ? 0 : H5Dwrite(set, memType, H5S_ALL, H5S_ALL, H5P_DEFAULT, data);
+  if (set >= 0) H5Dclose(set);
+  H5Sclose(space);
+  if (set < 0 || st < 0) throw std::ios_base::failure("Error: cannot write dataset \"" + name + "\"");
+}
+void Hdf5File::writeMatrix(const std::string& name, const DimensionSizes& dims, const float* data, MatrixDomainType domain)
+{
+  writeDataset(mFile, name, dims, H5T_IEEE_F32LE, H5T_NATIVE_FLOAT, data);
+  writeStringAttribute(name, kMatrixDataTypeName, kDataNames[0]);
+  writeStringAttribute(name, kMatrixDomainTypeName, kDomainNames[static_cast<int>(domain)]);
+}
+void Hdf5File::writeMatrix(const std::string& name, const DimensionSizes& dims, const size_t* data)
+{
+  writeDataset(mFile, name, dims, H5T_STD_U64LE, H5T_NATIVE_UINT64, data);
+  writeStringAttribute(name, kMatrixDataTypeName, kDataNames[1]);
+  writeStringAttribute(name, kMatrixDomainTypeName, kDomainNames[0]);
+}
+void Hdf5File::writeScalarValue(const std::string& name, float value) { writeMatrix(name, DimensionSizes(1, 1, 1), &value, MatrixDomainType::kReal); }
+void Hdf5File::writeScalarValue(const std::string& name, size_t value) { writeMatrix(name, DimensionSizes(1, 1, 1), &value); }
+
+void Hdf5File::writeHeader(const std::string& fileType, const std::string& description)
+{
+  char date[64];
+  const time_t now = time(nullptr);
+  strftime(date, sizeof(date), "%d/%m/%y, %H:%M:%S", localtime(&now));
+  writeStringAttribute("/", "created_by", "kspaceFirstOrder-HIP v0.1 (gfx950)");
+  writeStringAttribute("/", "creation_date", date);
+  writeStringAttribute("/", "file_description", description);
+  writeStringAttribute("/", "file_type", fileType);
+  writeStringAttribute("/", "major_version", "1");
+  writeStringAttribute("/", "minor_version", "1");
+}
+
+Hdf5Input::Hdf5Input(const std::string& fileName)
+{
+  mFile.open(fileName, true);
+  const std::string type = mFile.readFileType();
+  if (type != "input") throw std::ios_base::failure("Error: the file \"" + fileName + "\" is not a k-Wave input file (file_type = " + type + ")");
+  const std::string major = mFile.readStringAttribute("/", "major_version"), minor = mFile.readStringAttribute("/", "minor_version");
+  if (major != "1" || (minor != "0" && minor != "1"))
+    throw std::ios_base::failure("Error: unsupported input file version " + major + "." + minor);
+}
+InputProvider::DataType Hdf5Input::getDatasetType(const std::string& name) const
+{
+  return mFile.readMatrixDataType(name) == Hdf5File::MatrixDataType::kFloat ? DataType::kFloat : DataType::kLong;
+}

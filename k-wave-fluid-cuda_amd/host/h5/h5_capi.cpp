@@ -1,0 +1,144 @@
+// h5_capi.cpp — HDF5 entry points of libkwave_host_h5.so: run the solver from a k-Wave input file and write a k-Wave
+// output file (main.cpp:840-966 sequence; dataset shapes IndexOutputStream.cpp:91-117, WholeDomainOutputStream.cpp,
+// KSpaceFirstOrderSolver.cpp:952-973,1100-1169), plus a writer for synthetic input files.
+#include <cstring>
+#include <exception>
+
+#include "../HipError.h"
+#include "../HostSolverHandle.h"
+#include "../MatrixNames.h"
+#include "Hdf5File.h"
+
+#define KWH_TRY try {
+#define KWH_CATCH                                                                                                      \
+  }                                                                                                                    \
+  catch (const std::bad_alloc&) { kwh_set_error("out of memory"); return 4; }                                          \
+  catch (const std::exception& e) { kwh_set_error(e.what()); return 1; }                                               \
+  catch (...) { kwh_set_error("unknown exception"); return 1; }                                                        \
+  return 0;
+
+void kwh_write_output(kwh_solver* s, const std::string& path)
+{
+  const Parameters& params = Parameters::getInstance();
+  Hdf5File out;
+  out.create(path);
+  out.writeHeader("output", "k-Wave output written by kspaceFirstOrder-HIP");
+  const DimensionSizes dims = params.getGlobalDimensionSizes();
+  out.writeScalarValue(kNxName, dims.nx);
+  out.writeScalarValue(kNyName, dims.ny);
+  out.writeScalarValue(kNzName, dims.nz);
+  out.writeScalarValue(kNtName, params.getNt());
+  out.writeScalarValue(kTimeIndexName, params.getTimeIndex());
+  out.writeScalarValue(kDtName, params.getDt());
+  out.writeScalarValue(kDxName, params.getDx());
+  out.writeScalarValue(kDyName, params.getDy());
+  out.writeScalarValue(kDzName, params.getDz());
+  out.writeScalarValue(kCRefName, params.getCRef());
+  out.writeScalarValue(kNonLinearFlagName, params.getNonLinearFlag());
+  out.writeScalarValue(kAbsorbingFlagName, params.getAbsorbingFlag());
+  out.writeScalarValue(kSensorMaskTypeName, static_cast<size_t>(params.getSensorMaskType()));
+  // streams: raw series (Nsens, Nt - s, 1); aggregates (Nsens, 1, 1); whole-domain (Nx, Ny, Nz)
+  OutputStreamContainer& streams = s->solver->getOutputStreamContainer();
+  for (const std::string& name : streams.names())
+  {
+    BaseOutputStream* st = streams.find(name);
+    const bool series = st->reduceOp() == BaseOutputStream::ReduceOperator::kNone ||
+                        st->reduceOp() == BaseOutputStream::ReduceOperator::kC;
+    DimensionSizes d(st->size(), series ? st->sampledSteps() : 1, 1);
+    if (!series && st->size() == dims.nElements()) d = dims;
+    if (st->dataset().size() != d.nElements()) continue; // nothing sampled yet
+    out.writeMatrix(name, d, st->dataset().data(), Hdf5File::MatrixDomainType::kReal);
+  }
+  auto writeFinal = [&](MatrixContainer::MatrixIdx idx, const std::string& name) {
+    RealMatrix& m = s->solver->getMatrixContainer().getMatrix<RealMatrix>(idx);
+    m.copyFromDevice();
+    out.writeMatrix(name, m.getDimensionSizes(), m.getHostData(), Hdf5File::MatrixDomainType::kReal);
+    m.freeHostData();
+  };
+  using MI = MatrixContainer::MatrixIdx;
+  if (params.getStorePressureFinalAllFlag()) writeFinal(MI::kP, kPressureFinalName);
+  if (params.getStoreVelocityFinalAllFlag())
+  {
+    writeFinal(MI::kUxSgx, kUxFinalName);
+    writeFinal(MI::kUySgy, kUyFinalName);
+    writeFinal(MI::kUzSgz, kUzFinalName);
+  }
+  out.close();
+}
+
+extern "C" {
+
+KWH_API int kwh_create_from_file(const char* input_path, const kwh_options* o, kwh_solver** out)
+{
+  KWH_TRY
+  if (!input_path || !o || !out) throw std::invalid_argument("kwh_create_from_file: NULL argument");
+  *out = nullptr;
+  std::unique_ptr<kwh_solver> s(new kwh_solver());
+  s->file_input.reset(new Hdf5Input(input_path));
+  kwh_build_solver(*s, *s->file_input, kwh_convert_options(o));
+  s->file_input.reset(); // everything has been loaded; the file is closed like in loadInputData (:247-252)
+  *out = s.release();
+  KWH_CATCH
+}
+
+KWH_API int kwh_write_output_file(kwh_solver* s, const char* path)
+{
+  KWH_TRY
+  if (!s || !path) throw std::invalid_argument("kwh_write_output_file: NULL argument");
+  kwh_write_output(s, path);
+  KWH_CATCH
+}
+
+/* write an input file from in-memory datasets (the synthetic generator's output); complex[i] != 0 marks interleaved
+ * complex datasets (domain_type "complex") */
+KWH_API int kwh_write_input_file(const char* path, const kwh_dataset* sets, size_t n, const int32_t* is_complex)
+{
+  KWH_TRY
+  Hdf5File f;
+  f.create(path);
+  f.writeHeader("input", "synthetic k-Wave input written by kwave_amd.synthetic");
+  for (size_t i = 0; i < n; i++)
+  {
+    const DimensionSizes d(sets[i].nx, sets[i].ny, sets[i].nz);
+    if (sets[i].dtype == 0)
+      f.writeMatrix(sets[i].name, d, static_cast<const float*>(sets[i].data),
+                    (is_complex && is_complex[i]) ? Hdf5File::MatrixDomainType::kComplex : Hdf5File::MatrixDomainType::kReal);
+    else
+      f.writeMatrix(sets[i].name, d, static_cast<const size_t*>(sets[i].data));
+  }
+  f.close();
+  KWH_CATCH
+}
+
+/* generic readers used by the tests: dims as (x,y,z); dtype 0 float / 1 uint64 */
+KWH_API int kwh_h5_dataset_info(const char* path, const char* name, uint64_t dims[3], int32_t* dtype, int32_t* is_complex)
+{
+  KWH_TRY
+  Hdf5File f;
+  f.open(path, true);
+  const DimensionSizes d = f.getDatasetDimensionSizes(name);
+  dims[0] = d.nx; dims[1] = d.ny; dims[2] = d.nz;
+  *dtype      = f.readMatrixDataType(name) == Hdf5File::MatrixDataType::kFloat ? 0 : 1;
+  *is_complex = f.readMatrixDomainType(name) == Hdf5File::MatrixDomainType::kComplex ? 1 : 0;
+  KWH_CATCH
+}
+KWH_API int kwh_h5_read(const char* path, const char* name, void* dst, uint64_t n, int32_t dtype)
+{
+  KWH_TRY
+  Hdf5File f;
+  f.open(path, true);
+  if (dtype == 0) f.readCompleteDataset(name, n, static_cast<float*>(dst));
+  else f.readCompleteDataset(name, n, static_cast<size_t*>(dst));
+  KWH_CATCH
+}
+KWH_API int kwh_h5_read_attribute(const char* path, const char* dataset, const char* attr, char* out, uint64_t cap)
+{
+  KWH_TRY
+  Hdf5File f;
+  f.open(path, true);
+  const std::string v = f.readStringAttribute(dataset, attr);
+  std::strncpy(out, v.c_str(), cap);
+  if (cap) out[cap - 1] = 0;
+  KWH_CATCH
+}
+}

@@ -1,0 +1,86 @@
+// main.cpp — command-line front end "kspaceFirstOrder-HIP": input file -> simulation on an MI355X -> output file.
+// Mirrors the sequence of the reference's main() (main.cpp:840-966) and the subset of its flags that select what
+// the loop computes and stores (CommandLineParameters.cpp:264-292); cosmetics (usage box, progress table) are out of scope.
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+
+#include "../HipError.h"
+#include "../HostSolverHandle.h"
+#include "Hdf5File.h"
+
+void kwh_write_output(kwh_solver* s, const std::string& path);
+
+static void usage()
+{
+  std::printf("kspaceFirstOrder-HIP -i <input.h5> -o <output.h5> [-g dev] [-s start (1-based)] [--benchmark N]\n"
+              "  [-p|--p_raw] [--p_rms] [--p_max] [--p_min] [--p_max_all] [--p_min_all] [--p_final]\n"
+              "  [-u|--u_raw] [--u_rms] [--u_max] [--u_min] [--u_max_all] [--u_min_all] [--u_final] [--u_non_staggered_raw]\n"
+              "  [--p_c] [--u_non_staggered_c] [--I_avg_c] [--period P] [--mos M] [--harmonics H] [--no_overlap] [--granular]\n");
+}
+
+int main(int argc, char** argv)
+{
+  std::string in, out;
+  kwh_options o{};
+  o.device_idx    = -1;
+  o.fused_kernels = 1;
+  o.mos = o.harmonics = 1;
+  for (int i = 1; i < argc; i++)
+  {
+    const std::string a = argv[i];
+    auto next = [&]() -> const char* { if (i + 1 >= argc) { usage(); std::exit(EXIT_FAILURE); } return argv[++i]; };
+    if (a == "-i") in = next();
+    else if (a == "-o") out = next();
+    else if (a == "-g") o.device_idx = std::atoi(next());
+    else if (a == "-s") o.sampling_start_time_index = std::strtoull(next(), nullptr, 10) - 1; // 1-based on the CLI (:416-425)
+    else if (a == "--benchmark") o.benchmark_time_steps = std::strtoull(next(), nullptr, 10);
+    else if (a == "-p" || a == "--p_raw") o.p_raw = 1;
+    else if (a == "--p_rms") o.p_rms = 1;
+    else if (a == "--p_max") o.p_max = 1;
+    else if (a == "--p_min") o.p_min = 1;
+    else if (a == "--p_max_all") o.p_max_all = 1;
+    else if (a == "--p_min_all") o.p_min_all = 1;
+    else if (a == "--p_final") o.p_final = 1;
+    else if (a == "-u" || a == "--u_raw") o.u_raw = 1;
+    else if (a == "--u_rms") o.u_rms = 1;
+    else if (a == "--u_max") o.u_max = 1;
+    else if (a == "--u_min") o.u_min = 1;
+    else if (a == "--u_max_all") o.u_max_all = 1;
+    else if (a == "--u_min_all") o.u_min_all = 1;
+    else if (a == "--u_final") o.u_final = 1;
+    else if (a == "--u_non_staggered_raw") o.u_non_staggered_raw = 1;
+    else if (a == "--p_c") o.p_c = 1;
+    else if (a == "--u_non_staggered_c") o.u_non_staggered_c = 1;
+    else if (a == "--I_avg_c") o.i_avg_c = 1;
+    else if (a == "--period") o.period = std::strtof(next(), nullptr);
+    else if (a == "--mos") o.mos = std::strtoull(next(), nullptr, 10);
+    else if (a == "--harmonics") o.harmonics = std::strtoull(next(), nullptr, 10);
+    else if (a == "--no_overlap") o.no_overlap = 1;
+    else if (a == "--granular") o.fused_kernels = 0;
+    else if (a == "-h" || a == "--help") { usage(); return EXIT_SUCCESS; }
+    else { std::fprintf(stderr, "unknown flag %s\n", a.c_str()); usage(); return EXIT_FAILURE; }
+  }
+  if (in.empty() || out.empty()) { usage(); return EXIT_FAILURE; }
+  try
+  {
+    kwh_solver s;
+    s.file_input.reset(new Hdf5Input(in));
+    kwh_build_solver(s, *s.file_input, kwh_convert_options(&o));
+    s.file_input.reset();
+    std::printf("%s on %s\n", s.solver->getCodeName().c_str(),
+                Parameters::getInstance().getHipParameters().getDeviceName().c_str());
+    s.solver->compute();
+    kwCheck(kw_sync(Parameters::getInstance().getHipParameters().getContext()));
+    kwh_write_output(&s, out);
+    std::printf("time steps: %zu, output: %s\n", Parameters::getInstance().getTimeIndex(), out.c_str());
+    s.solver.reset();
+  }
+  catch (const std::exception& e)
+  { // Logger::errorAndTerminate (Logger.cpp:82-89)
+    std::fprintf(stderr, "Error: %s\n", e.what());
+    return EXIT_FAILURE;
+  }
+  return EXIT_SUCCESS;
+}

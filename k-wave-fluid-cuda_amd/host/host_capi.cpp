@@ -6,16 +6,52 @@
 #include <string>
 
 #include "HipError.h"
+#include "HostSolverHandle.h"
 #include "KSpaceFirstOrderSolver.h"
 #include "kwave_host.h"
 
 static thread_local std::string g_err;
+void kwh_set_error(const std::string& e) { g_err = e; }
 
-struct kwh_solver
+Parameters::Options kwh_convert_options(const kwh_options* o)
 {
-  MemoryInput                             input;
-  std::unique_ptr<KSpaceFirstOrderSolver> solver;
-};
+  Parameters::Options opt;
+  opt.deviceIdx              = o->device_idx;
+  opt.fusedKernels           = o->fused_kernels != 0;
+  opt.samplingStartTimeIndex = o->sampling_start_time_index;
+  opt.benchmarkTimeStepCount = o->benchmark_time_steps;
+  opt.storePressureRaw = o->p_raw; opt.storePressureRms = o->p_rms; opt.storePressureMax = o->p_max;
+  opt.storePressureMin = o->p_min; opt.storePressureMaxAll = o->p_max_all; opt.storePressureMinAll = o->p_min_all;
+  opt.storePressureFinalAll = o->p_final;
+  opt.storeVelocityRaw = o->u_raw; opt.storeVelocityRms = o->u_rms; opt.storeVelocityMax = o->u_max;
+  opt.storeVelocityMin = o->u_min; opt.storeVelocityMaxAll = o->u_max_all; opt.storeVelocityMinAll = o->u_min_all;
+  opt.storeVelocityFinalAll = o->u_final; opt.storeVelocityNonStaggeredRaw = o->u_non_staggered_raw;
+  opt.storePressureC = o->p_c; opt.storeVelocityNonStaggeredC = o->u_non_staggered_c;
+  opt.storeIntensityAvgC = o->i_avg_c; opt.noCompressionOverlap = o->no_overlap;
+  opt.period = o->period; opt.mos = o->mos ? o->mos : 1; opt.harmonics = o->harmonics ? o->harmonics : 1;
+  opt.slabRanks = o->slab_ranks ? o->slab_ranks : 1;
+  opt.slabRank  = o->slab_rank;
+  opt.nzGlobal  = o->nz_global;
+  opt.exchangeFn   = reinterpret_cast<kw_exchange_fn>(o->exchange_fn);
+  opt.exchangeUser = o->exchange_user;
+  opt.exchangeStartFn = reinterpret_cast<kw_exchange_start_fn>(o->exchange_start_fn);
+  opt.exchangeWaitFn  = reinterpret_cast<kw_exchange_wait_fn>(o->exchange_wait_fn);
+  for (int i = 0; i < 6; i++) opt.scratch[i] = o->scratch[i];
+  return opt;
+}
+
+/// Parameters::init + selectDevice + allocateMemory + loadInputData (main.cpp:857-917) on any InputProvider
+void kwh_build_solver(kwh_solver& s, const InputProvider& input, const Parameters::Options& opt)
+{
+  Parameters& params = Parameters::getInstance();
+  params.init(input, opt);
+  params.selectDevice();
+  params.getHipParameters().setUpDeviceConstants();
+  s.solver.reset(new KSpaceFirstOrderSolver());
+  s.solver->allocateMemory();
+  s.solver->loadInputData(input);
+}
+
 
 #define KWH_TRY try {
 #define KWH_CATCH                                                                                                      \
@@ -42,36 +78,7 @@ int kwh_create(const kwh_dataset* datasets, size_t n, const kwh_options* o, kwh_
     // complex datasets come with their float count in nx*ny*nz already doubled by the caller's shape
     s->input.add(d.name, d.data, d.dtype == 0 ? InputProvider::DataType::kFloat : InputProvider::DataType::kLong, dims);
   }
-  Parameters::Options opt;
-  opt.deviceIdx              = o->device_idx;
-  opt.fusedKernels           = o->fused_kernels != 0;
-  opt.samplingStartTimeIndex = o->sampling_start_time_index;
-  opt.benchmarkTimeStepCount = o->benchmark_time_steps;
-  opt.storePressureRaw = o->p_raw; opt.storePressureRms = o->p_rms; opt.storePressureMax = o->p_max;
-  opt.storePressureMin = o->p_min; opt.storePressureMaxAll = o->p_max_all; opt.storePressureMinAll = o->p_min_all;
-  opt.storePressureFinalAll = o->p_final;
-  opt.storeVelocityRaw = o->u_raw; opt.storeVelocityRms = o->u_rms; opt.storeVelocityMax = o->u_max;
-  opt.storeVelocityMin = o->u_min; opt.storeVelocityMaxAll = o->u_max_all; opt.storeVelocityMinAll = o->u_min_all;
-  opt.storeVelocityFinalAll = o->u_final; opt.storeVelocityNonStaggeredRaw = o->u_non_staggered_raw;
-  opt.storePressureC = o->p_c; opt.storeVelocityNonStaggeredC = o->u_non_staggered_c;
-  opt.storeIntensityAvgC = o->i_avg_c; opt.noCompressionOverlap = o->no_overlap;
-  opt.period = o->period; opt.mos = o->mos ? o->mos : 1; opt.harmonics = o->harmonics ? o->harmonics : 1;
-  opt.slabRanks = o->slab_ranks ? o->slab_ranks : 1;
-  opt.slabRank  = o->slab_rank;
-  opt.nzGlobal  = o->nz_global;
-  opt.exchangeFn   = reinterpret_cast<kw_exchange_fn>(o->exchange_fn);
-  opt.exchangeUser = o->exchange_user;
-  opt.exchangeStartFn = reinterpret_cast<kw_exchange_start_fn>(o->exchange_start_fn);
-  opt.exchangeWaitFn  = reinterpret_cast<kw_exchange_wait_fn>(o->exchange_wait_fn);
-  for (int i = 0; i < 6; i++) opt.scratch[i] = o->scratch[i];
-
-  Parameters& params = Parameters::getInstance();
-  params.init(s->input, opt);
-  params.selectDevice();
-  params.getHipParameters().setUpDeviceConstants();
-  s->solver.reset(new KSpaceFirstOrderSolver());
-  s->solver->allocateMemory();
-  s->solver->loadInputData(s->input);
+  kwh_build_solver(*s, s->input, kwh_convert_options(o));
   *out = s.release();
   KWH_CATCH
 }

@@ -1,0 +1,105 @@
+"""HDF5 file-format layer: input files the reference could read, output files with the
+reference's dataset shapes; the C++ loop driven from a file gives the same bits as from memory."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+
+@pytest.fixture(scope="module")
+def h5io():
+    import __graft_entry__ as ge
+    ge.build()
+    import kwave_amd  # noqa: F401
+    from kwave_amd import h5io as m
+    if not os.path.exists(m.H5_LIB_PATH):
+        pytest.skip("HDF5 component not built (no HDF5 in this image)")
+    return m
+
+
+def test_input_file_roundtrip_and_attributes(h5io, syn, tmp_path):
+    pr = syn.make_problem(16, 12, 8, nt=6, pml_size=2, source="p_source", source_many=1, sensor="random")
+    path = str(tmp_path / "in.h5")
+    h5io.write_input_file(pr, path)
+    assert h5io.read_attribute(path, "/", "file_type") == "input"
+    assert h5io.read_attribute(path, "/", "major_version") == "1" and h5io.read_attribute(path, "/", "minor_version") == "1"
+    # 3-D real array: dims (x,y,z), float/real
+    assert h5io.dataset_info(path, "c0") == ((16, 12, 8), "float", "real")
+    # scalars are (1,1,1); flags / sizes are "long"
+    assert h5io.dataset_info(path, "Nx") == ((1, 1, 1), "long", "real")
+    assert h5io.dataset_info(path, "dt") == ((1, 1, 1), "float", "real")
+    # complex operators: interleaved, doubled fastest dimension, domain_type complex (Hdf5File.cpp:898-915)
+    assert h5io.dataset_info(path, "ddx_k_shift_pos_r") == ((2 * 9, 1, 1), "float", "complex")
+    assert h5io.dataset_info(path, "ddy_k_shift_neg") == ((2, 12, 1), "float", "complex")
+    assert h5io.dataset_info(path, "sensor_mask_index")[1] == "long"
+    for name, a in pr.items():
+        got = h5io.read_dataset(path, name)
+        assert got.size == a.size and np.array_equal(got.ravel(), np.asarray(a).ravel()), name
+
+
+def test_wrong_file_type_is_rejected(h5io, syn, tmp_path):
+    """Reader checks like the reference's (KSpaceFirstOrderSolver.cpp:2797-2891): an output file is not an input file."""
+    import kwave_amd  # noqa: F401
+    from kwave_amd import capi
+    path = str(tmp_path / "not_input.h5")
+    pr = syn.make_problem(16, nt=4, pml_size=2)
+    h5io.write_input_file(pr, path)
+    with pytest.raises(capi.KWaveError):
+        h5io.read_dataset(path, "no_such_dataset")
+    with pytest.raises(capi.KWaveError):
+        h5io.FileSolver(str(tmp_path / "missing.h5"))
+
+
+@pytest.mark.gpu
+def test_file_driven_run_equals_memory_run_and_output_file(h5io, syn, tmp_path):
+    from kwave_amd.solver import HostSolver
+    pr = syn.make_problem(32, heterogeneous=True, nonlinear=True, absorbing=True, source="p0", nt=15, pml_size=4,
+                          sensor="random")
+    path_in, path_out = str(tmp_path / "in.h5"), str(tmp_path / "out.h5")
+    h5io.write_input_file(pr, path_in)
+    mem = HostSolver(pr, p_raw=1, p_max=1, p_final=1)
+    mem.run(15)
+    mem.finish()
+    fs = h5io.FileSolver(path_in, p_raw=1, p_max=1, p_final=1)
+    fs.run(15)
+    fs.finish()
+    assert np.array_equal(fs.field("p"), mem.field("p"))
+    assert np.array_equal(fs.stream("p"), mem.stream("p"))
+    fs.write_output(path_out)
+    nsens = pr["sensor_mask_index"].size
+    assert h5io.read_attribute(path_out, "/", "file_type") == "output"
+    assert h5io.dataset_info(path_out, "p") == ((nsens, 15, 1), "float", "real")      # (Nsens, Nt - s, 1)
+    assert h5io.dataset_info(path_out, "p_max") == ((nsens, 1, 1), "float", "real")
+    assert h5io.dataset_info(path_out, "p_final") == ((32, 32, 32), "float", "real")
+    assert np.array_equal(h5io.read_dataset(path_out, "p").reshape(15, nsens), mem.stream("p"))
+    assert np.array_equal(h5io.read_dataset(path_out, "p_final"), mem.field("p"))
+    assert int(h5io.read_dataset(path_out, "t_index").ravel()[0]) == 15
+    fs.close()
+    mem.close()
+
+
+@pytest.mark.gpu
+def test_command_line_program(h5io, syn, tmp_path):
+    """kspaceFirstOrder-HIP -i in.h5 -o out.h5 --p_raw --p_final -s 3 --benchmark 12"""
+    import kwave_amd  # noqa: F401
+    from kwave_amd import capi
+    from kwave_amd.solver import HostSolver
+    pr = syn.make_problem(32, heterogeneous=False, nonlinear=False, absorbing=True, source="p0", nt=40, pml_size=4)
+    path_in, path_out = str(tmp_path / "in.h5"), str(tmp_path / "out.h5")
+    h5io.write_input_file(pr, path_in)
+    exe = os.path.join(capi.PKG, "lib", "kspaceFirstOrder-HIP")
+    r = subprocess.run([exe, "-i", path_in, "-o", path_out, "--p_raw", "--p_final", "-s", "3", "--benchmark", "12"],
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout
+    mem = HostSolver(pr, p_raw=1, sampling_start=2, benchmark_steps=12)
+    mem.run(12)
+    mem.finish()
+    nsens = pr["sensor_mask_index"].size
+    assert h5io.dataset_info(path_out, "p")[0] == (nsens, 10, 1)
+    assert np.array_equal(h5io.read_dataset(path_out, "p").reshape(10, nsens), mem.stream("p"))
+    assert np.array_equal(h5io.read_dataset(path_out, "p_final"), mem.field("p"))
+    mem.close()
+    r = subprocess.run([exe, "-i", str(tmp_path / "missing.h5"), "-o", path_out], stdout=subprocess.PIPE,
+                       stderr=subprocess.STDOUT, text=True, timeout=60)
+    assert r.returncode != 0 and "Error" in r.stdout
