@@ -70,10 +70,11 @@ struct RowAddr
 {
   uint32_t sh, mask, qstride, zmul;
   uint32_t estride; // 1 for y-lines; ny for lines along z (probe / plain z transform)
-  __device__ __forceinline__ size_t row(uint32_t z, uint32_t ky) const
+  // 32-bit element indices throughout the pipeline: every scratch / field array has < 2^32 elements (checked in
+  // kw_fused_supported), so addresses are "uniform base + 32-bit lane offset" and need no 64-bit VALU arithmetic
+  __device__ __forceinline__ uint32_t row(uint32_t z, uint32_t ky) const
   {
-    return static_cast<size_t>(ky >> sh) * qstride + static_cast<size_t>(ky & mask) * estride +
-           static_cast<size_t>(z) * zmul;
+    return (ky >> sh) * qstride + (ky & mask) * estride + z * zmul;
   }
 };
 
@@ -86,7 +87,10 @@ struct PassArgs
   RowAddr       ain, aout;
 };
 
-template<int L, int DIR> __global__ __launch_bounds__(Geo<L>::THREADS) void k_ypass(PassArgs a)
+// PIN / POUT: packed (per-peer chunk) addressing on the input / output side; the natural layout is the cheap
+// compile-time-strided case  element(k) = base + k * P.
+template<int L, int DIR, bool PIN, bool POUT>
+__global__ __launch_bounds__(Geo<L>::THREADS) void k_ypass(PassArgs a)
 {
   using G = Geo<L>;
   constexpr int R1 = G::R1, R2 = G::R2;
@@ -101,9 +105,19 @@ template<int L, int DIR> __global__ __launch_bounds__(Geo<L>::THREADS) void k_yp
   if (j < R2)
   {
     float2 v[R1];
+    if (PIN)
+    {
 #pragma unroll
-    for (int n1 = 0; n1 < R1; n1++)
-      v[n1] = valid ? Sin[a.ain.row(z, n1 * R2 + j) * a.P + kx] : make_float2(0.f, 0.f);
+      for (int n1 = 0; n1 < R1; n1++)
+        v[n1] = valid ? Sin[a.ain.row(z, n1 * R2 + j) * a.P + kx] : make_float2(0.f, 0.f);
+    }
+    else
+    {
+      const uint32_t b = (z * a.ain.zmul + j * a.ain.estride) * a.P + kx; // estride = 1 (y lines) or ny (z probe)
+      const uint32_t step = R2 * a.ain.estride * a.P;
+#pragma unroll
+      for (int n1 = 0; n1 < R1; n1++) v[n1] = valid ? Sin[b + n1 * step] : make_float2(0.f, 0.f);
+    }
     step_a<L, DIR>(v, j, a.tw);
 #pragma unroll
     for (int k1 = 0; k1 < R1; k1++) lds[k1 * G::SF + j * G::NL + c] = v[k1];
@@ -117,8 +131,18 @@ template<int L, int DIR> __global__ __launch_bounds__(Geo<L>::THREADS) void k_yp
     Dft<R2, DIR>::run(w);
     if (valid)
     {
+      if (POUT)
+      {
 #pragma unroll
-      for (int k2 = 0; k2 < R2; k2++) Sout[a.aout.row(z, j + R1 * k2) * a.P + kx] = w[k2];
+        for (int k2 = 0; k2 < R2; k2++) Sout[a.aout.row(z, j + R1 * k2) * a.P + kx] = w[k2];
+      }
+      else
+      {
+        const uint32_t b = (z * a.aout.zmul + j * a.aout.estride) * a.P + kx;
+        const uint32_t step = R1 * a.aout.estride * a.P;
+#pragma unroll
+        for (int k2 = 0; k2 < R2; k2++) Sout[b + k2 * step] = w[k2];
+      }
     }
   }
 }
@@ -178,8 +202,8 @@ template<int L, int MODE> __global__ __launch_bounds__(Geo<L>::THREADS) void k_z
   const uint32_t kx     = blockIdx.x * G::NL + c;
   const uint32_t ky     = blockIdx.y;
   const bool     valid  = kx < a.nxc;
-  const size_t   zstr   = static_cast<size_t>(a.ny) * a.P;
-  const size_t   base   = static_cast<size_t>(ky) * a.P + kx;
+  const uint32_t zstr   = a.ny * a.P;
+  const uint32_t base   = ky * a.P + kx;
   const uint32_t arr    = (MODE == Z_VGRAD || MODE == Z_ABSORB) ? blockIdx.z + a.arr0 : 0;
   const float2* __restrict__ in = a.in[arr];
 
@@ -188,7 +212,7 @@ template<int L, int MODE> __global__ __launch_bounds__(Geo<L>::THREADS) void k_z
     float2 v[R1];
 #pragma unroll
     for (int n1 = 0; n1 < R1; n1++)
-      v[n1] = valid ? in[base + static_cast<size_t>(n1 * R2 + j) * zstr] : make_float2(0.f, 0.f);
+      v[n1] = valid ? in[base + static_cast<uint32_t>(n1 * R2 + j) * zstr] : make_float2(0.f, 0.f);
     step_a<L, kFwd>(v, j, a.tw);
 #pragma unroll
     for (int k1 = 0; k1 < R1; k1++) lds[k1 * G::SF + j * G::NL + c] = v[k1];
@@ -211,7 +235,7 @@ template<int L, int MODE> __global__ __launch_bounds__(Geo<L>::THREADS) void k_z
     const float* __restrict__ op = a.op[(MODE == Z_ABSORB) ? arr : 0];
 #pragma unroll
     for (int k2 = 0; k2 < R2; k2++)
-      kap[k2] = valid ? op[base + static_cast<size_t>(j + R1 * k2) * zstr] : 0.f;
+      kap[k2] = valid ? op[base + static_cast<uint32_t>(j + R1 * k2) * zstr] : 0.f;
   }
 #pragma unroll 1
   for (int o = 0; o < NOUT; o++)
@@ -263,7 +287,7 @@ template<int L, int MODE> __global__ __launch_bounds__(Geo<L>::THREADS) void k_z
     {
       float2* __restrict__ out = a.out[(MODE == Z_PGRAD) ? o : arr];
 #pragma unroll
-      for (int q2 = 0; q2 < R1; q2++) out[base + static_cast<size_t>(j + R2 * q2) * zstr] = v[q2];
+      for (int q2 = 0; q2 < R1; q2++) out[base + static_cast<uint32_t>(j + R2 * q2) * zstr] = v[q2];
     }
     if (o + 1 < NOUT) __syncthreads(); // exchange buffer reused by the next output
   }
@@ -310,7 +334,7 @@ __device__ __forceinline__ void xfwd_tail(float2 (&v)[Fac<L>::R1], float2* lds, 
     for (int k2 = 0; k2 < R2; k2++) lds[c * G::ZP + f + R1 * k2] = w[k2];
   }
   __syncthreads();
-  const size_t tile_row0 = static_cast<size_t>(blockIdx.x) * G::NL * 2;
+  const uint32_t tile_row0 = blockIdx.x * G::NL * 2;
   for (int e = threadIdx.x; e < G::NL * HALF; e += G::THREADS)
   {
     const int    cc = e / HALF;
@@ -319,7 +343,7 @@ __device__ __forceinline__ void xfwd_tail(float2 (&v)[Fac<L>::R1], float2* lds, 
     const float2 zn = lds[cc * G::ZP + ((L - k) & (L - 1))];
     const float2 xa = make_float2(0.5f * (zk.x + zn.x), 0.5f * (zk.y - zn.y));
     const float2 xb = make_float2(0.5f * (zk.y + zn.y), 0.5f * (zn.x - zk.x));
-    const size_t r  = tile_row0 + 2 * cc;
+    const uint32_t r = tile_row0 + 2 * cc;
     out[r * P + k]       = xa;
     out[(r + 1) * P + k] = xb;
   }
@@ -334,7 +358,7 @@ template<int L> __global__ __launch_bounds__(Geo<L>::THREADS) void k_xfwd(XfwdAr
   const int    f   = threadIdx.x % G::TPL;
   const int    c   = threadIdx.x / G::TPL;
   const float* __restrict__ in = a.in[blockIdx.y];
-  const size_t row0 = (static_cast<size_t>(blockIdx.x) * G::NL + c) * 2;
+  const uint32_t row0 = (blockIdx.x * G::NL + c) * 2;
   float2 v[R1];
   if (f < R2)
   {
@@ -378,12 +402,12 @@ __device__ __forceinline__ void xinv_lines(const float2* __restrict__ src, uint3
 {
   using G = Geo<L>;
   constexpr int R1 = G::R1, R2 = G::R2, HALF = L / 2 + 1;
-  const size_t tile_row0 = static_cast<size_t>(blockIdx.x) * G::NL * 2;
+  const uint32_t tile_row0 = blockIdx.x * G::NL * 2;
   for (int e = threadIdx.x; e < G::NL * HALF; e += G::THREADS)
   {
     const int    cc = e / HALF;
     const int    k  = e - cc * HALF;
-    const size_t r  = tile_row0 + 2 * cc;
+    const uint32_t r = tile_row0 + 2 * cc;
     float2       A  = src[r * P + k];
     float2       B  = src[(r + 1) * P + k];
     if (k == 0 || k == L / 2) { A.y = 0.f; B.y = 0.f; } // C2R ignores the imaginary part of DC / Nyquist
@@ -470,17 +494,17 @@ template<int L, int EPI, bool CHAIN> __global__ __launch_bounds__(Geo<L>::THREAD
   }
 
   const kw_constants& k = a.c;
-  const size_t tile_row0 = static_cast<size_t>(blockIdx.x) * G::NL * 2;
+  const uint32_t tile_row0 = blockIdx.x * G::NL * 2;
 #pragma unroll
   for (int q = 0; q < NQ; q++)
   {
     const int      e   = threadIdx.x + q * G::THREADS;
     const int      row = e / Q4;
     const uint32_t x   = 4u * static_cast<uint32_t>(e - row * Q4);
-    const size_t   r   = tile_row0 + row;
-    const uint32_t z   = static_cast<uint32_t>(r / k.ny);
-    const uint32_t y   = static_cast<uint32_t>(r - static_cast<size_t>(z) * k.ny);
-    const size_t   i   = r * L + x;
+    const uint32_t r   = tile_row0 + row;
+    const uint32_t z   = r / k.ny;
+    const uint32_t y   = r - z * k.ny;
+    const uint32_t i   = r * L + x;
     if (EPI == EPI_STORE)
     {
       st4(a.out[comp] + i, res[0][q]);
@@ -731,9 +755,12 @@ kw_status launch_ypass(kw_ctx* ctx, int dir, int narr, float2* const* in, float2
   a.ain  = pack_in ? packed : natural;
   a.aout = pack_out ? packed : natural;
   const dim3 grid(f.P / nl_of(c.ny), c.nz, narr);
+  // forward: natural in, natural or packed out; inverse: natural or packed in, natural out
 #define M(LEN)                                                                                                         \
-  if (dir < 0) LAUNCH((k_ypass<LEN, kFwd>), grid, dim3(Geo<LEN>::THREADS), a);                                         \
-  else LAUNCH((k_ypass<LEN, kInv>), grid, dim3(Geo<LEN>::THREADS), a)
+  if (dir < 0) { if (pack_out) LAUNCH((k_ypass<LEN, kFwd, false, true>), grid, dim3(Geo<LEN>::THREADS), a);           \
+                 else LAUNCH((k_ypass<LEN, kFwd, false, false>), grid, dim3(Geo<LEN>::THREADS), a); }                  \
+  else         { if (pack_in) LAUNCH((k_ypass<LEN, kInv, true, false>), grid, dim3(Geo<LEN>::THREADS), a);            \
+                 else LAUNCH((k_ypass<LEN, kInv, false, false>), grid, dim3(Geo<LEN>::THREADS), a); }
   KW_LEN_SWITCH(c.ny, M)
 #undef M
   return KW_OK;
@@ -955,6 +982,8 @@ kw_status kw_fused_supported(kw_ctx* ctx, int* out)
   const uint32_t nzg    = (f.nranks > 1) ? f.nz_global : c.nz;
   bool ok = supported_len(c.nx) && supported_len(c.ny) && supported_len(nzg) && ((c.ny * c.nz) % (2 * NLMAX) == 0);
   if (f.nranks > 1) ok = ok && (nzg == c.nz * f.nranks) && (c.ny % f.nranks == 0);
+  const uint64_t P64 = (c.nx_complex + NLMAX - 1) / NLMAX * NLMAX;
+  ok = ok && (P64 * c.ny * c.nz < (1ull << 32)) && (static_cast<uint64_t>(c.nx) * c.ny * c.nz < (1ull << 32));
   *out = ok ? 1 : 0;
   return KW_OK;
 }
@@ -1247,7 +1276,7 @@ kw_status kw_fused_probe(kw_ctx* ctx, int which, const float* op)
     a.P   = f.P;
     a.ain = a.aout = RowAddr{31u, 0xffffffffu, 0u, 1u, c.ny}; // element k of line (ky = blockIdx.y): row k*ny + ky
     const dim3 grid(f.P / nl_of(c.nz), c.ny, 1);
-#define M(LEN) LAUNCH((k_ypass<LEN, kFwd>), grid, dim3(Geo<LEN>::THREADS), a)
+#define M(LEN) LAUNCH((k_ypass<LEN, kFwd, false, false>), grid, dim3(Geo<LEN>::THREADS), a)
     KW_LEN_SWITCH(c.nz, M)
 #undef M
     return KW_OK;
