@@ -47,8 +47,11 @@ def build_hip(force: bool = False, verbose: bool = False) -> str:
         for s in srcs:
             o = os.path.join(LIB_DIR, os.path.basename(s) + ".o")
             if force or _newer(o, [s] + [d for d in deps if d.endswith(".h")]):
+                extra = os.environ.get("KW_HIPCC_EXTRA", "").split()
+                # -fno-slp-vectorize: packed-f32 pairing buys nothing here (same instruction count, more moves; measured +0.6 %)
                 cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden",
-                       "-I" + INCLUDE, "-I" + CSRC, "-I" + os.path.join(ROCM, "include"), "-c", s, "-o", o]
+                       "-fno-slp-vectorize"] + extra + [
+                    "-I" + INCLUDE, "-I" + CSRC, "-I" + os.path.join(ROCM, "include"), "-c", s, "-o", o]
                 if verbose:
                     cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
                 out = _run(cmd)
