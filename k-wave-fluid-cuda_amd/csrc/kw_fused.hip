@@ -50,14 +50,35 @@ template<int L> struct Geo
   static constexpr int LP   = LP0 + ((16 - LP0 % 32) + 32) % 32;
   static constexpr int ZP   = L + 16;
   static constexpr int LDSX = NL * cmax(LP, ZP);
+  // inter-step twiddles, LDS-resident: T[k][n] = W_L^(k*n), k < R1, n < R2, pitch TP (odd: conflict-free both ways)
+  static constexpr int TP   = R2 + 1;
+  static constexpr int TWN  = R1 * TP;
 };
 
+// Block barrier that orders LDS traffic only.  __syncthreads() also drains every outstanding global load and store
+// (vmcnt(0)) — here all cross-thread communication goes through LDS, and global stores / prefetched loads should stay in
+// flight across the exchange steps.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 // ---- register-level steps -------------------------------------------------------------------------------------------
-template<int L, int DIR> __device__ __forceinline__ void step_a(float2 (&v)[Fac<L>::R1], int n2, const float2* __restrict__ tw)
+// Fill the block's twiddle table from the global one (tw[m] = exp(-2*pi*i*m/L)); the caller's next lds_barrier()
+// publishes it.  Every use below is "one VGPR base + compile-time offset", so twiddles cost neither address registers
+// nor global-memory requests.
+template<int L> __device__ __forceinline__ void load_twiddles(float2* twl, const float2* __restrict__ tw)
+{
+  using G = Geo<L>;
+  for (int e = threadIdx.x; e < G::R1 * G::R2; e += G::THREADS)
+  {
+    const int k = e / G::R2, n = e - k * G::R2;
+    twl[k * G::TP + n] = tw[k * n];
+  }
+}
+
+template<int L, int DIR> __device__ __forceinline__ void step_a(float2 (&v)[Fac<L>::R1], int n2, const float2* twl)
 {
   Dft<Fac<L>::R1, DIR>::run(v);
 #pragma unroll
-  for (int k1 = 1; k1 < Fac<L>::R1; k1++) v[k1] = apply_tw<DIR>(v[k1], tw[n2 * k1]);
+  for (int k1 = 1; k1 < Fac<L>::R1; k1++) v[k1] = apply_tw<DIR>(v[k1], twl[k1 * Geo<L>::TP + n2]);
 }
 
 // =====================================================================================================================
@@ -95,34 +116,41 @@ __global__ __launch_bounds__(Geo<L>::THREADS) void k_ypass(PassArgs a)
   using G = Geo<L>;
   constexpr int R1 = G::R1, R2 = G::R2;
   __shared__ float2 lds[G::LDSB];
+  __shared__ float2 twl[G::TWN];
+  load_twiddles<L>(twl, a.tw);
   const float2* __restrict__ Sin = a.in[blockIdx.z];
   float2* __restrict__ Sout      = a.out[blockIdx.z];
   const int      c     = threadIdx.x % G::NL;
   const int      j     = threadIdx.x / G::NL;
   const uint32_t kx    = blockIdx.x * G::NL + c;
   const bool     valid = kx < a.nxc;
+  const uint32_t kxl   = min(kx, a.nxc - 1u); // pad lanes re-read the last column (no branch, no extra sector); never stored
   const uint32_t z     = blockIdx.y;
+  float2 v[R1];
   if (j < R2)
   {
-    float2 v[R1];
     if (PIN)
     {
 #pragma unroll
       for (int n1 = 0; n1 < R1; n1++)
-        v[n1] = valid ? Sin[a.ain.row(z, n1 * R2 + j) * a.P + kx] : make_float2(0.f, 0.f);
+        v[n1] = Sin[a.ain.row(z, n1 * R2 + j) * a.P + kxl];
     }
     else
     {
-      const uint32_t b = (z * a.ain.zmul + j * a.ain.estride) * a.P + kx; // estride = 1 (y lines) or ny (z probe)
+      const uint32_t b = (z * a.ain.zmul + j * a.ain.estride) * a.P + kxl; // estride = 1 (y lines) or ny (z probe)
       const uint32_t step = R2 * a.ain.estride * a.P;
 #pragma unroll
-      for (int n1 = 0; n1 < R1; n1++) v[n1] = valid ? Sin[b + n1 * step] : make_float2(0.f, 0.f);
+      for (int n1 = 0; n1 < R1; n1++) v[n1] = Sin[b + n1 * step];
     }
-    step_a<L, DIR>(v, j, a.tw);
+  }
+  lds_barrier(); // twiddle table visible (the line loads stay in flight across it)
+  if (j < R2)
+  {
+    step_a<L, DIR>(v, j, twl);
 #pragma unroll
     for (int k1 = 0; k1 < R1; k1++) lds[k1 * G::SF + j * G::NL + c] = v[k1];
   }
-  __syncthreads();
+  lds_barrier();
   if (j < R1)
   {
     float2 w[R2];
@@ -169,7 +197,7 @@ struct ZArgs
 // thread (c,q1) holds x[q1 + R2*q2], q2 < R1 — returned in v
 template<int L>
 __device__ __forceinline__ void inverse_from_regs(float2 (&w)[Fac<L>::R2], float2 (&v)[Fac<L>::R1], float2* lds, int c,
-                                                  int j, const float2* __restrict__ tw)
+                                                  int j, const float2* twl)
 {
   using G = Geo<L>;
   constexpr int R1 = G::R1, R2 = G::R2;
@@ -179,11 +207,11 @@ __device__ __forceinline__ void inverse_from_regs(float2 (&w)[Fac<L>::R2], float
 #pragma unroll
     for (int q1 = 0; q1 < R2; q1++)
     {
-      const float2 t = (q1 == 0) ? w[0] : apply_tw<kInv>(w[q1], tw[j * q1]);
+      const float2 t = (q1 == 0) ? w[0] : apply_tw<kInv>(w[q1], twl[j * G::TP + q1]);
       lds[q1 * G::SI + j * G::NL + c] = t;
     }
   }
-  __syncthreads();
+  lds_barrier();
   if (j < R2)
   {
 #pragma unroll
@@ -197,6 +225,8 @@ template<int L, int MODE> __global__ __launch_bounds__(Geo<L>::THREADS) void k_z
   using G = Geo<L>;
   constexpr int R1 = G::R1, R2 = G::R2;
   __shared__ float2 lds[G::LDSB];
+  __shared__ float2 twl[G::TWN];
+  load_twiddles<L>(twl, a.tw);
   const int      c      = threadIdx.x % G::NL;
   const int      j      = threadIdx.x / G::NL;
   const uint32_t kx     = blockIdx.x * G::NL + c;
@@ -204,20 +234,28 @@ template<int L, int MODE> __global__ __launch_bounds__(Geo<L>::THREADS) void k_z
   const bool     valid  = kx < a.nxc;
   const uint32_t zstr   = a.ny * a.P;
   const uint32_t base   = ky * a.P + kx;
+  const uint32_t kxl    = min(kx, a.nxc - 1u); // pad lanes re-read the last column; their results are never stored
+  const uint32_t basel  = ky * a.P + kxl;
   const uint32_t arr    = (MODE == Z_VGRAD || MODE == Z_ABSORB) ? blockIdx.z + a.arr0 : 0;
   const float2* __restrict__ in = a.in[arr];
 
-  if (j < R2)
   {
     float2 v[R1];
+    if (j < R2)
+    {
 #pragma unroll
-    for (int n1 = 0; n1 < R1; n1++)
-      v[n1] = valid ? in[base + static_cast<uint32_t>(n1 * R2 + j) * zstr] : make_float2(0.f, 0.f);
-    step_a<L, kFwd>(v, j, a.tw);
+      for (int n1 = 0; n1 < R1; n1++)
+        v[n1] = in[basel + static_cast<uint32_t>(n1 * R2 + j) * zstr];
+    }
+    lds_barrier(); // twiddle table visible (the line loads stay in flight across it)
+    if (j < R2)
+    {
+      step_a<L, kFwd>(v, j, twl);
 #pragma unroll
-    for (int k1 = 0; k1 < R1; k1++) lds[k1 * G::SF + j * G::NL + c] = v[k1];
+      for (int k1 = 0; k1 < R1; k1++) lds[k1 * G::SF + j * G::NL + c] = v[k1];
+    }
   }
-  __syncthreads();
+  lds_barrier();
   float2 X[R2];
   if (j < R1)
   {
@@ -225,17 +263,24 @@ template<int L, int MODE> __global__ __launch_bounds__(Geo<L>::THREADS) void k_z
     for (int n2 = 0; n2 < R2; n2++) X[n2] = lds[j * G::SF + n2 * G::NL + c];
     Dft<R2, kFwd>::run(X);
   }
-  __syncthreads(); // forward exchange buffer is free again
+  lds_barrier(); // forward exchange buffer is free again
 
   constexpr int NOUT = (MODE == Z_PGRAD) ? 3 : 1;
-  // spectral operators for the elements this thread holds: kz = j + R1*k2
-  float kap[R2];
+  // spectral operator for the elements this thread holds (kz = j + R1*k2), folded into X once:
+  //   Z_PGRAD  SolverCudaKernels.cu:1149-1155  e = X*kappa;            out_d = e (x) dd_d_pos
+  //   Z_VGRAD  :1220-1236                      e = X*(kappa*divider);  out   = e (x) dd_neg of this array's own axis
+  //   Z_ABSORB :1817-1818                      out = X*nabla
+  //   Z_SOURCE :742-744                        out = X*(sourceKappa*divider)
   if (j < R1)
   {
     const float* __restrict__ op = a.op[(MODE == Z_ABSORB) ? arr : 0];
 #pragma unroll
     for (int k2 = 0; k2 < R2; k2++)
-      kap[k2] = valid ? op[base + static_cast<uint32_t>(j + R1 * k2) * zstr] : 0.f;
+    {
+      float s = op[basel + static_cast<uint32_t>(j + R1 * k2) * zstr];
+      if (MODE == Z_VGRAD || MODE == Z_SOURCE) s *= a.divider;
+      X[k2] = make_float2(X[k2].x * s, X[k2].y * s);
+    }
   }
 #pragma unroll 1
   for (int o = 0; o < NOUT; o++)
@@ -243,53 +288,30 @@ template<int L, int MODE> __global__ __launch_bounds__(Geo<L>::THREADS) void k_z
     float2 w[R2];
     if (j < R1)
     {
-      if (MODE == Z_PGRAD)
-      { // SolverCudaKernels.cu:1149-1155: e = X*kappa; out = e (x) dd{x,y,z}_pos
-        const float2 dxy = (o == 0) ? (valid ? a.dd[0][kx] : make_float2(0.f, 0.f)) : a.dd[1][ky + a.ky0];
+      if (MODE == Z_PGRAD || MODE == Z_VGRAD)
+      {
+        const uint32_t axis = (MODE == Z_PGRAD) ? o : arr;
+        const float2   dxy  = (axis == 0) ? a.dd[0][kxl] : a.dd[1][ky + a.ky0];
 #pragma unroll
-        for (int k2 = 0; k2 < R2; k2++)
-        {
-          const float2 e = make_float2(X[k2].x * kap[k2], X[k2].y * kap[k2]);
-          const float2 d = (o == 2) ? a.dd[2][j + R1 * k2] : dxy;
-          w[k2]          = cmulf(e, d);
-        }
-      }
-      else if (MODE == Z_VGRAD)
-      { // :1220-1236: (X * (kappa*divider)) (x) dd_neg of this array's own axis
-        const float2 dxy = (arr == 0) ? (valid ? a.dd[0][kx] : make_float2(0.f, 0.f)) : a.dd[1][ky + a.ky0];
-#pragma unroll
-        for (int k2 = 0; k2 < R2; k2++)
-        {
-          const float  ek = kap[k2] * a.divider;
-          const float2 e  = make_float2(X[k2].x * ek, X[k2].y * ek);
-          const float2 d  = (arr == 2) ? a.dd[2][j + R1 * k2] : dxy;
-          w[k2]           = cmulf(e, d);
-        }
-      }
-      else if (MODE == Z_ABSORB)
-      { // :1817-1818: X *= nabla
-#pragma unroll
-        for (int k2 = 0; k2 < R2; k2++) w[k2] = make_float2(X[k2].x * kap[k2], X[k2].y * kap[k2]);
+        for (int k2 = 0; k2 < R2; k2++) w[k2] = cmulf(X[k2], (axis == 2) ? a.dd[2][j + R1 * k2] : dxy);
       }
       else
-      { // Z_SOURCE :742-744: S *= sourceKappa * divider
+      {
 #pragma unroll
-        for (int k2 = 0; k2 < R2; k2++)
-        {
-          const float s = kap[k2] * a.divider;
-          w[k2]         = make_float2(X[k2].x * s, X[k2].y * s);
-        }
+        for (int k2 = 0; k2 < R2; k2++) w[k2] = X[k2];
       }
     }
     float2 v[R1];
-    inverse_from_regs<L>(w, v, lds, c, j, a.tw);
+    inverse_from_regs<L>(w, v, lds, c, j, twl);
     if (j < R2 && valid)
     {
       float2* __restrict__ out = a.out[(MODE == Z_PGRAD) ? o : arr];
+      uint32_t ob = base + static_cast<uint32_t>(j) * zstr;
+      if (NOUT > 1) asm volatile("" : "+v"(ob)); // recomputed per output: 16 hoisted 64-bit addresses cost an occupancy step
 #pragma unroll
-      for (int q2 = 0; q2 < R1; q2++) out[base + static_cast<uint32_t>(j + R2 * q2) * zstr] = v[q2];
+      for (int q2 = 0; q2 < R1; q2++) out[ob + static_cast<uint32_t>(R2 * q2) * zstr] = v[q2];
     }
-    if (o + 1 < NOUT) __syncthreads(); // exchange buffer reused by the next output
+    if (o + 1 < NOUT) lds_barrier(); // exchange buffer reused by the next output
   }
 }
 
@@ -309,7 +331,7 @@ struct XfwdArgs
 // exchange buffer must be free on entry and is free again on exit (trailing barrier).
 template<int L>
 __device__ __forceinline__ void xfwd_tail(float2 (&v)[Fac<L>::R1], float2* lds, int c, int f,
-                                          const float2* __restrict__ tw, float2* __restrict__ out, uint32_t P)
+                                          const float2* tw, float2* __restrict__ out, uint32_t P)
 {
   using G = Geo<L>;
   constexpr int R1 = G::R1, R2 = G::R2, HALF = L / 2 + 1;
@@ -319,7 +341,7 @@ __device__ __forceinline__ void xfwd_tail(float2 (&v)[Fac<L>::R1], float2* lds, 
 #pragma unroll
     for (int k1 = 0; k1 < R1; k1++) lds[c * G::LP + k1 * (R2 + 1) + f] = v[k1];
   }
-  __syncthreads();
+  lds_barrier();
   float2 w[R2];
   if (f < R1)
   {
@@ -327,13 +349,13 @@ __device__ __forceinline__ void xfwd_tail(float2 (&v)[Fac<L>::R1], float2* lds, 
     for (int n2 = 0; n2 < R2; n2++) w[n2] = lds[c * G::LP + f * (R2 + 1) + n2];
     Dft<R2, kFwd>::run(w);
   }
-  __syncthreads();
+  lds_barrier();
   if (f < R1)
   {
 #pragma unroll
     for (int k2 = 0; k2 < R2; k2++) lds[c * G::ZP + f + R1 * k2] = w[k2];
   }
-  __syncthreads();
+  lds_barrier();
   const uint32_t tile_row0 = blockIdx.x * G::NL * 2;
   for (int e = threadIdx.x; e < G::NL * HALF; e += G::THREADS)
   {
@@ -347,7 +369,7 @@ __device__ __forceinline__ void xfwd_tail(float2 (&v)[Fac<L>::R1], float2* lds, 
     out[r * P + k]       = xa;
     out[(r + 1) * P + k] = xb;
   }
-  __syncthreads();
+  lds_barrier();
 }
 
 template<int L> __global__ __launch_bounds__(Geo<L>::THREADS) void k_xfwd(XfwdArgs a)
@@ -355,6 +377,8 @@ template<int L> __global__ __launch_bounds__(Geo<L>::THREADS) void k_xfwd(XfwdAr
   using G = Geo<L>;
   constexpr int R1 = G::R1, R2 = G::R2;
   __shared__ float2 lds[G::LDSX];
+  __shared__ float2 twl[G::TWN];
+  load_twiddles<L>(twl, a.tw);
   const int    f   = threadIdx.x % G::TPL;
   const int    c   = threadIdx.x / G::TPL;
   const float* __restrict__ in = a.in[blockIdx.y];
@@ -367,7 +391,8 @@ template<int L> __global__ __launch_bounds__(Geo<L>::THREADS) void k_xfwd(XfwdAr
 #pragma unroll
     for (int n1 = 0; n1 < R1; n1++) v[n1] = make_float2(ra[n1 * R2 + f], rb[n1 * R2 + f]);
   }
-  xfwd_tail<L>(v, lds, c, f, a.tw, a.out[blockIdx.y], a.P);
+  lds_barrier(); // twiddle table visible
+  xfwd_tail<L>(v, lds, c, f, twl, a.out[blockIdx.y], a.P);
 }
 
 // =====================================================================================================================
@@ -398,7 +423,7 @@ struct XinvArgs
 // standalone inverse of one array for this block's 32 rows; thread (c, f<R1) ends with x[f + R1*k2] of rows (2c, 2c+1)
 template<int L>
 __device__ __forceinline__ void xinv_lines(const float2* __restrict__ src, uint32_t P, float2* lds, int c, int f,
-                                           const float2* __restrict__ tw, float2 (&w)[Fac<L>::R2])
+                                           const float2* tw, float2 (&w)[Fac<L>::R2])
 {
   using G = Geo<L>;
   constexpr int R1 = G::R1, R2 = G::R2, HALF = L / 2 + 1;
@@ -414,28 +439,28 @@ __device__ __forceinline__ void xinv_lines(const float2* __restrict__ src, uint3
     lds[cc * G::ZP + k] = make_float2(A.x - B.y, A.y + B.x);
     if (k != 0 && k != L / 2) lds[cc * G::ZP + L - k] = make_float2(A.x + B.y, B.x - A.y);
   }
-  __syncthreads();
+  lds_barrier();
   float2 v[R1];
   if (f < R2)
   {
 #pragma unroll
     for (int n1 = 0; n1 < R1; n1++) v[n1] = lds[c * G::ZP + n1 * R2 + f];
   }
-  __syncthreads();
+  lds_barrier();
   if (f < R2)
   {
     step_a<L, kInv>(v, f, tw);
 #pragma unroll
     for (int k1 = 0; k1 < R1; k1++) lds[c * G::LP + k1 * (R2 + 1) + f] = v[k1];
   }
-  __syncthreads();
+  lds_barrier();
   if (f < R1)
   {
 #pragma unroll
     for (int n2 = 0; n2 < R2; n2++) w[n2] = lds[c * G::LP + f * (R2 + 1) + n2];
     Dft<R2, kInv>::run(w);
   }
-  __syncthreads();
+  lds_barrier();
 }
 
 __device__ __forceinline__ float  f4get(const float4& v, int k) { return k == 0 ? v.x : k == 1 ? v.y : k == 2 ? v.z : v.w; }
@@ -459,6 +484,8 @@ template<int L, int EPI, bool CHAIN> __global__ __launch_bounds__(Geo<L>::THREAD
   constexpr int NQ  = (2 * G::NL * Q4) / G::THREADS;  // float4 per thread
   static_assert((2 * G::NL * Q4) % G::THREADS == 0, "tile must divide evenly");
   __shared__ float2 lds[G::LDSX];
+  __shared__ float2 twl[G::TWN];
+  load_twiddles<L>(twl, a.tw); // published by the first barrier of xinv_lines
   float* ldsr = reinterpret_cast<float*>(lds);
   const int f = threadIdx.x % G::TPL;
   const int c = threadIdx.x / G::TPL;
@@ -471,7 +498,7 @@ template<int L, int EPI, bool CHAIN> __global__ __launch_bounds__(Geo<L>::THREAD
   for (int i = 0; i < NA; i++)
   {
     float2 w[R2];
-    xinv_lines<L>(a.in[(NA == 1) ? comp : i], a.P, lds, c, f, a.tw, w); // ends with a barrier
+    xinv_lines<L>(a.in[(NA == 1) ? comp : i], a.P, lds, c, f, twl, w); // ends with a barrier
     if (f < R1)
     {
 #pragma unroll
@@ -481,7 +508,7 @@ template<int L, int EPI, bool CHAIN> __global__ __launch_bounds__(Geo<L>::THREAD
         ldsr[(2 * c + 1) * RP + f + R1 * k2] = w[k2].y;
       }
     }
-    __syncthreads();
+    lds_barrier();
 #pragma unroll
     for (int q = 0; q < NQ; q++)
     {
@@ -490,7 +517,7 @@ template<int L, int EPI, bool CHAIN> __global__ __launch_bounds__(Geo<L>::THREAD
       const int x4  = e - row * Q4;
       res[i][q]     = *reinterpret_cast<const float4*>(&ldsr[row * RP + 4 * x4]);
     }
-    __syncthreads();
+    lds_barrier();
   }
 
   const kw_constants& k = a.c;
@@ -673,7 +700,7 @@ template<int L, int EPI, bool CHAIN> __global__ __launch_bounds__(Geo<L>::THREAD
         const int x4  = e - row * Q4;
         *reinterpret_cast<float4*>(&ldsr[row * RP + 4 * x4]) = fw[jf][q];
       }
-      __syncthreads();
+      lds_barrier();
       float2 v[R1c];
       if (f < R2c)
       {
@@ -681,8 +708,8 @@ template<int L, int EPI, bool CHAIN> __global__ __launch_bounds__(Geo<L>::THREAD
         for (int n1 = 0; n1 < R1c; n1++)
           v[n1] = make_float2(ldsr[(2 * c) * RP + n1 * R2c + f], ldsr[(2 * c + 1) * RP + n1 * R2c + f]);
       }
-      __syncthreads(); // the real tile aliases the exchange buffer
-      xfwd_tail<L>(v, lds, c, f, a.tw, a.fout[(NA == 1) ? comp : jf], a.P);
+      lds_barrier(); // the real tile aliases the exchange buffer
+      xfwd_tail<L>(v, lds, c, f, twl, a.fout[(NA == 1) ? comp : jf], a.P);
     }
   }
 }
