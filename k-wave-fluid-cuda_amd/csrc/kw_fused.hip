@@ -55,6 +55,10 @@ template<int L> struct Geo
   static constexpr int TWN  = R1 * TP;
 };
 
+// "thread t takes part in a step of R threads per line": compile-time true when every thread of a line does (R == TPL),
+// so that the common L = 256 kernels carry no divergent regions (and no phi-separated register sets) at all.
+#define ACT(R, t) ((R) == G::TPL || (t) < (R))
+
 // Block barrier that orders LDS traffic only.  __syncthreads() also drains every outstanding global load and store
 // (vmcnt(0)) — here all cross-thread communication goes through LDS, and global stores / prefetched loads should stay in
 // flight across the exchange steps.
@@ -127,7 +131,7 @@ __global__ __launch_bounds__(Geo<L>::THREADS) void k_ypass(PassArgs a)
   const uint32_t kxl   = min(kx, a.nxc - 1u); // pad lanes re-read the last column (no branch, no extra sector); never stored
   const uint32_t z     = blockIdx.y;
   float2 v[R1];
-  if (j < R2)
+  if (ACT(R2, j))
   {
     if (PIN)
     {
@@ -144,14 +148,14 @@ __global__ __launch_bounds__(Geo<L>::THREADS) void k_ypass(PassArgs a)
     }
   }
   lds_barrier(); // twiddle table visible (the line loads stay in flight across it)
-  if (j < R2)
+  if (ACT(R2, j))
   {
     step_a<L, DIR>(v, j, twl);
 #pragma unroll
     for (int k1 = 0; k1 < R1; k1++) lds[k1 * G::SF + j * G::NL + c] = v[k1];
   }
   lds_barrier();
-  if (j < R1)
+  if (ACT(R1, j))
   {
     float2 w[R2];
 #pragma unroll
@@ -189,7 +193,8 @@ struct ZArgs
   const float2* tw;
   float         divider;
   uint32_t      nxc, P, ny, nz;
-  uint32_t      arr0; // index of the first array of this launch (per-array launches)
+  uint32_t      arr0; // first array of this launch
+  uint32_t      narr; // arrays processed back to back by each block (VGRAD / ABSORB)
   uint32_t      ky0;  // global ky of local row 0 (slab mode: rank * ny/nranks); ny above = number of LOCAL rows
 };
 
@@ -201,7 +206,7 @@ __device__ __forceinline__ void inverse_from_regs(float2 (&w)[Fac<L>::R2], float
 {
   using G = Geo<L>;
   constexpr int R1 = G::R1, R2 = G::R2;
-  if (j < R1)
+  if (ACT(R1, j))
   {
     Dft<R2, kInv>::run(w);
 #pragma unroll
@@ -212,7 +217,7 @@ __device__ __forceinline__ void inverse_from_regs(float2 (&w)[Fac<L>::R2], float
     }
   }
   lds_barrier();
-  if (j < R2)
+  if (ACT(R2, j))
   {
 #pragma unroll
     for (int k1 = 0; k1 < R1; k1++) v[k1] = lds[j * G::SI + k1 * G::NL + c];
@@ -220,6 +225,9 @@ __device__ __forceinline__ void inverse_from_regs(float2 (&w)[Fac<L>::R2], float
   }
 }
 
+// One block owns the z-lines of tile (ky = blockIdx.y, kx tile = blockIdx.x) of `narr` arrays (VGRAD: the three velocity
+// spectra, ABSORB: the two pressure terms), processed back to back: the lines of array i+1 are in flight while array i
+// is transformed, and kappa is fetched once for all three velocity components.  PGRAD has one input and three outputs.
 template<int L, int MODE> __global__ __launch_bounds__(Geo<L>::THREADS) void k_zfused(ZArgs a)
 {
   using G = Geo<L>;
@@ -236,82 +244,117 @@ template<int L, int MODE> __global__ __launch_bounds__(Geo<L>::THREADS) void k_z
   const uint32_t base   = ky * a.P + kx;
   const uint32_t kxl    = min(kx, a.nxc - 1u); // pad lanes re-read the last column; their results are never stored
   const uint32_t basel  = ky * a.P + kxl;
-  const uint32_t arr    = (MODE == Z_VGRAD || MODE == Z_ABSORB) ? blockIdx.z + a.arr0 : 0;
-  const float2* __restrict__ in = a.in[arr];
+  constexpr bool MULTI  = (MODE == Z_VGRAD || MODE == Z_ABSORB);
+  const uint32_t arr0   = MULTI ? a.arr0 : 0;
+  const uint32_t narr   = MULTI ? a.narr : 1;
+  constexpr int  NOUT   = (MODE == Z_PGRAD) ? 3 : 1;
 
+  float2 v[R1];
+  if (ACT(R2, j))
   {
-    float2 v[R1];
-    if (j < R2)
-    {
+    const float2* __restrict__ in = a.in[arr0];
 #pragma unroll
-      for (int n1 = 0; n1 < R1; n1++)
-        v[n1] = in[basel + static_cast<uint32_t>(n1 * R2 + j) * zstr];
-    }
-    lds_barrier(); // twiddle table visible (the line loads stay in flight across it)
-    if (j < R2)
+    for (int n1 = 0; n1 < R1; n1++) v[n1] = in[basel + static_cast<uint32_t>(n1 * R2 + j) * zstr];
+  }
+  // spectral operator of the elements this thread will hold after the forward transform (kz = j + R1*k2)
+  float kap[R2];
+  if (ACT(R1, j))
+  {
+    const float* __restrict__ op = a.op[(MODE == Z_ABSORB) ? arr0 : 0];
+#pragma unroll
+    for (int k2 = 0; k2 < R2; k2++) kap[k2] = op[basel + static_cast<uint32_t>(j + R1 * k2) * zstr];
+  }
+  lds_barrier(); // twiddle table visible (the loads above stay in flight across it)
+
+#pragma unroll 1
+  for (uint32_t ia = 0; ia < narr; ia++)
+  {
+    const uint32_t arr = arr0 + ia;
+    if (ACT(R2, j))
     {
       step_a<L, kFwd>(v, j, twl);
 #pragma unroll
       for (int k1 = 0; k1 < R1; k1++) lds[k1 * G::SF + j * G::NL + c] = v[k1];
     }
-  }
-  lds_barrier();
-  float2 X[R2];
-  if (j < R1)
-  {
+    // next array's lines: in flight during this array's two transforms
+    if (MULTI && ia + 1 < narr && ACT(R2, j))
+    {
+      const float2* __restrict__ in = a.in[arr + 1];
+      uint32_t lb = basel + static_cast<uint32_t>(j) * zstr;
+      asm volatile("" : "+v"(lb)); // per-iteration address arithmetic instead of 16 loop-invariant address registers
 #pragma unroll
-    for (int n2 = 0; n2 < R2; n2++) X[n2] = lds[j * G::SF + n2 * G::NL + c];
-    Dft<R2, kFwd>::run(X);
-  }
-  lds_barrier(); // forward exchange buffer is free again
+      for (int n1 = 0; n1 < R1; n1++) v[n1] = in[lb + static_cast<uint32_t>(n1 * R2) * zstr];
+    }
+    lds_barrier();
+    float2 X[R2];
+    if (ACT(R1, j))
+    {
+#pragma unroll
+      for (int n2 = 0; n2 < R2; n2++) X[n2] = lds[j * G::SF + n2 * G::NL + c];
+      Dft<R2, kFwd>::run(X);
+      //   Z_PGRAD  SolverCudaKernels.cu:1149-1155  e = X*kappa;            out_d = e (x) dd_d_pos
+      //   Z_VGRAD  :1220-1236                      e = X*(kappa*divider);  out   = e (x) dd_neg of this array's own axis
+      //   Z_ABSORB :1817-1818                      out = X*nabla
+      //   Z_SOURCE :742-744                        out = X*(sourceKappa*divider)
+#pragma unroll
+      for (int k2 = 0; k2 < R2; k2++)
+      {
+        float sc = kap[k2];
+        if (MODE == Z_VGRAD || MODE == Z_SOURCE) sc *= a.divider;
+        X[k2] = make_float2(X[k2].x * sc, X[k2].y * sc);
+      }
+      if (MODE == Z_ABSORB && ia + 1 < narr)
+      {
+        const float* __restrict__ op = a.op[arr + 1];
+        uint32_t lb = basel + static_cast<uint32_t>(j) * zstr;
+        asm volatile("" : "+v"(lb));
+#pragma unroll
+        for (int k2 = 0; k2 < R2; k2++) kap[k2] = op[lb + static_cast<uint32_t>(R1 * k2) * zstr];
+      }
+    }
+    lds_barrier(); // forward exchange buffer is free again
 
-  constexpr int NOUT = (MODE == Z_PGRAD) ? 3 : 1;
-  // spectral operator for the elements this thread holds (kz = j + R1*k2), folded into X once:
-  //   Z_PGRAD  SolverCudaKernels.cu:1149-1155  e = X*kappa;            out_d = e (x) dd_d_pos
-  //   Z_VGRAD  :1220-1236                      e = X*(kappa*divider);  out   = e (x) dd_neg of this array's own axis
-  //   Z_ABSORB :1817-1818                      out = X*nabla
-  //   Z_SOURCE :742-744                        out = X*(sourceKappa*divider)
-  if (j < R1)
-  {
-    const float* __restrict__ op = a.op[(MODE == Z_ABSORB) ? arr : 0];
-#pragma unroll
-    for (int k2 = 0; k2 < R2; k2++)
-    {
-      float s = op[basel + static_cast<uint32_t>(j + R1 * k2) * zstr];
-      if (MODE == Z_VGRAD || MODE == Z_SOURCE) s *= a.divider;
-      X[k2] = make_float2(X[k2].x * s, X[k2].y * s);
-    }
-  }
 #pragma unroll 1
-  for (int o = 0; o < NOUT; o++)
-  {
-    float2 w[R2];
-    if (j < R1)
+    for (int o = 0; o < NOUT; o++)
     {
-      if (MODE == Z_PGRAD || MODE == Z_VGRAD)
+      float2 w[R2];
+      if (ACT(R1, j))
       {
-        const uint32_t axis = (MODE == Z_PGRAD) ? o : arr;
-        const float2   dxy  = (axis == 0) ? a.dd[0][kxl] : a.dd[1][ky + a.ky0];
+        if (MODE == Z_PGRAD || MODE == Z_VGRAD)
+        {
+          const uint32_t axis = (MODE == Z_PGRAD) ? o : arr;
+          if (axis == 2)
+          {
+            uint32_t jz = j;
+            asm volatile("" : "+v"(jz)); // keeps the 16 ddz loads inside this pass instead of hoisted registers
 #pragma unroll
-        for (int k2 = 0; k2 < R2; k2++) w[k2] = cmulf(X[k2], (axis == 2) ? a.dd[2][j + R1 * k2] : dxy);
+            for (int k2 = 0; k2 < R2; k2++) w[k2] = cmulf(X[k2], a.dd[2][jz + R1 * k2]);
+          }
+          else
+          {
+            const float2 dxy = (axis == 0) ? a.dd[0][kxl] : a.dd[1][ky + a.ky0];
+#pragma unroll
+            for (int k2 = 0; k2 < R2; k2++) w[k2] = cmulf(X[k2], dxy);
+          }
+        }
+        else
+        {
+#pragma unroll
+          for (int k2 = 0; k2 < R2; k2++) w[k2] = X[k2];
+        }
       }
-      else
+      float2 r[R1];
+      inverse_from_regs<L>(w, r, lds, c, j, twl);
+      if (ACT(R2, j) && valid)
       {
+        float2* __restrict__ out = a.out[(MODE == Z_PGRAD) ? o : arr];
+        uint32_t ob = base + static_cast<uint32_t>(j) * zstr;
+        asm volatile("" : "+v"(ob)); // recomputed per output: 16 hoisted 64-bit addresses cost an occupancy step
 #pragma unroll
-        for (int k2 = 0; k2 < R2; k2++) w[k2] = X[k2];
+        for (int q2 = 0; q2 < R1; q2++) out[ob + static_cast<uint32_t>(R2 * q2) * zstr] = r[q2];
       }
+      if (o + 1 < NOUT || ia + 1 < narr) lds_barrier(); // exchange buffer reused by the next output / array
     }
-    float2 v[R1];
-    inverse_from_regs<L>(w, v, lds, c, j, twl);
-    if (j < R2 && valid)
-    {
-      float2* __restrict__ out = a.out[(MODE == Z_PGRAD) ? o : arr];
-      uint32_t ob = base + static_cast<uint32_t>(j) * zstr;
-      if (NOUT > 1) asm volatile("" : "+v"(ob)); // recomputed per output: 16 hoisted 64-bit addresses cost an occupancy step
-#pragma unroll
-      for (int q2 = 0; q2 < R1; q2++) out[ob + static_cast<uint32_t>(R2 * q2) * zstr] = v[q2];
-    }
-    if (o + 1 < NOUT) lds_barrier(); // exchange buffer reused by the next output
   }
 }
 
@@ -335,7 +378,7 @@ __device__ __forceinline__ void xfwd_tail(float2 (&v)[Fac<L>::R1], float2* lds, 
 {
   using G = Geo<L>;
   constexpr int R1 = G::R1, R2 = G::R2, HALF = L / 2 + 1;
-  if (f < R2)
+  if (ACT(R2, f))
   {
     step_a<L, kFwd>(v, f, tw);
 #pragma unroll
@@ -343,14 +386,14 @@ __device__ __forceinline__ void xfwd_tail(float2 (&v)[Fac<L>::R1], float2* lds, 
   }
   lds_barrier();
   float2 w[R2];
-  if (f < R1)
+  if (ACT(R1, f))
   {
 #pragma unroll
     for (int n2 = 0; n2 < R2; n2++) w[n2] = lds[c * G::LP + f * (R2 + 1) + n2];
     Dft<R2, kFwd>::run(w);
   }
   lds_barrier();
-  if (f < R1)
+  if (ACT(R1, f))
   {
 #pragma unroll
     for (int k2 = 0; k2 < R2; k2++) lds[c * G::ZP + f + R1 * k2] = w[k2];
@@ -384,7 +427,7 @@ template<int L> __global__ __launch_bounds__(Geo<L>::THREADS) void k_xfwd(XfwdAr
   const float* __restrict__ in = a.in[blockIdx.y];
   const uint32_t row0 = (blockIdx.x * G::NL + c) * 2;
   float2 v[R1];
-  if (f < R2)
+  if (ACT(R2, f))
   {
     const float* __restrict__ ra = in + row0 * L;
     const float* __restrict__ rb = ra + L;
@@ -441,20 +484,20 @@ __device__ __forceinline__ void xinv_lines(const float2* __restrict__ src, uint3
   }
   lds_barrier();
   float2 v[R1];
-  if (f < R2)
+  if (ACT(R2, f))
   {
 #pragma unroll
     for (int n1 = 0; n1 < R1; n1++) v[n1] = lds[c * G::ZP + n1 * R2 + f];
   }
   lds_barrier();
-  if (f < R2)
+  if (ACT(R2, f))
   {
     step_a<L, kInv>(v, f, tw);
 #pragma unroll
     for (int k1 = 0; k1 < R1; k1++) lds[c * G::LP + k1 * (R2 + 1) + f] = v[k1];
   }
   lds_barrier();
-  if (f < R1)
+  if (ACT(R1, f))
   {
 #pragma unroll
     for (int n2 = 0; n2 < R2; n2++) w[n2] = lds[c * G::LP + f * (R2 + 1) + n2];
@@ -499,7 +542,7 @@ template<int L, int EPI, bool CHAIN> __global__ __launch_bounds__(Geo<L>::THREAD
   {
     float2 w[R2];
     xinv_lines<L>(a.in[(NA == 1) ? comp : i], a.P, lds, c, f, twl, w); // ends with a barrier
-    if (f < R1)
+    if (ACT(R1, f))
     {
 #pragma unroll
       for (int k2 = 0; k2 < R2; k2++)
@@ -702,7 +745,7 @@ template<int L, int EPI, bool CHAIN> __global__ __launch_bounds__(Geo<L>::THREAD
       }
       lds_barrier();
       float2 v[R1c];
-      if (f < R2c)
+      if (ACT(R2c, f))
       {
 #pragma unroll
         for (int n1 = 0; n1 < R1c; n1++)
@@ -805,7 +848,8 @@ template<int MODE> kw_status launch_zfused(kw_ctx* ctx, int narr, ZArgs a)
   a.ny      = f.nyl;
   a.nz      = f.nz_global;
   a.ky0     = f.rank * f.nyl;
-  const dim3 grid(f.P / nl_of(f.nz_global), f.nyl, narr);
+  a.narr    = narr;
+  const dim3 grid(f.P / nl_of(f.nz_global), f.nyl, 1);
 #define M(LEN) LAUNCH((k_zfused<LEN, MODE>), grid, dim3(Geo<LEN>::THREADS), a)
   KW_LEN_SWITCH(f.nz_global, M)
 #undef M
