@@ -109,6 +109,7 @@ struct PassArgs
   float2*       out[3];
   const float2* tw;
   uint32_t      nxc, P;
+  uint32_t      narr; // arrays per block (grid.z * narr arrays in the launch)
   RowAddr       ain, aout;
 };
 
@@ -122,60 +123,69 @@ __global__ __launch_bounds__(Geo<L>::THREADS) void k_ypass(PassArgs a)
   __shared__ float2 lds[G::LDSB];
   __shared__ float2 twl[G::TWN];
   load_twiddles<L>(twl, a.tw);
-  const float2* __restrict__ Sin = a.in[blockIdx.z];
-  float2* __restrict__ Sout      = a.out[blockIdx.z];
   const int      c     = threadIdx.x % G::NL;
   const int      j     = threadIdx.x / G::NL;
   const uint32_t kx    = blockIdx.x * G::NL + c;
   const bool     valid = kx < a.nxc;
   const uint32_t kxl   = min(kx, a.nxc - 1u); // pad lanes re-read the last column (no branch, no extra sector); never stored
   const uint32_t z     = blockIdx.y;
-  float2 v[R1];
-  if (ACT(R2, j))
-  {
+  const uint32_t arr0  = blockIdx.z * a.narr; // each block takes a.narr arrays back to back (next one's lines prefetched)
+
+  auto load_lines = [&](float2 (&v)[R1], const float2* __restrict__ Sin) {
     if (PIN)
     {
 #pragma unroll
-      for (int n1 = 0; n1 < R1; n1++)
-        v[n1] = Sin[a.ain.row(z, n1 * R2 + j) * a.P + kxl];
+      for (int n1 = 0; n1 < R1; n1++) v[n1] = Sin[a.ain.row(z, n1 * R2 + j) * a.P + kxl];
     }
     else
     {
-      const uint32_t b = (z * a.ain.zmul + j * a.ain.estride) * a.P + kxl; // estride = 1 (y lines) or ny (z probe)
+      uint32_t b = (z * a.ain.zmul + j * a.ain.estride) * a.P + kxl; // estride = 1 (y lines) or ny (z probe)
+      asm volatile("" : "+v"(b));
       const uint32_t step = R2 * a.ain.estride * a.P;
 #pragma unroll
       for (int n1 = 0; n1 < R1; n1++) v[n1] = Sin[b + n1 * step];
     }
-  }
+  };
+
+  float2 v[R1];
+  if (ACT(R2, j)) load_lines(v, a.in[arr0]);
   lds_barrier(); // twiddle table visible (the line loads stay in flight across it)
-  if (ACT(R2, j))
+#pragma unroll 1
+  for (uint32_t ia = 0; ia < a.narr; ia++)
   {
-    step_a<L, DIR>(v, j, twl);
-#pragma unroll
-    for (int k1 = 0; k1 < R1; k1++) lds[k1 * G::SF + j * G::NL + c] = v[k1];
-  }
-  lds_barrier();
-  if (ACT(R1, j))
-  {
-    float2 w[R2];
-#pragma unroll
-    for (int n2 = 0; n2 < R2; n2++) w[n2] = lds[j * G::SF + n2 * G::NL + c];
-    Dft<R2, DIR>::run(w);
-    if (valid)
+    if (ACT(R2, j))
     {
-      if (POUT)
-      {
+      step_a<L, DIR>(v, j, twl);
 #pragma unroll
-        for (int k2 = 0; k2 < R2; k2++) Sout[a.aout.row(z, j + R1 * k2) * a.P + kx] = w[k2];
-      }
-      else
-      {
-        const uint32_t b = (z * a.aout.zmul + j * a.aout.estride) * a.P + kx;
-        const uint32_t step = R1 * a.aout.estride * a.P;
+      for (int k1 = 0; k1 < R1; k1++) lds[k1 * G::SF + j * G::NL + c] = v[k1];
+      if (ia + 1 < a.narr) load_lines(v, a.in[arr0 + ia + 1]);
+    }
+    lds_barrier();
+    if (ACT(R1, j))
+    {
+      float2 w[R2];
 #pragma unroll
-        for (int k2 = 0; k2 < R2; k2++) Sout[b + k2 * step] = w[k2];
+      for (int n2 = 0; n2 < R2; n2++) w[n2] = lds[j * G::SF + n2 * G::NL + c];
+      Dft<R2, DIR>::run(w);
+      if (valid)
+      {
+        float2* __restrict__ Sout = a.out[arr0 + ia];
+        if (POUT)
+        {
+#pragma unroll
+          for (int k2 = 0; k2 < R2; k2++) Sout[a.aout.row(z, j + R1 * k2) * a.P + kx] = w[k2];
+        }
+        else
+        {
+          uint32_t b = (z * a.aout.zmul + j * a.aout.estride) * a.P + kx;
+          asm volatile("" : "+v"(b));
+          const uint32_t step = R1 * a.aout.estride * a.P;
+#pragma unroll
+          for (int k2 = 0; k2 < R2; k2++) Sout[b + k2 * step] = w[k2];
+        }
       }
     }
+    if (ia + 1 < a.narr) lds_barrier(); // exchange buffer reused by the next array
   }
 }
 
@@ -536,7 +546,6 @@ template<int L, int EPI, bool CHAIN> __global__ __launch_bounds__(Geo<L>::THREAD
   float4 res[NA][NQ];
   constexpr int NF = CHAIN ? ((EPI == EPI_DENSITY) ? 2 : 1) : 1; // chained forward transforms
   float4 fw[NF][NQ];
-  static_assert(!CHAIN || EPI == EPI_DENSITY || EPI == EPI_VELOCITY, "chain only after velocity / density");
 #pragma unroll
   for (int i = 0; i < NA; i++)
   {
@@ -770,6 +779,52 @@ __global__ void k_import_reduced(float* __restrict__ dst, const float* __restric
   }
 }
 
+// ---- tuning probes (kw_fused_probe): the memory pattern of a line pass without its arithmetic ---------------------
+__global__ void k_probe_copy4(float4* __restrict__ p, size_t n4)
+{
+  for (size_t e = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x; e < n4; e += static_cast<size_t>(gridDim.x) * blockDim.x)
+  {
+    float4 v = p[e];
+    v.x += 1.f;
+    p[e] = v;
+  }
+}
+// LEVEL 0: tile loads + tile stores only; 1: plus the LDS exchange (no DFTs)
+template<int L, int LEVEL> __global__ __launch_bounds__(Geo<L>::THREADS) void k_probe_tile(PassArgs a)
+{
+  using G = Geo<L>;
+  constexpr int R1 = G::R1, R2 = G::R2;
+  __shared__ float2 lds[G::LDSB];
+  const int      c   = threadIdx.x % G::NL;
+  const int      j   = threadIdx.x / G::NL;
+  const uint32_t kx  = blockIdx.x * G::NL + c;
+  const uint32_t kxl = min(kx, a.nxc - 1u);
+  const uint32_t z   = blockIdx.y;
+  float2* __restrict__ S = a.out[blockIdx.z];
+  float2 v[R1], w[R2];
+  const uint32_t b = (z * a.ain.zmul + j * a.ain.estride) * a.P;
+#pragma unroll
+  for (int n1 = 0; n1 < R1; n1++) v[n1] = S[b + kxl + n1 * (R2 * a.ain.estride * a.P)];
+  if (LEVEL >= 1)
+  {
+#pragma unroll
+    for (int k1 = 0; k1 < R1; k1++) lds[k1 * G::SF + j * G::NL + c] = v[k1];
+    lds_barrier();
+#pragma unroll
+    for (int n2 = 0; n2 < R2; n2++) w[n2] = lds[j * G::SF + n2 * G::NL + c];
+  }
+  else
+  {
+#pragma unroll
+    for (int n2 = 0; n2 < R2; n2++) w[n2] = make_float2(v[n2 % R1].x + 1.f, v[n2 % R1].y);
+  }
+  if (kx < a.nxc)
+  {
+#pragma unroll
+    for (int k2 = 0; k2 < R2; k2++) S[b + kx + k2 * (R1 * a.ain.estride * a.P)] = w[k2];
+  }
+}
+
 // ---- host side ------------------------------------------------------------------------------------------------------
 bool supported_len(uint32_t n) { return n == 16 || n == 32 || n == 64 || n == 128 || n == 256 || n == 512; }
 
@@ -824,7 +879,8 @@ kw_status launch_ypass(kw_ctx* ctx, int dir, int narr, float2* const* in, float2
   const RowAddr packed{sh, f.nyl - 1u, c.nz * f.nyl, f.nyl, 1u};
   a.ain  = pack_in ? packed : natural;
   a.aout = pack_out ? packed : natural;
-  const dim3 grid(f.P / nl_of(c.ny), c.nz, narr);
+  a.narr = f.ypass_loop ? narr : 1;
+  const dim3 grid(f.P / nl_of(c.ny), c.nz, narr / a.narr);
   // forward: natural in, natural or packed out; inverse: natural or packed in, natural out
 #define M(LEN)                                                                                                         \
   if (dir < 0) { if (pack_out) LAUNCH((k_ypass<LEN, kFwd, false, true>), grid, dim3(Geo<LEN>::THREADS), a);           \
@@ -1011,6 +1067,8 @@ kw_status create_impl(kw_ctx* ctx, void* const s[3], void* const t[3])
   {
     const char* e = getenv("KW_FUSED_PER_ARRAY");
     f.per_array   = (e != nullptr) && (e[0] != '0');
+    e             = getenv("KW_FUSED_YPASS_LOOP");
+    f.ypass_loop  = (e == nullptr) || (e[0] != '0');
   }
   f.ready = true;
   return KW_OK;
@@ -1345,10 +1403,33 @@ kw_status kw_fused_probe(kw_ctx* ctx, int which, const float* op)
     a.tw  = f.tw[2];
     a.nxc = c.nx_complex;
     a.P   = f.P;
+    a.narr = 1;
     a.ain = a.aout = RowAddr{31u, 0xffffffffu, 0u, 1u, c.ny}; // element k of line (ky = blockIdx.y): row k*ny + ky
     const dim3 grid(f.P / nl_of(c.nz), c.ny, 1);
 #define M(LEN) LAUNCH((k_ypass<LEN, kFwd, false, false>), grid, dim3(Geo<LEN>::THREADS), a)
     KW_LEN_SWITCH(c.nz, M)
+#undef M
+    return KW_OK;
+  }
+  if (which == 10)
+  {
+    const size_t n4 = static_cast<size_t>(f.P) * c.ny * c.nz / 2;
+    LAUNCH(k_probe_copy4, dim3(256 * 16), dim3(256), reinterpret_cast<float4*>(f.s[0]), n4);
+    return KW_OK;
+  }
+  if (which >= 11 && which <= 14)
+  { // 11/12: y-line tiles, 13/14: z-line tiles; odd: loads + stores only, even: plus the LDS exchange
+    KW_REQUIRE(c.nz == c.ny && Fac<256>::R1 == Fac<256>::R2);
+    PassArgs a{};
+    a.out[0] = f.s[0];
+    a.nxc = c.nx_complex;
+    a.P   = f.P;
+    a.ain = (which <= 12) ? RowAddr{31u, 0xffffffffu, 0u, c.ny, 1u} : RowAddr{31u, 0xffffffffu, 0u, 1u, c.ny};
+    const dim3 grid(f.P / nl_of(c.ny), c.nz, 1);
+#define M(LEN)                                                                                                         \
+  if (which & 1) LAUNCH((k_probe_tile<LEN, 0>), grid, dim3(Geo<LEN>::THREADS), a);                                    \
+  else LAUNCH((k_probe_tile<LEN, 1>), grid, dim3(Geo<LEN>::THREADS), a)
+    KW_LEN_SWITCH(c.ny, M)
 #undef M
     return KW_OK;
   }

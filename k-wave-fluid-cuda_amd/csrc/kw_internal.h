@@ -40,6 +40,7 @@ struct kw_ctx
   {
     bool     ready = false;
     bool     per_array = false;                    // launch order: chain per array instead of batched (A/B knob; batched is faster)
+    bool     ypass_loop = true;                    // y-pass blocks walk the arrays of a launch (prefetching) instead of one array per block
     uint32_t P     = 0;                            // padded half-spectrum row pitch (complex), multiple of 16
     float2*  s[3]  = {nullptr, nullptr, nullptr};  // three padded complex scratch arrays [nz][ny][P]
     float2*  tw[3] = {nullptr, nullptr, nullptr};  // exp(-2 pi i m / n) for n = nx, ny, nz

@@ -27,8 +27,10 @@ def main(n=256, reps=30):
     capi.check(dev.L.kw_fused_reduced_elems(dev.ctx, C.byref(ne)))
     op = dev.array(np.ones(ne.value, dtype=np.float32))
     cbytes = 8 * (n // 2 + 1) * n * n
-    names = {0: "y-pass (1 array)", 1: "line pass along z (1 array)", 2: "z-fused (1 array + operator)", 3: "y-pass (3 arrays)"}
-    for which in (0, 1, 2, 3):
+    names = {0: "y-pass (1 array)", 1: "line pass along z (1 array)", 2: "z-fused (1 array + operator)", 3: "y-pass (3 arrays)",
+             10: "flat float4 copy in place", 11: "y tiles: load + store only", 12: "y tiles: + LDS exchange",
+             13: "z tiles: load + store only", 14: "z tiles: + LDS exchange"}
+    for which in (10, 11, 12, 0, 13, 14, 1, 2, 3):
         for _ in range(3):
             dev.call("fused_probe", which, op)
         e0, e1 = dev.event(), dev.event()
