@@ -110,6 +110,7 @@ struct PassArgs
   const float2* tw;
   uint32_t      nxc, P;
   uint32_t      narr; // arrays per block (grid.z * narr arrays in the launch)
+  uint32_t      z0;   // first plane of this launch (chunked plane-local passes)
   RowAddr       ain, aout;
 };
 
@@ -128,7 +129,7 @@ __global__ __launch_bounds__(Geo<L>::THREADS) void k_ypass(PassArgs a)
   const uint32_t kx    = blockIdx.x * G::NL + c;
   const bool     valid = kx < a.nxc;
   const uint32_t kxl   = min(kx, a.nxc - 1u); // pad lanes re-read the last column (no branch, no extra sector); never stored
-  const uint32_t z     = blockIdx.y;
+  const uint32_t z     = blockIdx.y + a.z0;
   const uint32_t arr0  = blockIdx.z * a.narr; // each block takes a.narr arrays back to back (next one's lines prefetched)
 
   auto load_lines = [&](float2 (&v)[R1], const float2* __restrict__ Sin) {
@@ -384,7 +385,7 @@ struct XfwdArgs
 // exchange buffer must be free on entry and is free again on exit (trailing barrier).
 template<int L>
 __device__ __forceinline__ void xfwd_tail(float2 (&v)[Fac<L>::R1], float2* lds, int c, int f,
-                                          const float2* tw, float2* __restrict__ out, uint32_t P)
+                                          const float2* tw, float2* __restrict__ out, uint32_t P, uint32_t tile)
 {
   using G = Geo<L>;
   constexpr int R1 = G::R1, R2 = G::R2, HALF = L / 2 + 1;
@@ -409,7 +410,7 @@ __device__ __forceinline__ void xfwd_tail(float2 (&v)[Fac<L>::R1], float2* lds, 
     for (int k2 = 0; k2 < R2; k2++) lds[c * G::ZP + f + R1 * k2] = w[k2];
   }
   lds_barrier();
-  const uint32_t tile_row0 = blockIdx.x * G::NL * 2;
+  const uint32_t tile_row0 = tile * G::NL * 2;
   for (int e = threadIdx.x; e < G::NL * HALF; e += G::THREADS)
   {
     const int    cc = e / HALF;
@@ -445,7 +446,7 @@ template<int L> __global__ __launch_bounds__(Geo<L>::THREADS) void k_xfwd(XfwdAr
     for (int n1 = 0; n1 < R1; n1++) v[n1] = make_float2(ra[n1 * R2 + f], rb[n1 * R2 + f]);
   }
   lds_barrier(); // twiddle table visible
-  xfwd_tail<L>(v, lds, c, f, twl, a.out[blockIdx.y], a.P);
+  xfwd_tail<L>(v, lds, c, f, twl, a.out[blockIdx.y], a.P, blockIdx.x);
 }
 
 // =====================================================================================================================
@@ -471,16 +472,17 @@ struct XinvArgs
   int           terms; // 0 none, 1 linear (t0 = sum rho, t1 = rho0*sum du), 2 nonlinear (t0, t1 = nonlinear term, t2)
   uint32_t      comp0; // first component of this launch (per-array launches)
   float2*       fout[3]; // CHAIN: where the forward x-transform of the epilogue's result goes (scratch rows)
+  uint32_t      tile0;   // first 2*NL-row tile of this launch (chunked plane-local passes)
 };
 
 // standalone inverse of one array for this block's 32 rows; thread (c, f<R1) ends with x[f + R1*k2] of rows (2c, 2c+1)
 template<int L>
 __device__ __forceinline__ void xinv_lines(const float2* __restrict__ src, uint32_t P, float2* lds, int c, int f,
-                                           const float2* tw, float2 (&w)[Fac<L>::R2])
+                                           const float2* tw, float2 (&w)[Fac<L>::R2], uint32_t tile)
 {
   using G = Geo<L>;
   constexpr int R1 = G::R1, R2 = G::R2, HALF = L / 2 + 1;
-  const uint32_t tile_row0 = blockIdx.x * G::NL * 2;
+  const uint32_t tile_row0 = tile * G::NL * 2;
   for (int e = threadIdx.x; e < G::NL * HALF; e += G::THREADS)
   {
     const int    cc = e / HALF;
@@ -543,6 +545,7 @@ template<int L, int EPI, bool CHAIN> __global__ __launch_bounds__(Geo<L>::THREAD
   const int f = threadIdx.x % G::TPL;
   const int c = threadIdx.x / G::TPL;
   const uint32_t comp = (NA == 1) ? blockIdx.y + a.comp0 : 0; // component / array index for single-array epilogues
+  const uint32_t tile = blockIdx.x + a.tile0;
   float4 res[NA][NQ];
   constexpr int NF = CHAIN ? ((EPI == EPI_DENSITY) ? 2 : 1) : 1; // chained forward transforms
   float4 fw[NF][NQ];
@@ -550,7 +553,7 @@ template<int L, int EPI, bool CHAIN> __global__ __launch_bounds__(Geo<L>::THREAD
   for (int i = 0; i < NA; i++)
   {
     float2 w[R2];
-    xinv_lines<L>(a.in[(NA == 1) ? comp : i], a.P, lds, c, f, twl, w); // ends with a barrier
+    xinv_lines<L>(a.in[(NA == 1) ? comp : i], a.P, lds, c, f, twl, w, tile); // ends with a barrier
     if (ACT(R1, f))
     {
 #pragma unroll
@@ -573,7 +576,7 @@ template<int L, int EPI, bool CHAIN> __global__ __launch_bounds__(Geo<L>::THREAD
   }
 
   const kw_constants& k = a.c;
-  const uint32_t tile_row0 = blockIdx.x * G::NL * 2;
+  const uint32_t tile_row0 = tile * G::NL * 2;
 #pragma unroll
   for (int q = 0; q < NQ; q++)
   {
@@ -761,7 +764,7 @@ template<int L, int EPI, bool CHAIN> __global__ __launch_bounds__(Geo<L>::THREAD
           v[n1] = make_float2(ldsr[(2 * c) * RP + n1 * R2c + f], ldsr[(2 * c + 1) * RP + n1 * R2c + f]);
       }
       lds_barrier(); // the real tile aliases the exchange buffer
-      xfwd_tail<L>(v, lds, c, f, twl, a.fout[(NA == 1) ? comp : jf], a.P);
+      xfwd_tail<L>(v, lds, c, f, twl, a.fout[(NA == 1) ? comp : jf], a.P, tile);
     }
   }
 }
@@ -864,7 +867,8 @@ kw_status launch_xfwd(kw_ctx* ctx, int narr, const float* const* in, float2* con
 
 // y-pass.  pack_out / pack_in select the packed (per-peer-chunk) row layout on that side; with one rank both layouts
 // coincide and the pass may run in place.
-kw_status launch_ypass(kw_ctx* ctx, int dir, int narr, float2* const* in, float2* const* out, bool pack_in, bool pack_out)
+kw_status launch_ypass(kw_ctx* ctx, int dir, int narr, float2* const* in, float2* const* out, bool pack_in, bool pack_out,
+                       uint32_t z0 = 0, uint32_t nzc = 0)
 {
   const kw_constants& c = ctx->c;
   const auto& f = ctx->fused;
@@ -880,7 +884,8 @@ kw_status launch_ypass(kw_ctx* ctx, int dir, int narr, float2* const* in, float2
   a.ain  = pack_in ? packed : natural;
   a.aout = pack_out ? packed : natural;
   a.narr = f.ypass_loop ? narr : 1;
-  const dim3 grid(f.P / nl_of(c.ny), c.nz, narr / a.narr);
+  a.z0   = z0;
+  const dim3 grid(f.P / nl_of(c.ny), nzc ? nzc : c.nz, narr / a.narr);
   // forward: natural in, natural or packed out; inverse: natural or packed in, natural out
 #define M(LEN)                                                                                                         \
   if (dir < 0) { if (pack_out) LAUNCH((k_ypass<LEN, kFwd, false, true>), grid, dim3(Geo<LEN>::THREADS), a);           \
@@ -912,13 +917,14 @@ template<int MODE> kw_status launch_zfused(kw_ctx* ctx, int narr, ZArgs a)
   return KW_OK;
 }
 
-template<int EPI, bool CHAIN = false> kw_status launch_xinv(kw_ctx* ctx, int ncomp, XinvArgs a)
+template<int EPI, bool CHAIN = false> kw_status launch_xinv(kw_ctx* ctx, int ncomp, XinvArgs a, uint32_t z0 = 0, uint32_t nzc = 0)
 {
   const kw_constants& c = ctx->c;
   a.tw = ctx->fused.tw[0];
   a.c  = c;
   a.P  = ctx->fused.P;
-  const dim3 grid(c.ny * c.nz / (2 * nl_of(c.nx)), ncomp, 1);
+  a.tile0 = z0 * c.ny / (2 * nl_of(c.nx));
+  const dim3 grid(c.ny * (nzc ? nzc : c.nz) / (2 * nl_of(c.nx)), ncomp, 1);
 #define M(LEN) LAUNCH((k_xinv<LEN, EPI, CHAIN>), grid, dim3(Geo<LEN>::THREADS), a)
   KW_LEN_SWITCH(c.nx, M)
 #undef M
@@ -985,11 +991,34 @@ template<int MODE> kw_status slab_chain(kw_ctx* ctx, int narr, const float* cons
 kw_status forward_xy(kw_ctx* ctx, int narr, const float* const* in, int s0 = 0)
 {
   auto& f = ctx->fused;
+  const int y_done = f.y_done;
+  f.y_done = 0;
   if (in != nullptr) KW_TRY(launch_xfwd(ctx, narr, in, f.s + s0)); // nullptr: x-spectra were chained into S[] already
+  else if (y_done >= s0 + narr) return KW_OK;                      // ... and so was their y-pass (chunked producer)
   if (f.nranks == 1) return launch_ypass(ctx, -1, narr, f.s + s0, f.s + s0, false, false);
   KW_TRY(launch_ypass(ctx, -1, narr, f.s + s0, f.t + s0, false, true));
   for (int i = 0; i < narr; i++) KW_TRY(xstart(ctx, s0 + i, f.t[s0 + i], f.s[s0 + i]));
   for (int i = 0; i < narr; i++) KW_TRY(xwait(ctx, s0 + i));
+  return KW_OK;
+}
+
+// Single rank: the plane-local tail of a stage — y-inverse, x-inverse + epilogue and, when the epilogue chains the
+// x-spectra of its results into S[0..nchain), their forward y-pass — runs per chunk of planes, so that what one kernel
+// writes is still in the Infinity Cache when the next one reads it.
+template<int EPI, bool CHAIN> kw_status plane_local_tail(kw_ctx* ctx, int narr, int ncomp, const XinvArgs& x, int nchain)
+{
+  auto& f = ctx->fused;
+  const kw_constants& c = ctx->c;
+  uint32_t nch = f.zchunks;
+  while (nch > 1 && (c.nz % nch != 0 || (c.nz / nch * c.ny) % (2 * nl_of(c.nx)) != 0)) nch--;
+  const uint32_t nzc = c.nz / nch;
+  for (uint32_t ch = 0; ch < nch; ch++)
+  {
+    KW_TRY(launch_ypass(ctx, +1, narr, f.s, f.s, false, false, ch * nzc, nzc));
+    KW_TRY((launch_xinv<EPI, CHAIN>(ctx, ncomp, x, ch * nzc, nzc)));
+    if (CHAIN) KW_TRY(launch_ypass(ctx, -1, nchain, f.s, f.s, false, false, ch * nzc, nzc));
+  }
+  if (CHAIN) f.y_done = nchain;
   return KW_OK;
 }
 
@@ -1067,6 +1096,8 @@ kw_status create_impl(kw_ctx* ctx, void* const s[3], void* const t[3])
   {
     const char* e = getenv("KW_FUSED_PER_ARRAY");
     f.per_array   = (e != nullptr) && (e[0] != '0');
+    e             = getenv("KW_FUSED_ZCHUNKS");
+    f.zchunks     = (e != nullptr && atoi(e) > 0) ? static_cast<uint32_t>(atoi(e)) : 1u;
     e             = getenv("KW_FUSED_YPASS_LOOP");
     f.ypass_loop  = (e == nullptr) || (e[0] != '0');
   }
@@ -1223,11 +1254,10 @@ kw_status kw_fused_velocity(kw_ctx* ctx, const float* p, float* ux, float* uy, f
   }
   else
   {
-    KW_TRY(inverse_y(ctx, 3));
-    // chained: the updated velocity rows are forward-transformed along x on the spot (valid as long as nothing else
-    // writes u before kw_fused_density(..., KW_FUSED_U_IN_SCRATCH))
-    if (chain_u_spectra) KW_TRY((launch_xinv<EPI_VELOCITY, true>(ctx, 3, x)));
-    else KW_TRY(launch_xinv<EPI_VELOCITY>(ctx, 3, x));
+    // chained: the updated velocity rows are forward-transformed along x (and y) on the spot (valid as long as nothing
+    // else writes u before kw_fused_density(..., KW_FUSED_U_IN_SCRATCH))
+    if (chain_u_spectra) KW_TRY((plane_local_tail<EPI_VELOCITY, true>(ctx, 3, 3, x, 3)));
+    else KW_TRY((plane_local_tail<EPI_VELOCITY, false>(ctx, 3, 3, x, 0)));
   }
   return KW_OK;
 }
@@ -1298,8 +1328,8 @@ kw_status kw_fused_density(kw_ctx* ctx, int nonlinear, const float* ux, const fl
   {
     KW_TRY(forward_xy(ctx, 3, u_in_scratch ? nullptr : in3));
     KW_TRY(launch_zfused<Z_VGRAD>(ctx, 3, z));
-    KW_TRY(inverse_y(ctx, 3));
   }
+  const bool tail_chunked = (ctx->fused.nranks == 1 && !ctx->fused.per_array);
   XinvArgs x{};
   float* rho[3] = { rx, ry, rz };
   const float* pml[3] = { pmlx, pmly, pmlz };
@@ -1312,7 +1342,12 @@ kw_status kw_fused_density(kw_ctx* ctx, int nonlinear, const float* ux, const fl
   x.terms     = terms;
   x.fout[0]   = S[0]; // chained: x-spectrum of rho0 * sum(du)
   x.fout[1]   = S[1]; //          x-spectrum of sum(rho)
-  if (chain_terms) KW_TRY((launch_xinv<EPI_DENSITY, true>(ctx, 1, x)));
+  if (tail_chunked)
+  {
+    if (chain_terms) KW_TRY((plane_local_tail<EPI_DENSITY, true>(ctx, 3, 1, x, 2)));
+    else KW_TRY((plane_local_tail<EPI_DENSITY, false>(ctx, 3, 1, x, 0)));
+  }
+  else if (chain_terms) KW_TRY((launch_xinv<EPI_DENSITY, true>(ctx, 1, x)));
   else KW_TRY(launch_xinv<EPI_DENSITY>(ctx, 1, x));
   return KW_OK;
 }
@@ -1351,14 +1386,14 @@ kw_status kw_fused_absorption_pressure(kw_ctx* ctx, float* p, const float* vel_g
   {
     KW_TRY(forward_xy(ctx, 2, terms_in_scratch ? nullptr : in2));
     KW_TRY(launch_zfused<Z_ABSORB>(ctx, 2, z));
-    KW_TRY(inverse_y(ctx, 2));
   }
   XinvArgs x{};
   x.in[0] = S[0]; x.in[1] = S[1];
   x.out[0] = p;
   x.m0[0] = first; x.m0[1] = c2;
   x.m1[0] = tau;   x.m1[1] = eta;
-  KW_TRY(launch_xinv<EPI_PSUM>(ctx, 1, x));
+  if (ctx->fused.nranks == 1 && !ctx->fused.per_array) KW_TRY((plane_local_tail<EPI_PSUM, false>(ctx, 2, 1, x, 0)));
+  else KW_TRY(launch_xinv<EPI_PSUM>(ctx, 1, x));
   return KW_OK;
 }
 

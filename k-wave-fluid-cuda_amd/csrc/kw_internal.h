@@ -41,6 +41,8 @@ struct kw_ctx
     bool     ready = false;
     bool     per_array = false;                    // launch order: chain per array instead of batched (A/B knob; batched is faster)
     bool     ypass_loop = true;                    // y-pass blocks walk the arrays of a launch (prefetching) instead of one array per block
+    uint32_t zchunks = 1;                          // plane-local passes (y^-1, x^-1 + epilogue, chained x, y) run per chunk of planes
+    int      y_done  = 0;                          // chained spectra in s[0..y_done) already carry their forward y-pass
     uint32_t P     = 0;                            // padded half-spectrum row pitch (complex), multiple of 16
     float2*  s[3]  = {nullptr, nullptr, nullptr};  // three padded complex scratch arrays [nz][ny][P]
     float2*  tw[3] = {nullptr, nullptr, nullptr};  // exp(-2 pi i m / n) for n = nx, ny, nz

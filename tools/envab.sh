@@ -1,0 +1,13 @@
+#!/bin/bash
+# tools/envab.sh VAR v1 v2 ... : bench the current build under VAR=v for each value, two interleaved repetitions (one box)
+var=$1; shift
+for rep in 1 2; do
+  for v in "$@"; do
+    env $var=$v python bench.py --no-cpu > gpurun_out/env_${var}_${v}_${rep}.json
+    python - <<PY
+import json
+d=json.load(open("gpurun_out/env_${var}_${v}_${rep}.json"))
+print("$var=$v", "$rep", d["value"], {k: round(x["ms_per_step"],4) for k,x in d["roofline"]["entry_points"].items()})
+PY
+  done
+done
