@@ -370,6 +370,232 @@ template<int L, int MODE> __global__ __launch_bounds__(Geo<L>::THREADS) void k_z
 }
 
 // =====================================================================================================================
+// Lines of 512 = 2 x 256.  One radix-2 decimation-in-frequency stage in registers around two 256-point four-step
+// transforms that use the block's exchange buffer one after the other:
+//   forward / standalone (either sign):  a[n] = x[n] + x[n+H],  b[n] = (x[n] - x[n+H]) * W_L^(DIR*n),
+//                                        X[2k] = F_H(a)[k],     X[2k+1] = F_H(b)[k]
+//   inverse started from spectrum registers:  a = F_H^-1(X[2k]),  b = F_H^-1(X[2k+1]),
+//                                        x[n] = a[n] + W_L^(+n) b[n],   x[n+H] = a[n] - W_L^(+n) b[n]
+// 16 lines x 16 threads with 32 elements per thread: the tile width (128-B segments), block size and LDS footprint of the
+// 256-point kernels, instead of 32-point register DFTs whose register demand leaves one or two waves per SIMD.
+// =====================================================================================================================
+template<int L> __device__ __forceinline__ void load_twiddles_split(float2* twl, float2* tw2, const float2* __restrict__ tw)
+{
+  using G = Geo<L / 2>;
+  for (int e = threadIdx.x; e < G::R1 * G::R2; e += G::THREADS)
+  {
+    const int k = e / G::R2, n = e - k * G::R2;
+    twl[k * G::TP + n] = tw[2 * k * n]; // W_H^(kn) = W_L^(2kn)
+  }
+  for (int e = threadIdx.x; e < L / 2; e += G::THREADS) tw2[e] = tw[e];
+}
+
+// H-point transform of the step-A registers v (thread (c, n2 = j) holds x[n1*R2 + j]); thread (c, k1 = j) ends with
+// X[j + R1*k2] in w.  The exchange buffer must be free on entry; the caller puts a barrier before its next use.
+template<int H, int DIR>
+__device__ __forceinline__ void line_fft(float2 (&v)[Fac<H>::R1], float2 (&w)[Fac<H>::R2], float2* lds, int c, int j,
+                                         const float2* twl)
+{
+  using G = Geo<H>;
+  step_a<H, DIR>(v, j, twl);
+#pragma unroll
+  for (int k1 = 0; k1 < G::R1; k1++) lds[k1 * G::SF + j * G::NL + c] = v[k1];
+  lds_barrier();
+#pragma unroll
+  for (int n2 = 0; n2 < G::R2; n2++) w[n2] = lds[j * G::SF + n2 * G::NL + c];
+  Dft<G::R2, DIR>::run(w);
+}
+
+template<int L, int DIR, bool PIN, bool POUT>
+__global__ __launch_bounds__(Geo<L / 2>::THREADS) void k_ypass_split(PassArgs a)
+{
+  constexpr int H = L / 2;
+  using G = Geo<H>;
+  constexpr int R1 = G::R1, R2 = G::R2;
+  static_assert(R1 == R2 && G::TPL == R1 && H == R1 * R2, "split lines are built on the balanced 256-point transform");
+  __shared__ float2 lds[G::LDSB];
+  __shared__ float2 twl[G::TWN];
+  __shared__ float2 tw2[H];
+  load_twiddles_split<L>(twl, tw2, a.tw);
+  const int      c     = threadIdx.x % G::NL;
+  const int      j     = threadIdx.x / G::NL;
+  const uint32_t kx    = blockIdx.x * G::NL + c;
+  const bool     valid = kx < a.nxc;
+  const uint32_t kxl   = min(kx, a.nxc - 1u);
+  const uint32_t z     = blockIdx.y + a.z0;
+  const float2* __restrict__ Sin = a.in[blockIdx.z];
+  float2* __restrict__ Sout      = a.out[blockIdx.z];
+
+  float2 va[R1], vb[R1];
+  if (PIN)
+  {
+#pragma unroll
+    for (int n1 = 0; n1 < R1; n1++)
+    {
+      va[n1] = Sin[a.ain.row(z, n1 * R2 + j) * a.P + kxl];
+      vb[n1] = Sin[a.ain.row(z, H + n1 * R2 + j) * a.P + kxl];
+    }
+  }
+  else
+  {
+    const uint32_t b    = (z * a.ain.zmul + j * a.ain.estride) * a.P + kxl;
+    const uint32_t step = R2 * a.ain.estride * a.P;
+#pragma unroll
+    for (int n1 = 0; n1 < R1; n1++)
+    {
+      va[n1] = Sin[b + n1 * step];
+      vb[n1] = Sin[b + (R1 + n1) * step];
+    }
+  }
+  lds_barrier(); // twiddle tables visible (the line loads stay in flight across it)
+#pragma unroll
+  for (int n1 = 0; n1 < R1; n1++)
+  {
+    const float2 lo = va[n1], hi = vb[n1];
+    va[n1] = cadd(lo, hi);
+    vb[n1] = apply_tw<DIR>(csub(lo, hi), tw2[n1 * R2 + j]);
+  }
+  float2 wa[R2], wb[R2];
+  line_fft<H, DIR>(va, wa, lds, c, j, twl);
+  lds_barrier();
+  line_fft<H, DIR>(vb, wb, lds, c, j, twl);
+  if (valid)
+  {
+    if (POUT)
+    {
+#pragma unroll
+      for (int k2 = 0; k2 < R2; k2++)
+      {
+        Sout[a.aout.row(z, 2 * (j + R1 * k2)) * a.P + kx]     = wa[k2];
+        Sout[a.aout.row(z, 2 * (j + R1 * k2) + 1) * a.P + kx] = wb[k2];
+      }
+    }
+    else
+    {
+      const uint32_t b    = (z * a.aout.zmul + 2 * j * a.aout.estride) * a.P + kx;
+      const uint32_t one  = a.aout.estride * a.P;
+      const uint32_t step = 2 * R1 * one;
+#pragma unroll
+      for (int k2 = 0; k2 < R2; k2++)
+      {
+        Sout[b + k2 * step]       = wa[k2];
+        Sout[b + one + k2 * step] = wb[k2];
+      }
+    }
+  }
+}
+
+template<int L, int MODE> __global__ __launch_bounds__(Geo<L / 2>::THREADS) void k_zfused_split(ZArgs a)
+{
+  constexpr int H = L / 2;
+  using G = Geo<H>;
+  constexpr int R1 = G::R1, R2 = G::R2;
+  static_assert(R1 == R2 && G::TPL == R1 && H == R1 * R2, "split lines are built on the balanced 256-point transform");
+  __shared__ float2 lds[G::LDSB];
+  __shared__ float2 twl[G::TWN];
+  __shared__ float2 tw2[H];
+  load_twiddles_split<L>(twl, tw2, a.tw);
+  const int      c      = threadIdx.x % G::NL;
+  const int      j      = threadIdx.x / G::NL;
+  const uint32_t kx     = blockIdx.x * G::NL + c;
+  const uint32_t ky     = blockIdx.y;
+  const bool     valid  = kx < a.nxc;
+  const uint32_t zstr   = a.ny * a.P;
+  const uint32_t base   = ky * a.P + kx;
+  const uint32_t kxl    = min(kx, a.nxc - 1u);
+  const uint32_t basel  = ky * a.P + kxl;
+  constexpr bool MULTI  = (MODE == Z_VGRAD || MODE == Z_ABSORB);
+  const uint32_t arr    = MULTI ? a.arr0 + blockIdx.z : 0;
+  constexpr int  NOUT   = (MODE == Z_PGRAD) ? 3 : 1;
+
+  float2 Xa[R2], Xb[R2]; // after the forward transform: X[2*(j + R1*k2)], X[2*(j + R1*k2) + 1]
+  {
+    float2 va[R1], vb[R1];
+    const float2* __restrict__ in = a.in[arr];
+    const uint32_t lb = basel + static_cast<uint32_t>(j) * zstr;
+#pragma unroll
+    for (int n1 = 0; n1 < R1; n1++)
+    {
+      va[n1] = in[lb + static_cast<uint32_t>(n1 * R2) * zstr];
+      vb[n1] = in[lb + static_cast<uint32_t>(H + n1 * R2) * zstr];
+    }
+    lds_barrier(); // twiddle tables visible
+#pragma unroll
+    for (int n1 = 0; n1 < R1; n1++)
+    {
+      const float2 lo = va[n1], hi = vb[n1];
+      va[n1] = cadd(lo, hi);
+      vb[n1] = apply_tw<kFwd>(csub(lo, hi), tw2[n1 * R2 + j]);
+    }
+    line_fft<H, kFwd>(va, Xa, lds, c, j, twl);
+    lds_barrier();
+    line_fft<H, kFwd>(vb, Xb, lds, c, j, twl);
+    lds_barrier(); // exchange buffer free for the inverse transforms
+  }
+  { // spectral operator (see k_zfused for the reference lines), kz = 2*(j + R1*k2) (+1)
+    const float* __restrict__ op = a.op[(MODE == Z_ABSORB) ? arr : 0];
+    const uint32_t lb = basel + static_cast<uint32_t>(2 * j) * zstr;
+#pragma unroll
+    for (int k2 = 0; k2 < R2; k2++)
+    {
+      float sa = op[lb + static_cast<uint32_t>(2 * R1 * k2) * zstr];
+      float sb = op[lb + static_cast<uint32_t>(2 * R1 * k2 + 1) * zstr];
+      if (MODE == Z_VGRAD || MODE == Z_SOURCE) { sa *= a.divider; sb *= a.divider; }
+      Xa[k2] = make_float2(Xa[k2].x * sa, Xa[k2].y * sa);
+      Xb[k2] = make_float2(Xb[k2].x * sb, Xb[k2].y * sb);
+    }
+  }
+#pragma unroll 1
+  for (int o = 0; o < NOUT; o++)
+  {
+    const uint32_t axis = (MODE == Z_PGRAD) ? o : arr;
+    float2 ra[R1], rb[R1];
+#pragma unroll
+    for (int half = 0; half < 2; half++)
+    {
+      float2 w[R2];
+      if (MODE == Z_PGRAD || MODE == Z_VGRAD)
+      {
+        if (axis == 2)
+        {
+          uint32_t jz = 2 * j + half;
+          asm volatile("" : "+v"(jz));
+#pragma unroll
+          for (int k2 = 0; k2 < R2; k2++) w[k2] = cmulf(half ? Xb[k2] : Xa[k2], a.dd[2][jz + 2 * R1 * k2]);
+        }
+        else
+        {
+          const float2 dxy = (axis == 0) ? a.dd[0][kxl] : a.dd[1][ky + a.ky0];
+#pragma unroll
+          for (int k2 = 0; k2 < R2; k2++) w[k2] = cmulf(half ? Xb[k2] : Xa[k2], dxy);
+        }
+      }
+      else
+      {
+#pragma unroll
+        for (int k2 = 0; k2 < R2; k2++) w[k2] = half ? Xb[k2] : Xa[k2];
+      }
+      if (half == 0) inverse_from_regs<H>(w, ra, lds, c, j, twl);
+      else inverse_from_regs<H>(w, rb, lds, c, j, twl);
+      if (half == 0 || o + 1 < NOUT) lds_barrier(); // exchange buffer reused by the next half / output
+    }
+    if (valid)
+    {
+      float2* __restrict__ out = a.out[(MODE == Z_PGRAD) ? o : arr];
+      uint32_t ob = base + static_cast<uint32_t>(j) * zstr;
+      asm volatile("" : "+v"(ob));
+#pragma unroll
+      for (int q2 = 0; q2 < R1; q2++)
+      { // n = j + R2*q2
+        const float2 t = apply_tw<kInv>(rb[q2], tw2[j + R2 * q2]);
+        out[ob + static_cast<uint32_t>(R2 * q2) * zstr]     = cadd(ra[q2], t);
+        out[ob + static_cast<uint32_t>(H + R2 * q2) * zstr] = csub(ra[q2], t);
+      }
+    }
+  }
+}
+
+// =====================================================================================================================
 // x-forward: two real rows per complex line -> two half-spectrum rows
 // =====================================================================================================================
 struct XfwdArgs
@@ -885,6 +1111,16 @@ kw_status launch_ypass(kw_ctx* ctx, int dir, int narr, float2* const* in, float2
   a.aout = pack_out ? packed : natural;
   a.narr = f.ypass_loop ? narr : 1;
   a.z0   = z0;
+  if (c.ny == 512 && f.split512)
+  { // 2 x 256 lines: 16-column tiles, one array per block
+    a.narr = 1;
+    const dim3 g(f.P / NLMAX, nzc ? nzc : c.nz, narr), b(Geo<256>::THREADS);
+    if (dir < 0) { if (pack_out) LAUNCH((k_ypass_split<512, kFwd, false, true>), g, b, a);
+                   else LAUNCH((k_ypass_split<512, kFwd, false, false>), g, b, a); }
+    else         { if (pack_in) LAUNCH((k_ypass_split<512, kInv, true, false>), g, b, a);
+                   else LAUNCH((k_ypass_split<512, kInv, false, false>), g, b, a); }
+    return KW_OK;
+  }
   const dim3 grid(f.P / nl_of(c.ny), nzc ? nzc : c.nz, narr / a.narr);
   // forward: natural in, natural or packed out; inverse: natural or packed in, natural out
 #define M(LEN)                                                                                                         \
@@ -910,6 +1146,11 @@ template<int MODE> kw_status launch_zfused(kw_ctx* ctx, int narr, ZArgs a)
   a.nz      = f.nz_global;
   a.ky0     = f.rank * f.nyl;
   a.narr    = narr;
+  if (f.nz_global == 512 && f.split512)
+  {
+    LAUNCH((k_zfused_split<512, MODE>), dim3(f.P / NLMAX, f.nyl, narr), dim3(Geo<256>::THREADS), a);
+    return KW_OK;
+  }
   const dim3 grid(f.P / nl_of(f.nz_global), f.nyl, 1);
 #define M(LEN) LAUNCH((k_zfused<LEN, MODE>), grid, dim3(Geo<LEN>::THREADS), a)
   KW_LEN_SWITCH(f.nz_global, M)
@@ -1098,6 +1339,8 @@ kw_status create_impl(kw_ctx* ctx, void* const s[3], void* const t[3])
     f.per_array   = (e != nullptr) && (e[0] != '0');
     e             = getenv("KW_FUSED_ZCHUNKS");
     f.zchunks     = (e != nullptr && atoi(e) > 0) ? static_cast<uint32_t>(atoi(e)) : 1u;
+    e             = getenv("KW_FUSED_SPLIT512");
+    f.split512    = (e == nullptr) || (e[0] != '0');
     e             = getenv("KW_FUSED_YPASS_LOOP");
     f.ypass_loop  = (e == nullptr) || (e[0] != '0');
   }

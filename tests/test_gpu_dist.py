@@ -31,6 +31,8 @@ def run_ranks(world, dims, steps, source, mode, tmp_path):
     (4, (32, 64, 64), "p0", 0),
     (2, (32, 32, 32), "p_source", 2),   # k-space corrected additive source: scaleSource is collective
     (2, (64, 32, 16), "u_source", 1),
+    (2, (16, 512, 16), "p0", 0),        # 512-point y lines (2 x 256 kernels) with packed per-peer addressing
+    (2, (16, 16, 512), "p0", 0),        # 512-point z lines on the transposed spectra
 ])
 def test_slab_ranks_match_oracle(orc, syn, tmp_path, world, dims, source, mode):
     steps = 20

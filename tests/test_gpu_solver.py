@@ -112,7 +112,7 @@ def test_fused_mixed_power_of_two_dims(orc, syn):
 
 @pytest.mark.parametrize("dims", [(512, 16, 32), (16, 512, 16), (16, 32, 512)])
 def test_fused_line_length_512(orc, syn, dims):
-    """512-point lines use the 8-lines-per-tile geometry (32-point register DFTs) in each of the three pass types."""
+    """512-point lines: 8-lines-per-tile geometry (32-point register DFTs) along x, 2 x 256 split kernels along y / z."""
     pr = syn.make_problem(*dims, heterogeneous=True, nonlinear=True, absorbing=True, source="p0", pml_size=4)
     errs = compare(orc, pr, 20, fused_kernels=True)
     assert max(errs.values()) < TOL, (dims, errs)
