@@ -170,8 +170,14 @@ def main():
     ap.add_argument("--granular", action="store_true", help="one launch per reference kernel instead of fused kernels")
     ap.add_argument("--strong", action="store_true", help="N>1: fixed --size^3 grid (default 512) instead of weak scaling")
     ap.add_argument("--backend", default="nccl", help="N>1: torch.distributed backend (nccl = RCCL; gloo for rehearsal)")
+    ap.add_argument("--slab-selftest", action="store_true",
+                    help="one rank through the N>1 code path (slab kernels + RCCL all-to-all with itself): rehearsal on a 1-GPU box")
     args = ap.parse_args()
 
+    if args.slab_selftest:
+        for k, v in (("MASTER_ADDR", "127.0.0.1"), ("MASTER_PORT", "29533"), ("RANK", "0"), ("WORLD_SIZE", "1"), ("LOCAL_RANK", "0")):
+            os.environ.setdefault(k, v)
+        return run_distributed(args)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     if args.gpus > 1 or world > 1:

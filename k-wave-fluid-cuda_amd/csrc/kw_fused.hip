@@ -1236,7 +1236,7 @@ kw_status forward_xy(kw_ctx* ctx, int narr, const float* const* in, int s0 = 0)
   f.y_done = 0;
   if (in != nullptr) KW_TRY(launch_xfwd(ctx, narr, in, f.s + s0)); // nullptr: x-spectra were chained into S[] already
   else if (y_done >= s0 + narr) return KW_OK;                      // ... and so was their y-pass (chunked producer)
-  if (f.nranks == 1) return launch_ypass(ctx, -1, narr, f.s + s0, f.s + s0, false, false);
+  if (!f.slab) return launch_ypass(ctx, -1, narr, f.s + s0, f.s + s0, false, false);
   KW_TRY(launch_ypass(ctx, -1, narr, f.s + s0, f.t + s0, false, true));
   for (int i = 0; i < narr; i++) KW_TRY(xstart(ctx, s0 + i, f.t[s0 + i], f.s[s0 + i]));
   for (int i = 0; i < narr; i++) KW_TRY(xwait(ctx, s0 + i));
@@ -1267,7 +1267,7 @@ template<int EPI, bool CHAIN> kw_status plane_local_tail(kw_ctx* ctx, int narr, 
 kw_status inverse_y(kw_ctx* ctx, int narr, int s0 = 0)
 {
   auto& f = ctx->fused;
-  if (f.nranks == 1) return launch_ypass(ctx, +1, narr, f.s + s0, f.s + s0, false, false);
+  if (!f.slab) return launch_ypass(ctx, +1, narr, f.s + s0, f.s + s0, false, false);
   for (int i = 0; i < narr; i++) KW_TRY(xstart(ctx, s0 + i, f.s[s0 + i], f.t[s0 + i]));
   for (int i = 0; i < narr; i++) KW_TRY(xwait(ctx, s0 + i));
   return launch_ypass(ctx, +1, narr, f.t + s0, f.s + s0, true, false);
@@ -1284,13 +1284,13 @@ kw_status alloc_scratch(kw_ctx* ctx, void* const s[3], void* const t[3])
     if (f.owns_scratch)
     {
       KW_HIP(hipMalloc(reinterpret_cast<void**>(&f.s[i]), elems * sizeof(float2)));
-      if (f.nranks > 1) KW_HIP(hipMalloc(reinterpret_cast<void**>(&f.t[i]), elems * sizeof(float2)));
+      if (f.slab) KW_HIP(hipMalloc(reinterpret_cast<void**>(&f.t[i]), elems * sizeof(float2)));
     }
     else
     {
-      KW_REQUIRE(s[i] != nullptr && (f.nranks == 1 || (t != nullptr && t[i] != nullptr)));
+      KW_REQUIRE(s[i] != nullptr && (!f.slab || (t != nullptr && t[i] != nullptr)));
       f.s[i] = static_cast<float2*>(s[i]);
-      f.t[i] = (f.nranks > 1) ? static_cast<float2*>(t[i]) : nullptr;
+      f.t[i] = (f.slab) ? static_cast<float2*>(t[i]) : nullptr;
     }
     KW_HIP(hipMemsetAsync(f.s[i], 0, elems * sizeof(float2), ctx->stream));
     if (f.t[i]) KW_HIP(hipMemsetAsync(f.t[i], 0, elems * sizeof(float2), ctx->stream));
@@ -1313,11 +1313,11 @@ kw_status create_impl(kw_ctx* ctx, void* const s[3], void* const t[3])
   const auto slab = ctx->fused;
   kw_fused_destroy(ctx);
   auto& f = ctx->fused;
-  f.nranks = slab.nranks; f.rank = slab.rank; f.exchange = slab.exchange; f.exchange_user = slab.exchange_user;
+  f.slab = slab.slab; f.nranks = slab.nranks; f.rank = slab.rank; f.exchange = slab.exchange; f.exchange_user = slab.exchange_user;
   f.exchange_start = slab.exchange_start; f.exchange_wait = slab.exchange_wait;
   KW_HIP(hipSetDevice(ctx->device));
   const kw_constants& c = ctx->c;
-  f.nz_global = (f.nranks > 1) ? slab.nz_global : c.nz;
+  f.nz_global = (f.slab) ? slab.nz_global : c.nz;
   f.nyl       = c.ny / f.nranks;
   f.P         = (c.nx_complex + NLMAX - 1) / NLMAX * NLMAX;
   KW_TRY(alloc_scratch(ctx, s, t));
@@ -1358,6 +1358,7 @@ kw_status kw_fused_set_slab(kw_ctx* ctx, uint32_t nranks, uint32_t rank, uint32_
   KW_REQUIRE(nranks >= 1 && rank < nranks);
   KW_REQUIRE(nranks == 1 || fn != nullptr);
   if (ctx->fused.ready) { kw_set_error("kw_fused_set_slab: must be called before kw_fused_create"); return KW_ERR_STATE; }
+  ctx->fused.slab          = (nranks > 1) || (fn != nullptr); // one rank with an exchange = the slab path against itself
   ctx->fused.nranks        = nranks;
   ctx->fused.rank          = rank;
   ctx->fused.nz_global     = nz_global;
@@ -1382,9 +1383,9 @@ kw_status kw_fused_supported(kw_ctx* ctx, int* out)
   KW_REQUIRE(out != nullptr);
   const kw_constants& c = ctx->c;
   const auto& f         = ctx->fused;
-  const uint32_t nzg    = (f.nranks > 1) ? f.nz_global : c.nz;
+  const uint32_t nzg    = (f.slab) ? f.nz_global : c.nz;
   bool ok = supported_len(c.nx) && supported_len(c.ny) && supported_len(nzg) && ((c.ny * c.nz) % (2 * NLMAX) == 0);
-  if (f.nranks > 1) ok = ok && (nzg == c.nz * f.nranks) && (c.ny % f.nranks == 0);
+  if (f.slab) ok = ok && (nzg == c.nz * f.nranks) && (c.ny % f.nranks == 0);
   const uint64_t P64 = (c.nx_complex + NLMAX - 1) / NLMAX * NLMAX;
   ok = ok && (P64 * c.ny * c.nz < (1ull << 32)) && (static_cast<uint64_t>(c.nx) * c.ny * c.nz < (1ull << 32));
   *out = ok ? 1 : 0;
@@ -1472,7 +1473,7 @@ kw_status kw_fused_velocity(kw_ctx* ctx, const float* p, float* ux, float* uy, f
   const float* dt[3] = { dtx, dty, dtz };
   const float* pml[3] = { pmlx, pmly, pmlz };
   for (int i = 0; i < 3; i++) { x.in[i] = S[i]; x.out[i] = u[i]; x.m0[i] = dt[i]; x.m1[i] = pml[i]; x.fout[i] = S[i]; }
-  if (ctx->fused.nranks > 1)
+  if (ctx->fused.slab)
   { // slab mode: the three transposes back are pipelined against the y-inverse / x-inverse of the previous component
     auto& f = ctx->fused;
     for (int i = 0; i < 3; i++) KW_TRY(xstart(ctx, i, f.s[i], f.t[i]));
@@ -1553,7 +1554,7 @@ kw_status kw_fused_density(kw_ctx* ctx, int nonlinear, const float* ux, const fl
   for (int i = 0; i < 3; i++) { z.in[i] = S[i]; z.out[i] = S[i]; }
   z.op[0] = kappa_padded;
   z.dd[0] = (const float2*)ddx; z.dd[1] = (const float2*)ddy; z.dd[2] = (const float2*)ddz;
-  if (ctx->fused.nranks > 1)
+  if (ctx->fused.slab)
   {
     KW_TRY(slab_chain<Z_VGRAD>(ctx, 3, u_in_scratch ? nullptr : in3, z));
   }
@@ -1572,7 +1573,7 @@ kw_status kw_fused_density(kw_ctx* ctx, int nonlinear, const float* ux, const fl
     KW_TRY(forward_xy(ctx, 3, u_in_scratch ? nullptr : in3));
     KW_TRY(launch_zfused<Z_VGRAD>(ctx, 3, z));
   }
-  const bool tail_chunked = (ctx->fused.nranks == 1 && !ctx->fused.per_array);
+  const bool tail_chunked = (!ctx->fused.slab && !ctx->fused.per_array);
   XinvArgs x{};
   float* rho[3] = { rx, ry, rz };
   const float* pml[3] = { pmlx, pmly, pmlz };
@@ -1611,7 +1612,7 @@ kw_status kw_fused_absorption_pressure(kw_ctx* ctx, float* p, const float* vel_g
   for (int i = 0; i < 2; i++) { z.in[i] = S[i]; z.out[i] = S[i]; }
   z.op[0] = nabla1_padded;
   z.op[1] = nabla2_padded;
-  if (ctx->fused.nranks > 1)
+  if (ctx->fused.slab)
   {
     KW_TRY(slab_chain<Z_ABSORB>(ctx, 2, terms_in_scratch ? nullptr : in2, z));
   }
@@ -1635,7 +1636,7 @@ kw_status kw_fused_absorption_pressure(kw_ctx* ctx, float* p, const float* vel_g
   x.out[0] = p;
   x.m0[0] = first; x.m0[1] = c2;
   x.m1[0] = tau;   x.m1[1] = eta;
-  if (ctx->fused.nranks == 1 && !ctx->fused.per_array) KW_TRY((plane_local_tail<EPI_PSUM, false>(ctx, 2, 1, x, 0)));
+  if (!ctx->fused.slab && !ctx->fused.per_array) KW_TRY((plane_local_tail<EPI_PSUM, false>(ctx, 2, 1, x, 0)));
   else KW_TRY(launch_xinv<EPI_PSUM>(ctx, 1, x));
   return KW_OK;
 }
@@ -1669,7 +1670,7 @@ kw_status kw_fused_probe(kw_ctx* ctx, int which, const float* op)
 {
   KW_FUSED_READY(ctx);
   auto& f = ctx->fused;
-  KW_REQUIRE(f.nranks == 1);
+  KW_REQUIRE(!f.slab);
   const kw_constants& c = ctx->c;
   if (which == 0) return launch_ypass(ctx, -1, 1, f.s, f.s, false, false);
   if (which == 3) return launch_ypass(ctx, -1, 3, f.s, f.s, false, false);

@@ -50,6 +50,7 @@ struct kw_ctx
     // Z-slab decomposition (multi-GPU): this context owns nz = nz_global/nranks planes of the real-space arrays and,
     // after the all-to-all transpose, nyl = ny/nranks rows of every spectrum with all nz_global planes.
     uint32_t nranks = 1, rank = 0, nz_global = 0, nyl = 0;
+    bool     slab   = false;                       // transposed z-pass + exchange (nranks > 1, or one rank exchanging with itself)
     float2*  t[3]  = {nullptr, nullptr, nullptr};  // exchange partners of s[] (slab mode only)
     bool     owns_scratch = true;
     kw_exchange_fn exchange = nullptr;             // all-to-all over the ranks (RCCL via the caller)

@@ -108,6 +108,7 @@ class SlabExchange:
         self.ctx = None
         self.stream = None
         self._host: Dict[int, tuple] = {}
+        self._view_cache: Dict[tuple, tuple] = {}
         self.callback = self.CB(self._exchange)
         self.calls = 0
         # split-phase form (RCCL only): the transpose of one array is in flight while other arrays compute
@@ -127,35 +128,41 @@ class SlabExchange:
         return ptrs
 
     def bind(self, ctx, stream=None):
-        """ctx: kw_ctx* of the solver; stream: torch stream every launch of the solver is moved to (nccl ordering)."""
+        """ctx: kw_ctx* of the solver; stream: torch stream every launch of the solver is moved to (nccl ordering).
+        The stream also becomes torch's current stream of this thread, so the collectives below are ordered after the
+        kernels already enqueued without a per-call stream context."""
         self.ctx = ctx
         self.stream = stream
         if stream is not None:
             capi.check(capi.load().kw_set_stream(ctx, C.c_void_p(stream.cuda_stream)))
+            self.torch.cuda.set_stream(stream)
+
+    def _views(self, send, recv, n):
+        key = (send, recv, n)
+        v = self._view_cache.get(key)
+        if v is None:
+            v = (self.tensors[send][: n // 4], self.tensors[recv][: n // 4])
+            self._view_cache[key] = v
+        return v
 
     def _start(self, user, send, recv, bytes_per_peer, slot):
         """all_to_all_single(async_op=True): the RCCL stream waits for the work enqueued so far on the solver's stream
         and the call returns; later launches on the solver's stream overlap with the collective."""
         self.calls += 1
-        torch, dist = self.torch, self.dist
-        n = bytes_per_peer * self.nranks
-        src, dst = self.tensors[send], self.tensors[recv]
-        with torch.cuda.stream(self.stream):
-            self.works[slot] = dist.all_to_all_single(dst[: n // 4], src[: n // 4], async_op=True)
+        src, dst = self._views(send, recv, bytes_per_peer * self.nranks)
+        self.works[slot] = self.dist.all_to_all_single(dst, src, async_op=True)
 
     def _wait(self, user, slot):
         """work.wait(): the solver's stream waits for the collective (the host does not block)."""
-        with self.torch.cuda.stream(self.stream):
-            self.works.pop(slot).wait()
+        self.works.pop(slot).wait()
 
     def _exchange(self, user, send, recv, bytes_per_peer):
         self.calls += 1
         torch, dist = self.torch, self.dist
         n = bytes_per_peer * self.nranks
         if self.backend == "nccl":
-            src, dst = self.tensors[send], self.tensors[recv]
-            with torch.cuda.stream(self.stream):
-                dist.all_to_all_single(dst[: n // 4], src[: n // 4])
+            src, dst = self._views(send, recv, n)
+            dist.all_to_all_single(dst, src)
             return
         # gloo (ranks sharing one GPU, tests): stage through pinned host memory
         hip = capi.load()

@@ -28,7 +28,7 @@ void Parameters::init(const InputProvider& in, const Options& options)
   mFullDimensionSizes    = DimensionSizes(x, y, z);
   mReducedDimensionSizes = DimensionSizes((x / 2) + 1, y, z);
   mGlobalDimensionSizes  = mFullDimensionSizes;
-  if (mOptions.slabRanks > 1)
+  if (isSlabDecomposed())
   {
     if (mOptions.nzGlobal != z * mOptions.slabRanks || mOptions.slabRank >= mOptions.slabRanks || y % mOptions.slabRanks != 0)
       throw std::invalid_argument("Z-slab decomposition: Nz_global must equal slabRanks * local Nz and Ny must divide by slabRanks");

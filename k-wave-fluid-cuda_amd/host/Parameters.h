@@ -81,7 +81,7 @@ class Parameters
   DimensionSizes getGlobalDimensionSizes() const { return mGlobalDimensionSizes; }
   size_t getSlabRanks() const { return mOptions.slabRanks; }
   size_t getSlabRank() const { return mOptions.slabRank; }
-  bool   isSlabDecomposed() const { return mOptions.slabRanks > 1; }
+  bool   isSlabDecomposed() const { return mOptions.slabRanks > 1 || mOptions.exchangeFn != nullptr; }
   DimensionSizes getReducedDimensionSizes() const { return mReducedDimensionSizes; }
   bool           isSimulation3D() const { return mGlobalDimensionSizes.is3D(); }
   bool           isSimulation2D() const { return mGlobalDimensionSizes.is2D(); }
