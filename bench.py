@@ -56,6 +56,20 @@ def alg_bytes(n: int, *, het=True, nonlinear=True, absorbing=True):
     per["fused_density"] = (6 * (R + Cx) + per["compute_velocity_gradient"] + per["compute_density_nonlinear"]
                             + (terms if absorbing else 0))
     per["fused_absorption_pressure"] = 4 * (R + Cx) + per["compute_absorbtion_term"] + per["sum_pressure_terms"]
+    # kernels of the fused pipeline (kw_fused.hip): every array a kernel has to read or write, once
+    nl = int(nonlinear)
+    for na in (1, 2, 3):
+        per[f"k_xfwd[{na}]"] = na * (R + Cx)
+        per[f"k_ypass_fwd[{na}]"] = per[f"k_ypass_inv[{na}]"] = 2 * na * Cx
+        per[f"k_zfused_vgrad[{na}]"] = 2 * na * Cx + K
+        per[f"k_zfused_absorb[{na}]"] = na * (2 * Cx + K)
+    per["k_zfused_pgrad"] = 4 * Cx + K
+    per["k_zfused_source"] = 2 * Cx + K
+    per["k_xinv_velocity"] = 3 * Cx + (6 + 3 * h) * R
+    per["k_xinv_velocity_chain"] = per["k_xinv_velocity"] + 3 * Cx
+    per["k_xinv_density"] = 3 * Cx + (6 + h) * R + ((h * nl + 1 + 2) * R if absorbing else 0)
+    per["k_xinv_density_chain"] = 3 * Cx + (6 + h) * R + (h * nl + 1) * R + 2 * Cx
+    per["k_xinv_psum"] = 2 * Cx + (2 + 3 * h) * R
     n_fft = 10 + 4 * int(absorbing)
     b = n_fft * (R + Cx) + per["compute_pressure_gradient"] + per["compute_velocity"] + per["compute_velocity_gradient"]
     b += per["compute_density_nonlinear"]
@@ -213,14 +227,30 @@ def main():
         table[name] = {"calls_per_step": calls / P, "avg_ms": round(avg, 4),
                        "ms_per_step": round(total_ms / P, 4),
                        "alg_gbs": round(ab / (avg * 1e-3) / 1e9, 1) if ab else None}
-    dom = max((k for k in table if per.get(k)), key=lambda k: table[k]["ms_per_step"])
+        if name.startswith("fused_"):  # stage boundaries of the pipeline differ from the reference's (chained passes)
+            table[name]["alg_gbs"] = None
+    # dominant GPU kernel (fused pipeline: the "k_*" records; granular path: one kernel per entry point)
+    kernels = [k for k in table if per.get(k) and (k.startswith("k_") or args.granular)]
+    dom = max(kernels, key=lambda k: table[k]["ms_per_step"])
     achieved = per[dom] / (table[dom]["avg_ms"] * 1e-3) / 1e9
-    roofline = {"bound": "hbm", "kernel": "kw_" + dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+    traffic, traffic_src = None, None
+    pmc_file = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    if n == 256 and not args.granular and os.path.exists(pmc_file):
+        pmc = json.load(open(pmc_file))
+        traffic = pmc.get("traffic_bytes_per_bench_kernel", {}).get(dom)
+        traffic_src = ("profiles/r01_pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) of this "
+                       "workload, 128-B read requests counted x2 (gfx950 correction, checked on probe kernels of known size)")
+        step_traffic = pmc.get("traffic_bytes_per_step")
+    else:
+        step_traffic = None
+    roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                "traffic_source": traffic_src,
                 "alg_bytes_per_launch": per[dom], "avg_ms": table[dom]["avg_ms"],
                 "step": {"alg_bytes": b_step, "achieved": round(b_step / (ms * 1e-3 / K) / 1e9, 1),
-                         "frac": round(b_step / (ms * 1e-3 / K) / 1e9 / HBM_PEAK_GBS, 4)},
-                "entry_points": table}
+                         "frac": round(b_step / (ms * 1e-3 / K) / 1e9 / HBM_PEAK_GBS, 4), "traffic": step_traffic},
+                "entry_points": {k: v for k, v in table.items() if not k.startswith("k_")},
+                "kernels": {k: v for k, v in table.items() if k.startswith("k_")}}
     info = capi.DeviceInfo()
     capi.check(hip.kw_device_info_get(sim.ctx, info))
     sim.close()

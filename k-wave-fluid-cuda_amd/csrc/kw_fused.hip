@@ -1079,6 +1079,8 @@ bool supported_len(uint32_t n) { return n == 16 || n == 32 || n == 64 || n == 12
 kw_status launch_xfwd(kw_ctx* ctx, int narr, const float* const* in, float2* const* out)
 {
   const kw_constants& c = ctx->c;
+  static const char* const names[3] = { "k_xfwd[1]", "k_xfwd[2]", "k_xfwd[3]" };
+  KW_PROF(ctx, names[narr - 1]);
   XfwdArgs a{};
   for (int i = 0; i < narr; i++) { a.in[i] = in[i]; a.out[i] = out[i]; }
   a.tw = ctx->fused.tw[0];
@@ -1098,6 +1100,9 @@ kw_status launch_ypass(kw_ctx* ctx, int dir, int narr, float2* const* in, float2
 {
   const kw_constants& c = ctx->c;
   const auto& f = ctx->fused;
+  static const char* const names[2][3] = { { "k_ypass_fwd[1]", "k_ypass_fwd[2]", "k_ypass_fwd[3]" },
+                                           { "k_ypass_inv[1]", "k_ypass_inv[2]", "k_ypass_inv[3]" } };
+  KW_PROF(ctx, names[dir < 0 ? 0 : 1][narr - 1]);
   PassArgs a{};
   for (int i = 0; i < narr; i++) { a.in[i] = in[i]; a.out[i] = out[i]; }
   a.tw  = f.tw[1];
@@ -1138,6 +1143,11 @@ template<int MODE> kw_status launch_zfused(kw_ctx* ctx, int narr, ZArgs a)
 {
   const kw_constants& c = ctx->c;
   const auto& f = ctx->fused;
+  static const char* const names[4][3] = { { "k_zfused_pgrad", "k_zfused_pgrad", "k_zfused_pgrad" },
+                                           { "k_zfused_vgrad[1]", "k_zfused_vgrad[2]", "k_zfused_vgrad[3]" },
+                                           { "k_zfused_absorb[1]", "k_zfused_absorb[2]", "k_zfused_absorb[3]" },
+                                           { "k_zfused_source", "k_zfused_source", "k_zfused_source" } };
+  KW_PROF(ctx, names[MODE][narr - 1]);
   a.tw      = f.tw[2];
   a.divider = c.fft_divider;
   a.nxc     = c.nx_complex;
@@ -1161,6 +1171,10 @@ template<int MODE> kw_status launch_zfused(kw_ctx* ctx, int narr, ZArgs a)
 template<int EPI, bool CHAIN = false> kw_status launch_xinv(kw_ctx* ctx, int ncomp, XinvArgs a, uint32_t z0 = 0, uint32_t nzc = 0)
 {
   const kw_constants& c = ctx->c;
+  static const char* const names[5][2] = { { "k_xinv_store", "k_xinv_store" }, { "k_xinv_velocity", "k_xinv_velocity_chain" },
+                                           { "k_xinv_initvel", "k_xinv_initvel" }, { "k_xinv_density", "k_xinv_density_chain" },
+                                           { "k_xinv_psum", "k_xinv_psum" } };
+  KW_PROF(ctx, names[EPI][CHAIN ? 1 : 0]);
   a.tw = ctx->fused.tw[0];
   a.c  = c;
   a.P  = ctx->fused.P;

@@ -87,15 +87,54 @@ def main():
     # measured on this build's own probes (8 B/lane tile loads and 16 B/lane flat loads)
     r8 = calib.get("k_probe_tile<256, 0>", {}).get("fetch_ratio")
     r16 = calib.get("k_probe_copy4", {}).get("fetch_ratio")
+    # true read bytes: 128-B requests are tallied at 64 B (x2), 64-B requests (the 4-B-per-lane operator reads of the
+    # z-fused kernels, 16 lanes per row segment) are tallied exactly
+    op_bytes = 4 * P * n * n  # one padded reduced real operator
+    op_reads = {"k_zfused<256, 0>": 1, "k_zfused<256, 1>": 1, "k_zfused<256, 2>": 2, "k_zfused<256, 3>": 1}
+    steps = None
     table = []
     for k in f256:
         if k not in w256:
             continue
-        table.append({"kernel": k, "launches": f256[k][0], "FETCH_SIZE_bytes": f256[k][1], "WRITE_SIZE_bytes": w256[k][1]})
-    res = {"grid": [n, n, n], "calibration": calib, "fetch_ratio_8B_per_lane": r8, "fetch_ratio_16B_per_lane": r16,
-           "per_kernel_launch": table}
+        nops = op_reads.get(k, 0) * op_bytes
+        rd = 2.0 * (f256[k][1] - nops) + nops
+        table.append({"kernel": k, "launches": f256[k][0], "FETCH_SIZE_bytes": round(f256[k][1]),
+                      "WRITE_SIZE_bytes": round(w256[k][1]), "read_bytes_corrected": round(rd),
+                      "traffic_bytes": round(rd + w256[k][1])})
+        if k == "k_xinv<256, 3, true>":
+            steps = f256[k][0]
+    by = {t["kernel"]: t for t in table}
+    per_step = sum(t["traffic_bytes"] * t["launches"] for t in table if t["kernel"].startswith("k_") and
+                   not t["kernel"].startswith(("k_import", "k_add_initial", "k_xinv<256, 2"))) / max(steps or 1, 1)
+
+    def per_array(kernel, arrays_per_step):
+        t = by.get(kernel)
+        return t["traffic_bytes"] * t["launches"] / steps / arrays_per_step if t else 0.0
+    yf, yi = per_array("k_ypass<256, -1, false, false>", 6), per_array("k_ypass<256, 1, false, false>", 8)
+    g = lambda k: by.get(k, {}).get("traffic_bytes", 0)
+    entry = {
+        "fused_velocity": g("k_xfwd<256>") + yf + g("k_zfused<256, 0>") + 3 * yi + 3 * g("k_xinv<256, 1, true>") / 1 + 3 * yf,
+        "fused_density": g("k_zfused<256, 1>") + 3 * yi + g("k_xinv<256, 3, true>") + 2 * yf,
+        "fused_absorption_pressure": g("k_zfused<256, 2>") + 2 * yi + g("k_xinv<256, 4, false>"),
+    }
+    # k_xinv<256,1,true> is launched once per step with grid.y = 3: its per-launch figure already covers 3 components
+    entry["fused_velocity"] = g("k_xfwd<256>") + yf + g("k_zfused<256, 0>") + 3 * yi + g("k_xinv<256, 1, true>") + 3 * yf
+    bench_names = {"k_xfwd[1]": g("k_xfwd<256>"), "k_zfused_pgrad": g("k_zfused<256, 0>"),
+                   "k_zfused_vgrad[3]": g("k_zfused<256, 1>"), "k_zfused_absorb[2]": g("k_zfused<256, 2>"),
+                   "k_xinv_velocity_chain": g("k_xinv<256, 1, true>"), "k_xinv_density_chain": g("k_xinv<256, 3, true>"),
+                   "k_xinv_psum": g("k_xinv<256, 4, false>")}
+    for na in (1, 2, 3):
+        bench_names[f"k_ypass_fwd[{na}]"] = na * yf
+        bench_names[f"k_ypass_inv[{na}]"] = na * yi
+    res = {"grid": [n, n, n], "units": "bytes per kernel launch; traffic = corrected reads + WRITE_SIZE",
+           "calibration": calib, "fetch_ratio_8B_per_lane": r8, "fetch_ratio_16B_per_lane": r16,
+           "per_kernel_launch": table, "steps_profiled": steps, "traffic_bytes_per_step": round(per_step),
+           "traffic_bytes_per_entry_point": {k: round(v) for k, v in entry.items()},
+           "traffic_bytes_per_bench_kernel": {k: round(v) for k, v in bench_names.items()}}
     json.dump(res, open(os.path.join(dst, f"{rnd}_pmc_traffic.json"), "w"), indent=1)
-    print(json.dumps(res, indent=1)[:3000])
+    print(json.dumps({k: res[k] for k in ("traffic_bytes_per_step", "traffic_bytes_per_entry_point", "steps_profiled")}, indent=1))
+    for t in table:
+        print(f"{t['kernel']:42s} n={t['launches']:3d} traffic={t['traffic_bytes'] / 1e6:8.1f} MB")
 
 
 if __name__ == "__main__":
