@@ -70,6 +70,7 @@ def alg_bytes(n: int, *, het=True, nonlinear=True, absorbing=True):
     per["k_xinv_density"] = 3 * Cx + (6 + h) * R + ((h * nl + 1 + 2) * R if absorbing else 0)
     per["k_xinv_density_chain"] = 3 * Cx + (6 + h) * R + (h * nl + 1) * R + 2 * Cx
     per["k_xinv_psum"] = 2 * Cx + (2 + 3 * h) * R
+    per["k_xinv_psum_chain"] = per["k_xinv_psum"] + Cx
     n_fft = 10 + 4 * int(absorbing)
     b = n_fft * (R + Cx) + per["compute_pressure_gradient"] + per["compute_velocity"] + per["compute_velocity_gradient"]
     b += per["compute_density_nonlinear"]

@@ -294,9 +294,13 @@ KW_API kw_status kw_fused_velocity(kw_ctx* ctx, const float* p, float* ux_sgx, f
                                    const float* pml_x_sgx, const float* pml_y_sgy, const float* pml_z_sgz,
                                    const float* kappa_padded, const float* ddx_k_shift_pos,
                                    const float* ddy_k_shift_pos, const float* ddz_k_shift_pos, int chain_u_spectra);
-/* chain_u_spectra != 0: the kernel that updates u also forward-transforms the updated rows along x into the pipeline's
- * scratch, so kw_fused_density(flags & KW_FUSED_U_IN_SCRATCH) skips re-reading u.  Only valid when nothing else
- * (velocity / transducer source injection) writes u in between. */
+/* chain_u_spectra & KW_FUSED_CHAIN_U: the kernel that updates u also forward-transforms the updated rows along x into the
+ * pipeline's scratch, so kw_fused_density(flags & KW_FUSED_U_IN_SCRATCH) skips re-reading u.  Only valid when nothing
+ * else (velocity / transducer source injection) writes u in between.
+ * chain_u_spectra & KW_FUSED_P_IN_SCRATCH: the spectrum of p was left in scratch by the previous
+ * kw_fused_absorption_pressure(flags & KW_FUSED_CHAIN_P) and p has not been written since; p is not read. */
+#define KW_FUSED_CHAIN_U       1
+#define KW_FUSED_P_IN_SCRATCH  2
 #define KW_FUSED_U_IN_SCRATCH 1 /* kw_fused_density: x-spectra of ux,uy,uz are already in scratch */
 #define KW_FUSED_CHAIN_TERMS  2 /* kw_fused_density: chain the x-spectra of rho0*sum(du) and sum(rho) into scratch for
                                    kw_fused_absorption_pressure(terms_in_scratch = 1); only the term the pressure sum
@@ -323,7 +327,9 @@ KW_API kw_status kw_fused_density(kw_ctx* ctx, int nonlinear, const float* ux_sg
 KW_API kw_status kw_fused_absorption_pressure(kw_ctx* ctx, float* p, const float* velocity_gradient_term,
                                               const float* density_sum, const float* first,
                                               const float* nabla1_padded, const float* nabla2_padded, const float* c2,
-                                              const float* absorb_tau, const float* absorb_eta, int terms_in_scratch);
+                                              const float* absorb_tau, const float* absorb_eta, int flags);
+#define KW_FUSED_TERMS_IN_SCRATCH 1 /* kw_fused_absorption_pressure: the two terms' spectra were chained by kw_fused_density */
+#define KW_FUSED_CHAIN_P          2 /* ... and the kernel that writes p forward-transforms it for the next kw_fused_velocity */
 /* tuning probe: one pass of the pipeline over its scratch (0 y-pass, 1 line pass along z, 2 z-fused, 3 y-pass x3) */
 KW_API kw_status kw_fused_probe(kw_ctx* ctx, int which, const float* padded_reduced_operator);
 /* FFT part of scaleSource (KSpaceFirstOrderSolver.cpp:2346-2351; .cu:740-745), in place on scaled_source */

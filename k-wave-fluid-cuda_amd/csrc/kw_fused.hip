@@ -962,6 +962,7 @@ template<int L, int EPI, bool CHAIN> __global__ __launch_bounds__(Geo<L>::THREAD
       for (int t = 0; t < 4; t++)
         f4put(o, t, f4get(c24, t) * (f4get(fi, t) + (k.fft_divider * ((f4get(tt, t) * f4get(tau4, t)) - (f4get(et, t) * f4get(eta4, t))))));
       st4(a.out[0] + i, o);
+      if constexpr (CHAIN) fw[0][q] = o;
     }
   }
 
@@ -1173,7 +1174,7 @@ template<int EPI, bool CHAIN = false> kw_status launch_xinv(kw_ctx* ctx, int nco
   const kw_constants& c = ctx->c;
   static const char* const names[5][2] = { { "k_xinv_store", "k_xinv_store" }, { "k_xinv_velocity", "k_xinv_velocity_chain" },
                                            { "k_xinv_initvel", "k_xinv_initvel" }, { "k_xinv_density", "k_xinv_density_chain" },
-                                           { "k_xinv_psum", "k_xinv_psum" } };
+                                           { "k_xinv_psum", "k_xinv_psum_chain" } };
   KW_PROF(ctx, names[EPI][CHAIN ? 1 : 0]);
   a.tw = ctx->fused.tw[0];
   a.c  = c;
@@ -1475,7 +1476,9 @@ kw_status kw_fused_velocity(kw_ctx* ctx, const float* p, float* ux, float* uy, f
   KW_REQUIRE((dtx == nullptr) == (dty == nullptr) && (dtx == nullptr) == (dtz == nullptr));
   float2** S = ctx->fused.s;
   const float* in1[1] = { p };
-  KW_TRY(forward_xy(ctx, 1, in1));
+  const bool p_in_scratch = (chain_u_spectra & KW_FUSED_P_IN_SCRATCH) != 0;
+  chain_u_spectra &= KW_FUSED_CHAIN_U;
+  KW_TRY(forward_xy(ctx, 1, p_in_scratch ? nullptr : in1));
   ZArgs z{};
   z.in[0] = S[0];
   for (int i = 0; i < 3; i++) z.out[i] = S[i];
@@ -1613,8 +1616,10 @@ kw_status kw_fused_density(kw_ctx* ctx, int nonlinear, const float* ux, const fl
 // A11 absorbing branch after the terms: p = c2*(first + d*(tau*ifftn(nabla1*fftn(vel_grad_term)) - eta*ifftn(nabla2*fftn(density_sum))))
 kw_status kw_fused_absorption_pressure(kw_ctx* ctx, float* p, const float* vel_grad_term, const float* density_sum,
                                        const float* first, const float* nabla1_padded, const float* nabla2_padded,
-                                       const float* c2, const float* tau, const float* eta, int terms_in_scratch)
+                                       const float* c2, const float* tau, const float* eta, int flags)
 {
+  const bool terms_in_scratch = (flags & KW_FUSED_TERMS_IN_SCRATCH) != 0;
+  const bool chain_p          = (flags & KW_FUSED_CHAIN_P) != 0;
   KW_FUSED_READY(ctx);
   KW_PROF(ctx, "fused_absorption_pressure");
   KW_REQUIRE(p && first && nabla1_padded && nabla2_padded);
@@ -1650,7 +1655,13 @@ kw_status kw_fused_absorption_pressure(kw_ctx* ctx, float* p, const float* vel_g
   x.out[0] = p;
   x.m0[0] = first; x.m0[1] = c2;
   x.m1[0] = tau;   x.m1[1] = eta;
-  if (!ctx->fused.slab && !ctx->fused.per_array) KW_TRY((plane_local_tail<EPI_PSUM, false>(ctx, 2, 1, x, 0)));
+  x.fout[0] = S[0]; // chained: x-spectrum of the new p
+  if (!ctx->fused.slab && !ctx->fused.per_array)
+  {
+    if (chain_p) KW_TRY((plane_local_tail<EPI_PSUM, true>(ctx, 2, 1, x, 1)));
+    else KW_TRY((plane_local_tail<EPI_PSUM, false>(ctx, 2, 1, x, 0)));
+  }
+  else if (chain_p) KW_TRY((launch_xinv<EPI_PSUM, true>(ctx, 1, x)));
   else KW_TRY(launch_xinv<EPI_PSUM>(ctx, 1, x));
   return KW_OK;
 }

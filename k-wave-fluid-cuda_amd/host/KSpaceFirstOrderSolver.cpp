@@ -138,6 +138,7 @@ template<SD sd> void KSpaceFirstOrderSolver::computeMainLoop()
 void KSpaceFirstOrderSolver::runTimeSteps(size_t nSteps)
 {
   prepare();
+  mPressureInScratch = false;
   for (size_t s = 0; s < nSteps && mParameters.getTimeIndex() < mParameters.getNt(); s++)
   {
     const size_t timeIndex = mParameters.getTimeIndex();
@@ -193,7 +194,9 @@ template<SD sd> void KSpaceFirstOrderSolver::computeVelocity()
                               real(MI::kPmlZSgz).getDeviceData(), mKappaPadded,
                               c.getMatrix<ComplexMatrix>(MI::kDdxKShiftPosR).getDeviceData(),
                               c.getMatrix<ComplexMatrix>(MI::kDdyKShiftPos).getDeviceData(),
-                              c.getMatrix<ComplexMatrix>(MI::kDdzKShiftPos).getDeviceData(), mVelocityChained ? 1 : 0));
+                              c.getMatrix<ComplexMatrix>(MI::kDdzKShiftPos).getDeviceData(),
+                              (mVelocityChained ? KW_FUSED_CHAIN_U : 0) | (mPressureInScratch ? KW_FUSED_P_IN_SCRATCH : 0)));
+    mPressureInScratch = false;
     return;
   }
   getTempHipFftX().computeR2CFftND(getP());
@@ -270,12 +273,17 @@ template<SD sd> void KSpaceFirstOrderSolver::computePressureNonlinear()
       SolverHipKernels::computePressureTermsNonlinear<sd>(densitySum, nonlinearTerm, velocityGradientSum, mMatrixContainer);
     if (mFused)
     {
+      // the kernel that writes p also leaves its spectrum for the next step's velocity stage, unless p is about to be
+      // overwritten by the initial pressure source (step 0)
+      const bool chainP = !((mParameters.getTimeIndex() == 0) && (mParameters.getInitialPressureSourceFlag() == 1));
       kwCheck(kw_fused_absorption_pressure(mParameters.getHipParameters().getContext(), getP().getDeviceData(),
                                            velocityGradientSum.getDeviceData(), densitySum.getDeviceData(),
                                            nonlinearTerm.getDeviceData(), mNabla1Padded, mNabla2Padded,
                                            mMatrixContainer.realDeviceOrNull(MI::kC2),
                                            mMatrixContainer.realDeviceOrNull(MI::kAbsorbTau),
-                                           mMatrixContainer.realDeviceOrNull(MI::kAbsorbEta), mTermsFused ? 1 : 0));
+                                           mMatrixContainer.realDeviceOrNull(MI::kAbsorbEta),
+                                           (mTermsFused ? KW_FUSED_TERMS_IN_SCRATCH : 0) | (chainP ? KW_FUSED_CHAIN_P : 0)));
+      mPressureInScratch = chainP;
       return;
     }
     getTempHipFftX().computeR2CFftND(velocityGradientSum);
@@ -303,12 +311,17 @@ template<SD sd> void KSpaceFirstOrderSolver::computePressureLinear()
       SolverHipKernels::computePressureTermsLinear<sd>(densitySum, velocityGradientTerm, mMatrixContainer);
     if (mFused)
     {
+      // the kernel that writes p also leaves its spectrum for the next step's velocity stage, unless p is about to be
+      // overwritten by the initial pressure source (step 0)
+      const bool chainP = !((mParameters.getTimeIndex() == 0) && (mParameters.getInitialPressureSourceFlag() == 1));
       kwCheck(kw_fused_absorption_pressure(mParameters.getHipParameters().getContext(), getP().getDeviceData(),
                                            velocityGradientTerm.getDeviceData(), densitySum.getDeviceData(),
                                            densitySum.getDeviceData(), mNabla1Padded, mNabla2Padded,
                                            mMatrixContainer.realDeviceOrNull(MI::kC2),
                                            mMatrixContainer.realDeviceOrNull(MI::kAbsorbTau),
-                                           mMatrixContainer.realDeviceOrNull(MI::kAbsorbEta), mTermsFused ? 1 : 0));
+                                           mMatrixContainer.realDeviceOrNull(MI::kAbsorbEta),
+                                           (mTermsFused ? KW_FUSED_TERMS_IN_SCRATCH : 0) | (chainP ? KW_FUSED_CHAIN_P : 0)));
+      mPressureInScratch = chainP;
       return;
     }
     getTempHipFftX().computeR2CFftND(velocityGradientTerm);
