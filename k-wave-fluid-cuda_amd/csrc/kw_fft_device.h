@@ -51,8 +51,14 @@ __device__ constexpr float kSin64[64] = {
   -0.70710678118654752440f, -0.63439328416364549822f, -0.55557023301960222474f, -0.47139673682599764856f,
   -0.38268343236508977173f, -0.29028467725446236764f, -0.19509032201612826785f, -0.09801714032956060199f };
 
+#ifdef KW_PK
+// complex values as 64-bit register pairs: one v_pk_add_f32 per complex add
+__device__ __forceinline__ float2 cadd(float2 a, float2 b) { return a + b; }
+__device__ __forceinline__ float2 csub(float2 a, float2 b) { return a - b; }
+#else
 __device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
 __device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
+#endif
 __device__ __forceinline__ float2 cmulf(float2 a, float2 b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
 __device__ __forceinline__ float2 cconj(float2 a) { return make_float2(a.x, -a.y); }
 
@@ -66,7 +72,11 @@ template<int R, int K, int DIR> __device__ __forceinline__ float2 mul_const_tw(f
   if (idx == 48) return (DIR < 0) ? make_float2(-a.y, a.x) : make_float2(a.y, -a.x);
   const float c = kCos64[idx];
   const float s = (DIR < 0) ? -kSin64[idx] : kSin64[idx];
+#if defined(KW_PK) && KW_PK >= 2
+  return a * make_float2(c, c) + make_float2(-a.y, a.x) * make_float2(s, s);
+#else
   return make_float2(a.x * c - a.y * s, a.x * s + a.y * c);
+#endif
 }
 
 // natural-order in, natural-order out DFT of compile-time size R (power of two <= 64) on registers
