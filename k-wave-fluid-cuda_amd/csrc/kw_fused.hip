@@ -109,6 +109,7 @@ struct PassArgs
   float2*       out[3];
   const float2* tw;
   uint32_t      nxc, P;
+  uint32_t      PX;   // row pitch of the packed (exchange) side: rows travel without their padding
   uint32_t      narr; // arrays per block (grid.z * narr arrays in the launch)
   uint32_t      z0;   // first plane of this launch (chunked plane-local passes)
   RowAddr       ain, aout;
@@ -136,7 +137,7 @@ __global__ __launch_bounds__(Geo<L>::THREADS) void k_ypass(PassArgs a)
     if (PIN)
     {
 #pragma unroll
-      for (int n1 = 0; n1 < R1; n1++) v[n1] = Sin[a.ain.row(z, n1 * R2 + j) * a.P + kxl];
+      for (int n1 = 0; n1 < R1; n1++) v[n1] = Sin[a.ain.row(z, n1 * R2 + j) * a.PX + kxl];
     }
     else
     {
@@ -174,7 +175,7 @@ __global__ __launch_bounds__(Geo<L>::THREADS) void k_ypass(PassArgs a)
         if (POUT)
         {
 #pragma unroll
-          for (int k2 = 0; k2 < R2; k2++) Sout[a.aout.row(z, j + R1 * k2) * a.P + kx] = w[k2];
+          for (int k2 = 0; k2 < R2; k2++) Sout[a.aout.row(z, j + R1 * k2) * a.PX + kx] = w[k2];
         }
         else
         {
@@ -204,6 +205,7 @@ struct ZArgs
   const float2* tw;
   float         divider;
   uint32_t      nxc, P, ny, nz;
+  uint32_t      Pop;  // row pitch of the operator arrays (always padded; P is the unpadded exchange pitch in slab mode)
   uint32_t      arr0; // first array of this launch
   uint32_t      narr; // arrays processed back to back by each block (VGRAD / ABSORB)
   uint32_t      ky0;  // global ky of local row 0 (slab mode: rank * ny/nranks); ny above = number of LOCAL rows
@@ -255,6 +257,7 @@ template<int L, int MODE> __global__ __launch_bounds__(Geo<L>::THREADS) void k_z
   const uint32_t base   = ky * a.P + kx;
   const uint32_t kxl    = min(kx, a.nxc - 1u); // pad lanes re-read the last column; their results are never stored
   const uint32_t basel  = ky * a.P + kxl;
+  const uint32_t opbase = ky * a.Pop + kxl, opzstr = a.ny * a.Pop;
   constexpr bool MULTI  = (MODE == Z_VGRAD || MODE == Z_ABSORB);
   const uint32_t arr0   = MULTI ? a.arr0 : 0;
   const uint32_t narr   = MULTI ? a.narr : 1;
@@ -273,7 +276,7 @@ template<int L, int MODE> __global__ __launch_bounds__(Geo<L>::THREADS) void k_z
   {
     const float* __restrict__ op = a.op[(MODE == Z_ABSORB) ? arr0 : 0];
 #pragma unroll
-    for (int k2 = 0; k2 < R2; k2++) kap[k2] = op[basel + static_cast<uint32_t>(j + R1 * k2) * zstr];
+    for (int k2 = 0; k2 < R2; k2++) kap[k2] = op[opbase + static_cast<uint32_t>(j + R1 * k2) * opzstr];
   }
   lds_barrier(); // twiddle table visible (the loads above stay in flight across it)
 
@@ -317,10 +320,10 @@ template<int L, int MODE> __global__ __launch_bounds__(Geo<L>::THREADS) void k_z
       if (MODE == Z_ABSORB && ia + 1 < narr)
       {
         const float* __restrict__ op = a.op[arr + 1];
-        uint32_t lb = basel + static_cast<uint32_t>(j) * zstr;
+        uint32_t lb = opbase + static_cast<uint32_t>(j) * opzstr;
         asm volatile("" : "+v"(lb));
 #pragma unroll
-        for (int k2 = 0; k2 < R2; k2++) kap[k2] = op[lb + static_cast<uint32_t>(R1 * k2) * zstr];
+        for (int k2 = 0; k2 < R2; k2++) kap[k2] = op[lb + static_cast<uint32_t>(R1 * k2) * opzstr];
       }
     }
     lds_barrier(); // forward exchange buffer is free again
@@ -432,8 +435,8 @@ __global__ __launch_bounds__(Geo<L / 2>::THREADS) void k_ypass_split(PassArgs a)
 #pragma unroll
     for (int n1 = 0; n1 < R1; n1++)
     {
-      va[n1] = Sin[a.ain.row(z, n1 * R2 + j) * a.P + kxl];
-      vb[n1] = Sin[a.ain.row(z, H + n1 * R2 + j) * a.P + kxl];
+      va[n1] = Sin[a.ain.row(z, n1 * R2 + j) * a.PX + kxl];
+      vb[n1] = Sin[a.ain.row(z, H + n1 * R2 + j) * a.PX + kxl];
     }
   }
   else
@@ -466,8 +469,8 @@ __global__ __launch_bounds__(Geo<L / 2>::THREADS) void k_ypass_split(PassArgs a)
 #pragma unroll
       for (int k2 = 0; k2 < R2; k2++)
       {
-        Sout[a.aout.row(z, 2 * (j + R1 * k2)) * a.P + kx]     = wa[k2];
-        Sout[a.aout.row(z, 2 * (j + R1 * k2) + 1) * a.P + kx] = wb[k2];
+        Sout[a.aout.row(z, 2 * (j + R1 * k2)) * a.PX + kx]     = wa[k2];
+        Sout[a.aout.row(z, 2 * (j + R1 * k2) + 1) * a.PX + kx] = wb[k2];
       }
     }
     else
@@ -504,6 +507,7 @@ template<int L, int MODE> __global__ __launch_bounds__(Geo<L / 2>::THREADS) void
   const uint32_t base   = ky * a.P + kx;
   const uint32_t kxl    = min(kx, a.nxc - 1u);
   const uint32_t basel  = ky * a.P + kxl;
+  const uint32_t opbase = ky * a.Pop + kxl, opzstr = a.ny * a.Pop;
   constexpr bool MULTI  = (MODE == Z_VGRAD || MODE == Z_ABSORB);
   const uint32_t arr    = MULTI ? a.arr0 + blockIdx.z : 0;
   constexpr int  NOUT   = (MODE == Z_PGRAD) ? 3 : 1;
@@ -534,12 +538,12 @@ template<int L, int MODE> __global__ __launch_bounds__(Geo<L / 2>::THREADS) void
   }
   { // spectral operator (see k_zfused for the reference lines), kz = 2*(j + R1*k2) (+1)
     const float* __restrict__ op = a.op[(MODE == Z_ABSORB) ? arr : 0];
-    const uint32_t lb = basel + static_cast<uint32_t>(2 * j) * zstr;
+    const uint32_t lb = opbase + static_cast<uint32_t>(2 * j) * opzstr;
 #pragma unroll
     for (int k2 = 0; k2 < R2; k2++)
     {
-      float sa = op[lb + static_cast<uint32_t>(2 * R1 * k2) * zstr];
-      float sb = op[lb + static_cast<uint32_t>(2 * R1 * k2 + 1) * zstr];
+      float sa = op[lb + static_cast<uint32_t>(2 * R1 * k2) * opzstr];
+      float sb = op[lb + static_cast<uint32_t>(2 * R1 * k2 + 1) * opzstr];
       if (MODE == Z_VGRAD || MODE == Z_SOURCE) { sa *= a.divider; sb *= a.divider; }
       Xa[k2] = make_float2(Xa[k2].x * sa, Xa[k2].y * sa);
       Xb[k2] = make_float2(Xb[k2].x * sb, Xb[k2].y * sb);
@@ -1109,6 +1113,7 @@ kw_status launch_ypass(kw_ctx* ctx, int dir, int narr, float2* const* in, float2
   a.tw  = f.tw[1];
   a.nxc = c.nx_complex;
   a.P   = f.P;
+  a.PX  = f.PX;
   uint32_t sh = 0;
   while ((1u << sh) < f.nyl) sh++;
   const RowAddr natural{31u, 0xffffffffu, 0u, c.ny, 1u};
@@ -1152,7 +1157,8 @@ template<int MODE> kw_status launch_zfused(kw_ctx* ctx, int narr, ZArgs a)
   a.tw      = f.tw[2];
   a.divider = c.fft_divider;
   a.nxc     = c.nx_complex;
-  a.P       = f.P;
+  a.P       = f.slab ? f.PX : f.P; // slab mode: the z-pass works on the exchanged (unpadded) rows in place
+  a.Pop     = f.P;
   a.ny      = f.nyl;
   a.nz      = f.nz_global;
   a.ky0     = f.rank * f.nyl;
@@ -1204,7 +1210,7 @@ template<int EPI, bool CHAIN = false> kw_status launch_xinv(kw_ctx* ctx, int nco
 kw_status xstart(kw_ctx* ctx, int slot, float2* send, float2* recv)
 {
   const auto& f = ctx->fused;
-  const size_t bytes_per_peer = static_cast<size_t>(ctx->c.nz) * f.nyl * f.P * sizeof(float2);
+  const size_t bytes_per_peer = static_cast<size_t>(ctx->c.nz) * f.nyl * f.PX * sizeof(float2);
   if (f.exchange_start != nullptr) f.exchange_start(f.exchange_user, send, recv, bytes_per_peer, slot);
   else f.exchange(f.exchange_user, send, recv, bytes_per_peer);
   return KW_OK;
@@ -1335,6 +1341,7 @@ kw_status create_impl(kw_ctx* ctx, void* const s[3], void* const t[3])
   f.nz_global = (f.slab) ? slab.nz_global : c.nz;
   f.nyl       = c.ny / f.nranks;
   f.P         = (c.nx_complex + NLMAX - 1) / NLMAX * NLMAX;
+  f.PX        = f.slab ? c.nx_complex : f.P; // exchange buffers carry rows without their padding (-10 % wire bytes)
   KW_TRY(alloc_scratch(ctx, s, t));
   const uint32_t lens[3] = { c.nx, c.ny, f.nz_global };
   for (int i = 0; i < 3; i++)

@@ -45,6 +45,7 @@ struct kw_ctx
     uint32_t zchunks = 1;                          // plane-local passes (y^-1, x^-1 + epilogue, chained x, y) run per chunk of planes
     int      y_done  = 0;                          // chained spectra in s[0..y_done) already carry their forward y-pass
     uint32_t P     = 0;                            // padded half-spectrum row pitch (complex), multiple of 16
+    uint32_t PX    = 0;                            // row pitch of exchange-side buffers (slab mode: nx/2+1, no padding)
     float2*  s[3]  = {nullptr, nullptr, nullptr};  // three padded complex scratch arrays [nz][ny][P]
     float2*  tw[3] = {nullptr, nullptr, nullptr};  // exp(-2 pi i m / n) for n = nx, ny, nz
     // Z-slab decomposition (multi-GPU): this context owns nz = nz_global/nranks planes of the real-space arrays and,
