@@ -73,6 +73,19 @@ KWH_API int      kwh_get_scalar(kwh_solver* s, const char* name, float* out);
 /* output streams by dataset name ("p","p_max","ux",...): size = points per step, steps = stored steps (1 for aggregates) */
 KWH_API int      kwh_stream_info(kwh_solver* s, const char* name, uint64_t* size, uint64_t* steps);
 KWH_API int      kwh_stream_read(kwh_solver* s, const char* name, float* dst, uint64_t n);
+/* Checkpoint / restart (KSpaceFirstOrderSolver.cpp:1176-1224 save, :186-228 recover; MatrixContainer.cpp:504-537): the
+ * state of a run is the seven arrays p, rhox, rhoy, rhoz, ux_sgx, uy_sgy, uz_sgz, the time index and the state of every
+ * output stream.  These calls move that state in and out of a prepared solver; the HDF5 checkpoint file itself is
+ * written by kwh_checkpoint_write / read by kwh_checkpoint_read (libkwave_host_h5.so). */
+KWH_API int      kwh_set_matrix(kwh_solver* s, const char* name, const float* src, uint64_t n);
+KWH_API int      kwh_set_time_index(kwh_solver* s, uint64_t t_index);
+KWH_API int      kwh_stream_count(kwh_solver* s, uint64_t* n);
+KWH_API int      kwh_stream_name(kwh_solver* s, uint64_t i, char* out, uint64_t cap);
+/* dst == NULL: only the sizes are returned */
+KWH_API int      kwh_stream_checkpoint(kwh_solver* s, const char* name, float* dst, uint64_t cap, uint64_t* n_floats,
+                                       uint64_t* sampled_steps);
+KWH_API int      kwh_stream_restore(kwh_solver* s, const char* name, const float* src, uint64_t n_floats,
+                                    uint64_t sampled_steps);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,38 @@
+/* kwave_host_h5.h — file-format side of the host layer (optional component libkwave_host_h5.so, needs libhdf5):
+ * k-Wave HDF5 input / output / checkpoint files around the solver of kwave_host.h.
+ *
+ * Replaces, for the path this build covers: main() (main.cpp:840-966: load input, run, write output),
+ * Hdf5File / Hdf5FileHeader (Hdf5/Hdf5File.cpp:97-1086, Hdf5FileHeader.cpp:62-200), the output-file scalars
+ * (Parameters.cpp:559-647), and checkpoint / restart (KSpaceSolver/KSpaceFirstOrderSolver.cpp:1176-1224 save,
+ * :186-228 recover, :1124-1169 file checks; Containers/MatrixContainer.cpp:504-537).
+ * Same conventions as kwave_host.h: int status (0 = ok), message through kwh_last_error(). */
+#ifndef KWAVE_HOST_H5_H
+#define KWAVE_HOST_H5_H
+#include "kwave_host.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Parameters::init + loadInputData from a k-Wave input file (file format 1.1; main.cpp:857-917) */
+KWH_API int kwh_create_from_file(const char* input_path, const kwh_options* options, kwh_solver** out);
+/* output file: header, scalars, one dataset per stream, p_final / u_final (KSpaceFirstOrderSolver.cpp:950-1053) */
+KWH_API int kwh_write_output_file(kwh_solver* s, const char* path);
+/* write an input file from in-memory datasets (what the MATLAB side / a generator produces); is_complex[i] != 0 marks
+ * interleaved complex float data (domain_type = "complex", fastest dimension doubled: Hdf5File.cpp:898-915) */
+KWH_API int kwh_write_input_file(const char* path, const kwh_dataset* datasets, size_t n, const int32_t* is_complex);
+/* reading back: dims (x,y,z), dtype (0 float / 1 uint64), domain; whole dataset; string attribute ("/" = root) */
+KWH_API int kwh_h5_dataset_info(const char* path, const char* name, uint64_t dims[3], int32_t* dtype, int32_t* is_complex);
+KWH_API int kwh_h5_read(const char* path, const char* name, void* dst, uint64_t n, int32_t dtype);
+KWH_API int kwh_h5_read_attribute(const char* path, const char* dataset, const char* attr, char* out, uint64_t cap);
+/* checkpoint file (file_type = "checkpoint"): p, rhox, rhoy, rhoz, ux_sgx, uy_sgy, uz_sgz, t_index, Nx, Ny, Nz as in the
+ * reference, plus the state of every output stream (stream_<name>, stream_<name>_steps).  kwh_checkpoint_read refuses a
+ * file whose type or dimensions do not match (KSpaceFirstOrderSolver.cpp:1132-1168) and leaves the solver at the stored
+ * time index; kwh_run then continues bit-identically to an uninterrupted run. */
+KWH_API int kwh_checkpoint_write(kwh_solver* s, const char* path);
+KWH_API int kwh_checkpoint_read(kwh_solver* s, const char* path);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -40,6 +40,8 @@ def load_h5() -> C.CDLL:
                                           C.POINTER(C.c_int32)]
         L.kwh_h5_read.argtypes = [C.c_char_p, C.c_char_p, C.c_void_p, C.c_uint64, C.c_int32]
         L.kwh_h5_read_attribute.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_uint64]
+        L.kwh_checkpoint_write.argtypes = [C.c_void_p, C.c_char_p]
+        L.kwh_checkpoint_read.argtypes = [C.c_void_p, C.c_char_p]
         _h5 = L
     return _h5
 
@@ -128,3 +130,11 @@ class FileSolver(HostSolver):
 
     def write_output(self, path: str):
         _h5check(self.L.kwh_write_output_file(self._h, path.encode()))
+
+    def write_checkpoint(self, path: str):
+        """State arrays, time index and stream states -> checkpoint file (KSpaceFirstOrderSolver.cpp:1176-1224)."""
+        _h5check(self.L.kwh_checkpoint_write(self._h, path.encode()))
+
+    def read_checkpoint(self, path: str):
+        """Recover from a checkpoint file; run() then continues from its time index (…Solver.cpp:186-228)."""
+        _h5check(self.L.kwh_checkpoint_read(self._h, path.encode()))

@@ -3,6 +3,7 @@
 
 #include <cstring>
 #include <limits>
+#include <stdexcept>
 
 #include "CompressHelper.h"
 #include "HipError.h"
@@ -104,6 +105,41 @@ void BaseOutputStream::postProcess()
     OutputStreamsHipKernels::postProcessingRms(mDeviceBuffer, scalingCoeff, mSize);
   }
   if (mReduceOp != ReduceOperator::kNone && mReduceOp != ReduceOperator::kC) copyAggregateFromDevice();
+}
+
+void BaseOutputStream::checkpointState(std::vector<float>& state, size_t& sampledSteps)
+{
+  if (mReduceOp == ReduceOperator::kC || mReduceOp == ReduceOperator::kIAvgC)
+    throw std::runtime_error("checkpointing of compression streams (" + mName + ") is not implemented");
+  if (mReduceOp == ReduceOperator::kNone)
+  {
+    while (mFlushedSteps < mSampledSteps) flushRaw(); // the step sampled last is still in its pinned buffer
+    state = mDataset;
+  }
+  else
+  { // accumulator as it stands (RMS: sum of squares, scaled only in postProcess)
+    state.resize(mSize);
+    kwCheck(kw_memcpy_d2h(ctx(), state.data(), mDeviceBuffer, mSize * sizeof(float)));
+  }
+  sampledSteps = mSampledSteps;
+}
+
+void BaseOutputStream::restoreState(const float* state, size_t n, size_t sampledSteps)
+{
+  if (mReduceOp == ReduceOperator::kC || mReduceOp == ReduceOperator::kIAvgC)
+    throw std::runtime_error("checkpointing of compression streams (" + mName + ") is not implemented");
+  if (mReduceOp == ReduceOperator::kNone)
+  {
+    if (n != sampledSteps * mSize) throw std::invalid_argument("checkpoint of stream " + mName + " has the wrong size");
+    mDataset.assign(state, state + n);
+    mSampledSteps = mFlushedSteps = sampledSteps;
+  }
+  else
+  {
+    if (n != mSize) throw std::invalid_argument("checkpoint of stream " + mName + " has the wrong size");
+    kwCheck(kw_memcpy_h2d(ctx(), mDeviceBuffer, state, mSize * sizeof(float)));
+    mSampledSteps = sampledSteps;
+  }
 }
 
 // ---- raw helpers ----------------------------------------------------------------------------------------------------

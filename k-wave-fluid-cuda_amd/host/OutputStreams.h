@@ -44,6 +44,11 @@ class BaseOutputStream
   const std::vector<float>& dataset() const { return mDataset; }
   size_t size() const { return mSize; }
   size_t sampledSteps() const { return mFlushedSteps; }
+  /// Checkpoint / restart (BaseOutputStream::checkpoint / reopen, e.g. IndexOutputStream.cpp:497-533): what a restart
+  /// needs to continue this stream — the series stored so far (raw; the reference keeps it in the output file) or the
+  /// device accumulator (rms / max / min) — and the number of sampled steps.
+  virtual void checkpointState(std::vector<float>& state, size_t& sampledSteps);
+  virtual void restoreState(const float* state, size_t n, size_t sampledSteps);
 
  protected:
   void allocateMemory();

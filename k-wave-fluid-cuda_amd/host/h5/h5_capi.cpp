@@ -66,6 +66,81 @@ void kwh_write_output(kwh_solver* s, const std::string& path)
   out.close();
 }
 
+// ---- checkpoint file (KSpaceFirstOrderSolver.cpp:1176-1224 write, :186-228 + :1124-1169 read / check) --------------
+// Root datasets: the seven state arrays under their matrix names (MatrixContainer.cpp:504-537), t_index, Nx, Ny, Nz;
+// header file_type = "checkpoint".  Streams: "stream_<name>" (series so far or accumulator) + "stream_<name>_steps";
+// the reference keeps raw series in the output file and re-opens it, here both live in the one checkpoint file.
+static const char* const kCheckpointMatrices[] = { "p", "rhox", "rhoy", "rhoz", "ux_sgx", "uy_sgy", "uz_sgz" };
+
+void kwh_checkpoint_write_impl(kwh_solver* s, const std::string& path)
+{
+  const Parameters& params = Parameters::getInstance();
+  s->solver->prepare();
+  Hdf5File f;
+  f.create(path);
+  f.writeHeader("checkpoint", "k-Wave checkpoint written by kspaceFirstOrder-HIP");
+  const DimensionSizes dims = params.getFullDimensionSizes();
+  f.writeScalarValue(kTimeIndexName, params.getTimeIndex());
+  f.writeScalarValue(kNxName, dims.nx);
+  f.writeScalarValue(kNyName, dims.ny);
+  f.writeScalarValue(kNzName, dims.nz);
+  std::vector<float> buf(dims.nElements());
+  for (const char* name : kCheckpointMatrices)
+  {
+    if (kwh_get_matrix(s, name, buf.data(), buf.size()) != 0) throw std::runtime_error(kwh_last_error());
+    f.writeMatrix(name, dims, buf.data(), Hdf5File::MatrixDomainType::kReal);
+  }
+  OutputStreamContainer& streams = s->solver->getOutputStreamContainer();
+  for (const std::string& name : streams.names())
+  {
+    std::vector<float> state;
+    size_t steps = 0;
+    streams.find(name)->checkpointState(state, steps);
+    f.writeScalarValue("stream_" + name + "_steps", steps);
+    if (!state.empty())
+      f.writeMatrix("stream_" + name, DimensionSizes(state.size(), 1, 1), state.data(), Hdf5File::MatrixDomainType::kReal);
+  }
+  f.close();
+}
+
+void kwh_checkpoint_read_impl(kwh_solver* s, const std::string& path)
+{
+  const Parameters& params = Parameters::getInstance();
+  s->solver->prepare();
+  Hdf5File f;
+  f.open(path);
+  if (f.readFileType() != "checkpoint") throw std::invalid_argument(path + " is not a checkpoint file"); // :1132-1136
+  const DimensionSizes dims = params.getFullDimensionSizes();
+  size_t v[4] = {0, 0, 0, 0};
+  f.readCompleteDataset(kNxName, 1, &v[0]);
+  f.readCompleteDataset(kNyName, 1, &v[1]);
+  f.readCompleteDataset(kNzName, 1, &v[2]);
+  f.readCompleteDataset(kTimeIndexName, 1, &v[3]);
+  if (v[0] != dims.nx || v[1] != dims.ny || v[2] != dims.nz)
+    throw std::invalid_argument("The dimension sizes in the checkpoint file do not match the input file"); // :1160-1168
+  std::vector<float> buf(dims.nElements());
+  for (const char* name : kCheckpointMatrices)
+  {
+    f.readCompleteDataset(name, buf.size(), buf.data());
+    if (kwh_set_matrix(s, name, buf.data(), buf.size()) != 0) throw std::runtime_error(kwh_last_error());
+  }
+  OutputStreamContainer& streams = s->solver->getOutputStreamContainer();
+  for (const std::string& name : streams.names())
+  {
+    size_t steps = 0;
+    f.readCompleteDataset("stream_" + name + "_steps", 1, &steps);
+    std::vector<float> state;
+    if (f.datasetExists("stream_" + name))
+    {
+      state.resize(f.getDatasetSize("stream_" + name));
+      f.readCompleteDataset("stream_" + name, state.size(), state.data());
+    }
+    streams.find(name)->restoreState(state.data(), state.size(), steps);
+  }
+  if (kwh_set_time_index(s, v[3]) != 0) throw std::runtime_error(kwh_last_error());
+  f.close();
+}
+
 extern "C" {
 
 KWH_API int kwh_create_from_file(const char* input_path, const kwh_options* o, kwh_solver** out)
@@ -139,6 +214,22 @@ KWH_API int kwh_h5_read_attribute(const char* path, const char* dataset, const c
   const std::string v = f.readStringAttribute(dataset, attr);
   std::strncpy(out, v.c_str(), cap);
   if (cap) out[cap - 1] = 0;
+  KWH_CATCH
+}
+
+KWH_API int kwh_checkpoint_write(kwh_solver* s, const char* path)
+{
+  KWH_TRY
+  if (!s || !path) throw std::invalid_argument("kwh_checkpoint_write: NULL argument");
+  kwh_checkpoint_write_impl(s, path);
+  KWH_CATCH
+}
+
+KWH_API int kwh_checkpoint_read(kwh_solver* s, const char* path)
+{
+  KWH_TRY
+  if (!s || !path) throw std::invalid_argument("kwh_checkpoint_read: NULL argument");
+  kwh_checkpoint_read_impl(s, path);
   KWH_CATCH
 }
 }

@@ -11,18 +11,23 @@
 #include "Hdf5File.h"
 
 void kwh_write_output(kwh_solver* s, const std::string& path);
+void kwh_checkpoint_write_impl(kwh_solver* s, const std::string& path);
+void kwh_checkpoint_read_impl(kwh_solver* s, const std::string& path);
 
 static void usage()
 {
   std::printf("kspaceFirstOrder-HIP -i <input.h5> -o <output.h5> [-g dev] [-s start (1-based)] [--benchmark N]\n"
               "  [-p|--p_raw] [--p_rms] [--p_max] [--p_min] [--p_max_all] [--p_min_all] [--p_final]\n"
               "  [-u|--u_raw] [--u_rms] [--u_max] [--u_min] [--u_max_all] [--u_min_all] [--u_final] [--u_non_staggered_raw]\n"
-              "  [--p_c] [--u_non_staggered_c] [--I_avg_c] [--period P] [--mos M] [--harmonics H] [--no_overlap] [--granular]\n");
+              "  [--p_c] [--u_non_staggered_c] [--I_avg_c] [--period P] [--mos M] [--harmonics H] [--no_overlap] [--granular]\n"
+              "  [--checkpoint_file <ckpt.h5> --checkpoint_timesteps N]  stop after N steps, leaving a checkpoint; the\n"
+              "      same command line resumes from it (CommandLineParameters.cpp:264-292)\n");
 }
 
 int main(int argc, char** argv)
 {
-  std::string in, out;
+  std::string in, out, ckpt;
+  size_t ckptSteps = 0;
   kwh_options o{};
   o.device_idx    = -1;
   o.fused_kernels = 1;
@@ -59,6 +64,8 @@ int main(int argc, char** argv)
     else if (a == "--harmonics") o.harmonics = std::strtoull(next(), nullptr, 10);
     else if (a == "--no_overlap") o.no_overlap = 1;
     else if (a == "--granular") o.fused_kernels = 0;
+    else if (a == "--checkpoint_file") ckpt = next();
+    else if (a == "--checkpoint_timesteps") ckptSteps = std::strtoull(next(), nullptr, 10);
     else if (a == "-h" || a == "--help") { usage(); return EXIT_SUCCESS; }
     else { std::fprintf(stderr, "unknown flag %s\n", a.c_str()); usage(); return EXIT_FAILURE; }
   }
@@ -71,10 +78,35 @@ int main(int argc, char** argv)
     s.file_input.reset();
     std::printf("%s on %s\n", s.solver->getCodeName().c_str(),
                 Parameters::getInstance().getHipParameters().getDeviceName().c_str());
-    s.solver->compute();
-    kwCheck(kw_sync(Parameters::getInstance().getHipParameters().getContext()));
+    Parameters& params = Parameters::getInstance();
+    const bool checkpointing = !ckpt.empty() && ckptSteps > 0;
+    if (checkpointing)
+    { // recover if a checkpoint exists (KSpaceFirstOrderSolver.cpp:186-228), run one leg, stop with a new checkpoint
+      if (FILE* f = std::fopen(ckpt.c_str(), "rb"))
+      {
+        std::fclose(f);
+        kwh_checkpoint_read_impl(&s, ckpt);
+        std::printf("recovered from %s at time step %zu\n", ckpt.c_str(), params.getTimeIndex());
+      }
+      s.solver->runTimeSteps(ckptSteps);
+      kwCheck(kw_sync(params.getHipParameters().getContext()));
+      if (params.getTimeIndex() < params.getNt())
+      {
+        kwh_checkpoint_write_impl(&s, ckpt);
+        std::printf("time steps: %zu of %zu, checkpoint: %s\n", params.getTimeIndex(), params.getNt(), ckpt.c_str());
+        s.solver.reset();
+        return EXIT_SUCCESS;
+      }
+      s.solver->finish();
+      std::remove(ckpt.c_str()); // main.cpp:951-958: the checkpoint is deleted once the simulation is complete
+    }
+    else
+    {
+      s.solver->compute();
+    }
+    kwCheck(kw_sync(params.getHipParameters().getContext()));
     kwh_write_output(&s, out);
-    std::printf("time steps: %zu, output: %s\n", Parameters::getInstance().getTimeIndex(), out.c_str());
+    std::printf("time steps: %zu, output: %s\n", params.getTimeIndex(), out.c_str());
     s.solver.reset();
   }
   catch (const std::exception& e)

@@ -192,4 +192,71 @@ int kwh_stream_read(kwh_solver* s, const char* name, float* dst, uint64_t n)
   std::memcpy(dst, st->dataset().data(), n * sizeof(float));
   KWH_CATCH
 }
+
+int kwh_set_matrix(kwh_solver* s, const char* name, const float* src, uint64_t n)
+{
+  KWH_TRY
+  if (!s || !name || !src) throw std::invalid_argument("kwh_set_matrix: NULL argument");
+  s->solver->prepare();
+  MatrixRecord::MatrixType t;
+  BaseMatrix* m = findMatrix(s, name, &t);
+  if (t == MatrixRecord::MatrixType::kIndex) throw std::invalid_argument("index matrices are not float matrices");
+  BaseFloatMatrix* f = static_cast<BaseFloatMatrix*>(m);
+  if (f->capacity() != n) throw std::invalid_argument(std::string("size mismatch for matrix ") + name);
+  kwCheck(kw_memcpy_h2d(Parameters::getInstance().getHipParameters().getContext(), f->getDeviceData(), src, n * sizeof(float)));
+  KWH_CATCH
+}
+
+int kwh_set_time_index(kwh_solver* s, uint64_t t)
+{
+  KWH_TRY
+  if (!s) throw std::invalid_argument("kwh_set_time_index: NULL solver");
+  if (t > Parameters::getInstance().getNt()) throw std::invalid_argument("kwh_set_time_index: beyond Nt");
+  Parameters::getInstance().setTimeIndex(t);
+  KWH_CATCH
+}
+
+int kwh_stream_count(kwh_solver* s, uint64_t* n)
+{
+  KWH_TRY
+  *n = s->solver->getOutputStreamContainer().names().size();
+  KWH_CATCH
+}
+
+int kwh_stream_name(kwh_solver* s, uint64_t i, char* out, uint64_t cap)
+{
+  KWH_TRY
+  const std::vector<std::string> names = s->solver->getOutputStreamContainer().names();
+  if (i >= names.size() || names[i].size() + 1 > cap) throw std::invalid_argument("kwh_stream_name: bad index or buffer");
+  std::memcpy(out, names[i].c_str(), names[i].size() + 1);
+  KWH_CATCH
+}
+
+int kwh_stream_checkpoint(kwh_solver* s, const char* name, float* dst, uint64_t cap, uint64_t* n_floats, uint64_t* steps)
+{
+  KWH_TRY
+  BaseOutputStream* st = s->solver->getOutputStreamContainer().find(name);
+  if (!st) throw std::invalid_argument(std::string("no output stream named ") + name);
+  std::vector<float> state;
+  size_t sampled = 0;
+  st->checkpointState(state, sampled);
+  *n_floats = state.size();
+  *steps    = sampled;
+  if (dst != nullptr)
+  {
+    if (cap < state.size()) throw std::invalid_argument("kwh_stream_checkpoint: buffer too small");
+    std::memcpy(dst, state.data(), state.size() * sizeof(float));
+  }
+  KWH_CATCH
+}
+
+int kwh_stream_restore(kwh_solver* s, const char* name, const float* src, uint64_t n, uint64_t steps)
+{
+  KWH_TRY
+  s->solver->prepare();
+  BaseOutputStream* st = s->solver->getOutputStreamContainer().find(name);
+  if (!st) throw std::invalid_argument(std::string("no output stream named ") + name);
+  st->restoreState(src, n, steps);
+  KWH_CATCH
+}
 }

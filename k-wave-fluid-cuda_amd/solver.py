@@ -67,6 +67,13 @@ def load_host() -> C.CDLL:
         L.kwh_get_scalar.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_float)]
         L.kwh_stream_info.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
         L.kwh_stream_read.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_uint64]
+        L.kwh_set_matrix.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_uint64]
+        L.kwh_set_time_index.argtypes = [C.c_void_p, C.c_uint64]
+        L.kwh_stream_count.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
+        L.kwh_stream_name.argtypes = [C.c_void_p, C.c_uint64, C.c_char_p, C.c_uint64]
+        L.kwh_stream_checkpoint.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64),
+                                            C.POINTER(C.c_uint64)]
+        L.kwh_stream_restore.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_uint64, C.c_uint64]
         _hlib = L
     return _hlib
 
@@ -186,6 +193,41 @@ class HostSolver:
         out = np.empty(size.value * steps.value, dtype=np.float32)
         _check(self.L.kwh_stream_read(self._h, name.encode(), out.ctypes.data, out.size))
         return out.reshape(steps.value, size.value) if steps.value != 1 else out
+
+    # ---- checkpoint / restart through the plain host API (the HDF5 checkpoint file is h5io.FileSolver's) ----
+    CHECKPOINT_MATRICES = ("p", "rhox", "rhoy", "rhoz", "ux_sgx", "uy_sgy", "uz_sgz")
+
+    def stream_names(self):
+        n = C.c_uint64()
+        _check(self.L.kwh_stream_count(self._h, C.byref(n)))
+        out = []
+        for i in range(n.value):
+            buf = C.create_string_buffer(128)
+            _check(self.L.kwh_stream_name(self._h, i, buf, 128))
+            out.append(buf.value.decode())
+        return out
+
+    def checkpoint_state(self) -> dict:
+        """{"t_index", "matrices": {name: array}, "streams": {name: (array, sampled_steps)}} of the run so far."""
+        st = {"t_index": self.t, "matrices": {}, "streams": {}}
+        for name in self.CHECKPOINT_MATRICES:
+            st["matrices"][name] = self.field(name).copy()
+        for name in self.stream_names():
+            n, steps = C.c_uint64(), C.c_uint64()
+            _check(self.L.kwh_stream_checkpoint(self._h, name.encode(), None, 0, C.byref(n), C.byref(steps)))
+            a = np.empty(n.value, dtype=np.float32)
+            _check(self.L.kwh_stream_checkpoint(self._h, name.encode(), a.ctypes.data, a.size, C.byref(n), C.byref(steps)))
+            st["streams"][name] = (a, steps.value)
+        return st
+
+    def restore_state(self, st: dict):
+        for name, a in st["matrices"].items():
+            a = np.ascontiguousarray(a, dtype=np.float32)
+            _check(self.L.kwh_set_matrix(self._h, name.encode(), a.ctypes.data, a.size))
+        for name, (a, steps) in st["streams"].items():
+            a = np.ascontiguousarray(a, dtype=np.float32)
+            _check(self.L.kwh_stream_restore(self._h, name.encode(), a.ctypes.data, a.size, steps))
+        _check(self.L.kwh_set_time_index(self._h, st["t_index"]))
 
     # HIP-event timing of n steps on the solver's stream
     def time_steps(self, n_steps: int) -> float:

@@ -40,6 +40,18 @@ def test_host_library_exports_every_declared_symbol(built):
         assert hasattr(L, sym), sym
 
 
+def test_h5_library_exports_every_declared_symbol(built):
+    from kwave_amd import h5io
+    if not os.path.exists(h5io.H5_LIB_PATH):
+        pytest.skip("HDF5 component not built (no libhdf5)")
+    L = h5io.load_h5()
+    txt = open(os.path.join(ROOT, "include", "kwave_host_h5.h")).read()
+    declared = sorted(set(re.findall(r"KWH_API\s+[\w\s\*]+?\b(kwh_\w+)\s*\(", txt)))
+    assert len(declared) >= 8
+    for sym in declared:
+        assert hasattr(L, sym), sym
+
+
 def test_header_cites_reference_lines():
     txt = open(os.path.join(ROOT, "include", "kwave_hip.h")).read()
     # each kernel entry names the SolverCudaKernels / OutputStreamsCudaKernels lines it replaces

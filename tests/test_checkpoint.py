@@ -1,0 +1,116 @@
+"""Checkpoint / restart (KSpaceFirstOrderSolver.cpp:1176-1224 save, :186-228 recover): a run that is
+stopped, saved, and continued in a NEW solver gives the same bits as the uninterrupted run — fields, raw series and
+aggregated streams — through the plain host API, through the HDF5 checkpoint file, and through the command line."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+STREAMS = dict(p_raw=1, p_max=1, p_rms=1, p_min=1, u_raw=1, u_max=1, p_max_all=1, p_final=1)
+
+
+def problem(syn, nt, **kw):
+    return syn.make_problem(32, 16, 32, heterogeneous=True, nonlinear=True, absorbing=True, nt=nt, pml_size=4,
+                            sensor="random", **kw)
+
+
+@pytest.mark.parametrize("source,split", [("p0", 1), ("p0", 9), ("p_source", 10), ("u_source", 7)])
+def test_restart_through_host_api_is_bit_identical(syn, source, split):
+    """split = 1 also covers the checkpoint taken right after the step that applies the initial pressure source."""
+    from kwave_amd.solver import HostSolver
+    nt = 24
+    pr = problem(syn, nt, source=source, source_many=1 if source != "p0" else 0)
+    ref = HostSolver(pr, **STREAMS)
+    ref.run(nt)
+    ref.finish()
+    a = HostSolver(pr, **STREAMS)
+    a.run(split)
+    state = a.checkpoint_state()
+    assert state["t_index"] == split
+    a.close()
+    b = HostSolver(pr, **STREAMS)
+    b.restore_state(state)
+    assert b.t == split
+    b.run(nt - split)
+    b.finish()
+    for f in ("p", "ux", "uy", "uz", "rhox", "rhoy", "rhoz"):
+        assert np.array_equal(b.field(f), ref.field(f)), f
+    for s in ("p", "p_max", "p_rms", "p_min", "ux", "uz", "ux_max", "p_max_all"):
+        assert np.array_equal(b.stream(s), ref.stream(s)), s
+    assert b.stream("p").shape == (nt, pr["sensor_mask_index"].size)
+    b.close()
+    ref.close()
+
+
+@pytest.fixture(scope="module")
+def h5io():
+    import kwave_amd  # noqa: F401
+    from kwave_amd import h5io as m
+    if not os.path.exists(m.H5_LIB_PATH):
+        pytest.skip("HDF5 component not built (no HDF5 in this image)")
+    return m
+
+
+def test_checkpoint_file_contents_and_recovery(h5io, syn, tmp_path):
+    from kwave_amd import capi
+    nt, split = 20, 8
+    pr = problem(syn, nt, source="p0")
+    path_in, ckpt = str(tmp_path / "in.h5"), str(tmp_path / "ckpt.h5")
+    h5io.write_input_file(pr, path_in)
+    ref = h5io.FileSolver(path_in, p_raw=1, p_max=1)
+    ref.run(nt)
+    ref.finish()
+    a = h5io.FileSolver(path_in, p_raw=1, p_max=1)
+    a.run(split)
+    a.write_checkpoint(ckpt)
+    # the reference's checkpoint layout: seven state arrays, t_index, dims, file_type (…Solver.cpp:1186-1207)
+    assert h5io.read_attribute(ckpt, "/", "file_type") == "checkpoint"
+    assert int(h5io.read_dataset(ckpt, "t_index").ravel()[0]) == split
+    for name in ("p", "rhox", "rhoy", "rhoz", "ux_sgx", "uy_sgy", "uz_sgz"):
+        assert h5io.dataset_info(ckpt, name) == ((32, 16, 32), "float", "real"), name
+    assert np.array_equal(h5io.read_dataset(ckpt, "p"), a.field("p"))
+    a.close()
+    b = h5io.FileSolver(path_in, p_raw=1, p_max=1)
+    b.read_checkpoint(ckpt)
+    assert b.t == split
+    b.run(nt - split)
+    b.finish()
+    assert np.array_equal(b.field("p"), ref.field("p"))
+    assert np.array_equal(b.stream("p"), ref.stream("p"))
+    assert np.array_equal(b.stream("p_max"), ref.stream("p_max"))
+    # file checks (…Solver.cpp:1124-1169): an input file is not a checkpoint; a checkpoint of another grid is refused
+    with pytest.raises(capi.KWaveError):
+        b.read_checkpoint(path_in)
+    other_in = str(tmp_path / "other.h5")
+    h5io.write_input_file(syn.make_problem(16, nt=4, pml_size=2), other_in)
+    c = h5io.FileSolver(other_in, p_raw=1, p_max=1)
+    with pytest.raises(capi.KWaveError):
+        c.read_checkpoint(ckpt)
+    c.close()
+    b.close()
+    ref.close()
+
+
+def test_command_line_checkpoint_legs(h5io, syn, tmp_path):
+    """Three invocations of the same command line: 7 + 7 + 6 steps, checkpoint removed at the end, output == one run."""
+    from kwave_amd import capi
+    nt = 20
+    pr = problem(syn, nt, source="p0")
+    path_in, out1, out2, ckpt = (str(tmp_path / n) for n in ("in.h5", "out_once.h5", "out_legs.h5", "ckpt.h5"))
+    h5io.write_input_file(pr, path_in)
+    exe = os.path.join(capi.PKG, "lib", "kspaceFirstOrder-HIP")
+    flags = ["--p_raw", "--p_max", "--u_rms", "--p_final"]
+    r = subprocess.run([exe, "-i", path_in, "-o", out1] + flags, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                       text=True, timeout=300)
+    assert r.returncode == 0, r.stdout
+    for leg in range(3):
+        r = subprocess.run([exe, "-i", path_in, "-o", out2, "--checkpoint_file", ckpt, "--checkpoint_timesteps", "7"] + flags,
+                           stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
+        assert r.returncode == 0, r.stdout
+        assert os.path.exists(ckpt) == (leg < 2), r.stdout
+        assert os.path.exists(out2) == (leg == 2)
+    for name in ("p", "p_max", "ux_rms", "uz_rms", "p_final"):
+        assert np.array_equal(h5io.read_dataset(out2, name), h5io.read_dataset(out1, name)), name
