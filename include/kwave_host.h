@@ -77,6 +77,12 @@ KWH_API int      kwh_stream_read(kwh_solver* s, const char* name, float* dst, ui
  * state of a run is the seven arrays p, rhox, rhoy, rhoz, ux_sgx, uy_sgy, uz_sgz, the time index and the state of every
  * output stream.  These calls move that state in and out of a prepared solver; the HDF5 checkpoint file itself is
  * written by kwh_checkpoint_write / read by kwh_checkpoint_read (libkwave_host_h5.so). */
+/* Compression helpers of the reference that run on the host (Compression/CompressHelper.cpp:146-216 findPeriod,
+ * :298-389 convertFloatCTo40b, :224-289 convert40bToFloatC; exponent bias e = 138 pressure / 114 velocity).  The
+ * solver uses findPeriod itself when compression streams are requested without a period (Parameters.cpp:488-512). */
+KWH_API int      kwh_find_period(const float* signal, uint64_t length, float* period);
+KWH_API int      kwh_pack_complex_40b(const float* re_im_pairs, uint64_t n, uint8_t* packed5n, int32_t e);
+KWH_API int      kwh_unpack_complex_40b(const uint8_t* packed5n, uint64_t n, float* re_im_pairs, int32_t e);
 KWH_API int      kwh_set_matrix(kwh_solver* s, const char* name, const float* src, uint64_t n);
 KWH_API int      kwh_set_time_index(kwh_solver* s, uint64_t t_index);
 KWH_API int      kwh_stream_count(kwh_solver* s, uint64_t* n);

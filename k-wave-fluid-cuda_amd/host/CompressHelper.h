@@ -2,11 +2,13 @@
 // Mirror of Compression/CompressHelper.{h,cpp} of the reference for what the sampling path needs: init (:48-65),
 // the triangular window (:700-710), the complex exponential basis (:733-746, velocity streams phase-shifted by half a
 // step) and the windowed / inverted-window bases bE, bE_1 (:760-778), normalised by 2/oSize as Parameters.cpp:549-551
-// requests.  The period finder and the 40-bit codec (:146-389) are later scope rows.
+// requests; the period finder (:146-216, with findPeaks :549-572, diff, median) used when no --period is given
+// (Parameters.cpp:488-512) and the 40-bit packing of complex coefficients (:224-389).
 #ifndef KW_HOST_COMPRESS_HELPER_H
 #define KW_HOST_COMPRESS_HELPER_H
 #include <complex>
 #include <cstddef>
+#include <cstdint>
 #include <vector>
 
 using FloatComplex = std::complex<float>;
@@ -25,6 +27,16 @@ class CompressHelper
   float  getPeriod() const { return mPeriod; }
   size_t getMos() const { return mMos; }
   size_t getHarmonics() const { return mHarmonics; }
+
+  /// period of a sampled signal in samples: sub-sample positions of the local maxima above half the largest one,
+  /// median of their spacings (CompressHelper.cpp:146-216)
+  static float findPeriod(const float* data, size_t length);
+  /// 40-bit packing of a complex coefficient (CompressHelper.cpp:298-389): byte 0 = real sign | imaginary sign |
+  /// bit 16 of each mantissa | 4-bit shared exponent (biased by `e`: 138 for pressure, 114 for velocity),
+  /// bytes 1-2 / 3-4 = low 16 bits of the real / imaginary 17-bit mantissa (leading flag bit explicit)
+  static void convertFloatCTo40b(FloatComplex value, uint8_t* packed5, int32_t e);
+  static void convert40bToFloatC(const uint8_t* packed5, FloatComplex& value, int32_t e);
+  static constexpr int32_t kMaxExpP = 138, kMaxExpU = 114; // CompressHelper.h:81-83
 
  private:
   CompressHelper() = default;

@@ -1,6 +1,8 @@
 // Parameters.cpp — see Parameters.h.  Follows Parameters/Parameters.cpp:194-459 (what is read, in which order,
 // how scalar-vs-matrix medium is detected) and Parameters/CudaParameters.cpp:81-177,238-288.
 #include "Parameters.h"
+#include <algorithm>
+#include <vector>
 
 #include <ios>
 #include <stdexcept>
@@ -129,8 +131,20 @@ void Parameters::init(const InputProvider& in, const Options& options)
     if (mBOnAScalarFlag) in.readScalarValue(kBonAName, mBOnAScalar);
   }
   if (mOptions.storePressureC || mOptions.storeVelocityNonStaggeredC || mOptions.storeIntensityAvgC)
-  { // Parameters.cpp:462-551: the period (in time steps) must be known; the automatic period finder is a later row
-    if (!(mOptions.period > 0.0f)) throw std::ios_base::failure("Error: compression streams need --period (> 0)");
+  { // Parameters.cpp:462-551: the period (in time steps) is given (--period) or found from the pressure source signal:
+    // the last <= 500 samples of the middle source point (:488-512)
+    if (!(mOptions.period > 0.0f))
+    {
+      if (!in.datasetExists(kPressureSourceInputName))
+        throw std::ios_base::failure("Error: compression streams need --period (> 0) or a p_source_input to derive it from");
+      const DimensionSizes size = in.getDatasetDimensionSizes(kPressureSourceInputName); // (nSrc | 1, Nt_src, 1)
+      std::vector<float> all(size.nElements());
+      in.readFloat(kPressureSourceInputName, all.data(), all.size());
+      const size_t length = std::min<size_t>(size.ny, 500);
+      std::vector<float> tail(length);
+      for (size_t t = 0; t < length; t++) tail[t] = all[(size.ny - length + t) * size.nx + size.nx / 2];
+      mOptions.period = CompressHelper::findPeriod(tail.data(), length);
+    }
     CompressHelper::getInstance().init(mOptions.period, mOptions.mos, mOptions.harmonics, true);
   }
   mRho0ScalarFlag = in.getDatasetDimensionSizes(kRho0Name) == scalarSizes;

@@ -6,6 +6,7 @@
 #include <string>
 
 #include "HipError.h"
+#include "CompressHelper.h"
 #include "HostSolverHandle.h"
 #include "KSpaceFirstOrderSolver.h"
 #include "kwave_host.h"
@@ -257,6 +258,36 @@ int kwh_stream_restore(kwh_solver* s, const char* name, const float* src, uint64
   BaseOutputStream* st = s->solver->getOutputStreamContainer().find(name);
   if (!st) throw std::invalid_argument(std::string("no output stream named ") + name);
   st->restoreState(src, n, steps);
+  KWH_CATCH
+}
+
+int kwh_find_period(const float* signal, uint64_t length, float* period)
+{
+  KWH_TRY
+  if (!signal || !period) throw std::invalid_argument("kwh_find_period: NULL argument");
+  *period = CompressHelper::findPeriod(signal, length);
+  KWH_CATCH
+}
+
+int kwh_pack_complex_40b(const float* v, uint64_t n, uint8_t* packed, int32_t e)
+{
+  KWH_TRY
+  if (!v || !packed) throw std::invalid_argument("kwh_pack_complex_40b: NULL argument");
+  for (uint64_t i = 0; i < n; i++) CompressHelper::convertFloatCTo40b(FloatComplex(v[2 * i], v[2 * i + 1]), packed + 5 * i, e);
+  KWH_CATCH
+}
+
+int kwh_unpack_complex_40b(const uint8_t* packed, uint64_t n, float* v, int32_t e)
+{
+  KWH_TRY
+  if (!v || !packed) throw std::invalid_argument("kwh_unpack_complex_40b: NULL argument");
+  for (uint64_t i = 0; i < n; i++)
+  {
+    FloatComplex c;
+    CompressHelper::convert40bToFloatC(packed + 5 * i, c, e);
+    v[2 * i]     = c.real();
+    v[2 * i + 1] = c.imag();
+  }
   KWH_CATCH
 }
 }

@@ -225,3 +225,32 @@ def test_config5_compression_and_intensity_streams(orc, syn):
         ref = (np.real(P * np.conj(U)).sum(axis=2) / 2.0).mean(axis=0)
         assert rel_l2(g.stream(f"I{nm}_avg_c"), ref) < 1e-5
     g.close()
+
+
+def test_compression_period_found_from_the_source_signal(syn):
+    """No --period: the period comes from the pressure source signal (Parameters.cpp:488-512, CompressHelper::findPeriod);
+    the run equals one given that period explicitly."""
+    import ctypes as C
+    from kwave_amd import solver
+    n, nt = 32, 90
+    pr = syn.make_problem(n, heterogeneous=False, nonlinear=False, absorbing=False, source="p_source", source_mode=1,
+                          nt=nt, pml_size=4, sensor="random")
+    sig = np.asarray(pr["p_source_input"], dtype=np.float32)
+    nsrc = pr["p_source_index"].size if int(np.asarray(pr.get("p_source_many", 0)).ravel()[0]) else 1
+    series = sig.reshape(-1, nsrc)[:, nsrc // 2]
+    tail = np.ascontiguousarray(series[-min(500, series.size):])
+    L = solver.load_host()
+    L.kwh_find_period.argtypes = [C.c_void_p, C.c_uint64, C.POINTER(C.c_float)]
+    per = C.c_float()
+    assert L.kwh_find_period(tail.ctypes.data, tail.size, C.byref(per)) == 0
+    dt = float(pr["dt"].ravel()[0])
+    assert abs(per.value - 1.0 / (1.0e6 * dt)) < 0.02 / (1.0e6 * dt)  # the generator's 1 MHz tone
+    auto = make_gpu(pr, p_c=1, harmonics=1)
+    auto.run(nt)
+    auto.finish()
+    given = make_gpu(pr, p_c=1, harmonics=1, period=per.value)
+    given.run(nt)
+    given.finish()
+    assert auto.stream("p_c").size > 0 and np.array_equal(auto.stream("p_c"), given.stream("p_c"))
+    auto.close()
+    given.close()
