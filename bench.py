@@ -63,7 +63,10 @@ def alg_bytes(n: int, *, het=True, nonlinear=True, absorbing=True):
         per[f"k_ypass_fwd[{na}]"] = per[f"k_ypass_inv[{na}]"] = 2 * na * Cx
         per[f"k_zfused_vgrad[{na}]"] = 2 * na * Cx + K
         per[f"k_zfused_absorb[{na}]"] = na * (2 * Cx + K)
-    per["k_zfused_pgrad"] = 4 * Cx + K
+    per["k_zfused_pgrad"] = 3 * Cx + K            # F{p} in; Q and G_z out (d/dx, d/dy share Q)
+    per["k_ypass_inv_pgrad[3]"] = 5 * Cx          # Q read once, three arrays written
+    per["k_ypass_inv_pgrad[2]"] = 3 * Cx
+    per["k_ypass_inv_pgrad[1]"] = 2 * Cx
     per["k_zfused_source"] = 2 * Cx + K
     per["k_xinv_velocity"] = 3 * Cx + (6 + 3 * h) * R
     per["k_xinv_velocity_chain"] = per["k_xinv_velocity"] + 3 * Cx

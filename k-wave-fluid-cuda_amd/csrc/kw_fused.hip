@@ -112,6 +112,7 @@ struct PassArgs
   uint32_t      PX;   // row pitch of the packed (exchange) side: rows travel without their padding
   uint32_t      narr; // arrays per block (grid.z * narr arrays in the launch)
   uint32_t      z0;   // first plane of this launch (chunked plane-local passes)
+  const float2* mul[3]; // per array: optional factor mul[ky] applied to the line before its transform (ddy of the gradient)
   RowAddr       ain, aout;
 };
 
@@ -157,6 +158,12 @@ __global__ __launch_bounds__(Geo<L>::THREADS) void k_ypass(PassArgs a)
   {
     if (ACT(R2, j))
     {
+      const float2* __restrict__ m = a.mul[arr0 + ia];
+      if (m != nullptr)
+      {
+#pragma unroll
+        for (int n1 = 0; n1 < R1; n1++) v[n1] = cmulf(v[n1], m[n1 * R2 + j]);
+      }
       step_a<L, DIR>(v, j, twl);
 #pragma unroll
       for (int k1 = 0; k1 < R1; k1++) lds[k1 * G::SF + j * G::NL + c] = v[k1];
@@ -261,7 +268,9 @@ template<int L, int MODE> __global__ __launch_bounds__(Geo<L>::THREADS) void k_z
   constexpr bool MULTI  = (MODE == Z_VGRAD || MODE == Z_ABSORB);
   const uint32_t arr0   = MULTI ? a.arr0 : 0;
   const uint32_t narr   = MULTI ? a.narr : 1;
-  constexpr int  NOUT   = (MODE == Z_PGRAD) ? 3 : 1;
+  // PGRAD: the x- and y-gradients share one z-inverse — ddx(kx), ddy(ky) do not depend on kz, so they are applied after
+  // the way back (y-pass / x-pass); only Q = F_z^-1{kappa X} and G_z = F_z^-1{ddz kappa X} leave this kernel
+  constexpr int  NOUT   = (MODE == Z_PGRAD) ? 2 : 1;
 
   float2 v[R1];
   if (ACT(R2, j))
@@ -336,8 +345,13 @@ template<int L, int MODE> __global__ __launch_bounds__(Geo<L>::THREADS) void k_z
       {
         if (MODE == Z_PGRAD || MODE == Z_VGRAD)
         {
-          const uint32_t axis = (MODE == Z_PGRAD) ? o : arr;
-          if (axis == 2)
+          const uint32_t axis = (MODE == Z_PGRAD) ? (o == 0 ? 3u : 2u) : arr;
+          if (axis == 3)
+          {
+#pragma unroll
+            for (int k2 = 0; k2 < R2; k2++) w[k2] = X[k2];
+          }
+          else if (axis == 2)
           {
             uint32_t jz = j;
             asm volatile("" : "+v"(jz)); // keeps the 16 ddz loads inside this pass instead of hoisted registers
@@ -361,7 +375,7 @@ template<int L, int MODE> __global__ __launch_bounds__(Geo<L>::THREADS) void k_z
       inverse_from_regs<L>(w, r, lds, c, j, twl);
       if (ACT(R2, j) && valid)
       {
-        float2* __restrict__ out = a.out[(MODE == Z_PGRAD) ? o : arr];
+        float2* __restrict__ out = a.out[(MODE == Z_PGRAD) ? 2 * o : arr];
         uint32_t ob = base + static_cast<uint32_t>(j) * zstr;
         asm volatile("" : "+v"(ob)); // recomputed per output: 16 hoisted 64-bit addresses cost an occupancy step
 #pragma unroll
@@ -451,10 +465,12 @@ __global__ __launch_bounds__(Geo<L / 2>::THREADS) void k_ypass_split(PassArgs a)
     }
   }
   lds_barrier(); // twiddle tables visible (the line loads stay in flight across it)
+  const float2* __restrict__ m = a.mul[blockIdx.z];
 #pragma unroll
   for (int n1 = 0; n1 < R1; n1++)
   {
-    const float2 lo = va[n1], hi = vb[n1];
+    float2 lo = va[n1], hi = vb[n1];
+    if (m != nullptr) { lo = cmulf(lo, m[n1 * R2 + j]); hi = cmulf(hi, m[H + n1 * R2 + j]); }
     va[n1] = cadd(lo, hi);
     vb[n1] = apply_tw<DIR>(csub(lo, hi), tw2[n1 * R2 + j]);
   }
@@ -510,7 +526,9 @@ template<int L, int MODE> __global__ __launch_bounds__(Geo<L / 2>::THREADS) void
   const uint32_t opbase = ky * a.Pop + kxl, opzstr = a.ny * a.Pop;
   constexpr bool MULTI  = (MODE == Z_VGRAD || MODE == Z_ABSORB);
   const uint32_t arr    = MULTI ? a.arr0 + blockIdx.z : 0;
-  constexpr int  NOUT   = (MODE == Z_PGRAD) ? 3 : 1;
+  // PGRAD: the x- and y-gradients share one z-inverse — ddx(kx), ddy(ky) do not depend on kz, so they are applied after
+  // the way back (y-pass / x-pass); only Q = F_z^-1{kappa X} and G_z = F_z^-1{ddz kappa X} leave this kernel
+  constexpr int  NOUT   = (MODE == Z_PGRAD) ? 2 : 1;
 
   float2 Xa[R2], Xb[R2]; // after the forward transform: X[2*(j + R1*k2)], X[2*(j + R1*k2) + 1]
   {
@@ -552,7 +570,7 @@ template<int L, int MODE> __global__ __launch_bounds__(Geo<L / 2>::THREADS) void
 #pragma unroll 1
   for (int o = 0; o < NOUT; o++)
   {
-    const uint32_t axis = (MODE == Z_PGRAD) ? o : arr;
+    const uint32_t axis = (MODE == Z_PGRAD) ? (o == 0 ? 3u : 2u) : arr;
     float2 ra[R1], rb[R1];
 #pragma unroll
     for (int half = 0; half < 2; half++)
@@ -560,7 +578,12 @@ template<int L, int MODE> __global__ __launch_bounds__(Geo<L / 2>::THREADS) void
       float2 w[R2];
       if (MODE == Z_PGRAD || MODE == Z_VGRAD)
       {
-        if (axis == 2)
+        if (axis == 3)
+        {
+#pragma unroll
+          for (int k2 = 0; k2 < R2; k2++) w[k2] = half ? Xb[k2] : Xa[k2];
+        }
+        else if (axis == 2)
         {
           uint32_t jz = 2 * j + half;
           asm volatile("" : "+v"(jz));
@@ -585,7 +608,7 @@ template<int L, int MODE> __global__ __launch_bounds__(Geo<L / 2>::THREADS) void
     }
     if (valid)
     {
-      float2* __restrict__ out = a.out[(MODE == Z_PGRAD) ? o : arr];
+      float2* __restrict__ out = a.out[(MODE == Z_PGRAD) ? 2 * o : arr];
       uint32_t ob = base + static_cast<uint32_t>(j) * zstr;
       asm volatile("" : "+v"(ob));
 #pragma unroll
@@ -703,12 +726,14 @@ struct XinvArgs
   uint32_t      comp0; // first component of this launch (per-array launches)
   float2*       fout[3]; // CHAIN: where the forward x-transform of the epilogue's result goes (scratch rows)
   uint32_t      tile0;   // first 2*NL-row tile of this launch (chunked plane-local passes)
+  const float2* mulx[3]; // per component: optional factor mulx[kx] applied to the rows before the inverse (ddx of the gradient)
 };
 
 // standalone inverse of one array for this block's 32 rows; thread (c, f<R1) ends with x[f + R1*k2] of rows (2c, 2c+1)
 template<int L>
 __device__ __forceinline__ void xinv_lines(const float2* __restrict__ src, uint32_t P, float2* lds, int c, int f,
-                                           const float2* tw, float2 (&w)[Fac<L>::R2], uint32_t tile)
+                                           const float2* tw, float2 (&w)[Fac<L>::R2], uint32_t tile,
+                                           const float2* __restrict__ mulx = nullptr)
 {
   using G = Geo<L>;
   constexpr int R1 = G::R1, R2 = G::R2, HALF = L / 2 + 1;
@@ -720,6 +745,7 @@ __device__ __forceinline__ void xinv_lines(const float2* __restrict__ src, uint3
     const uint32_t r = tile_row0 + 2 * cc;
     float2       A  = src[r * P + k];
     float2       B  = src[(r + 1) * P + k];
+    if (mulx != nullptr) { const float2 d = mulx[k]; A = cmulf(A, d); B = cmulf(B, d); }
     if (k == 0 || k == L / 2) { A.y = 0.f; B.y = 0.f; } // C2R ignores the imaginary part of DC / Nyquist
     lds[cc * G::ZP + k] = make_float2(A.x - B.y, A.y + B.x);
     if (k != 0 && k != L / 2) lds[cc * G::ZP + L - k] = make_float2(A.x + B.y, B.x - A.y);
@@ -783,7 +809,7 @@ template<int L, int EPI, bool CHAIN> __global__ __launch_bounds__(Geo<L>::THREAD
   for (int i = 0; i < NA; i++)
   {
     float2 w[R2];
-    xinv_lines<L>(a.in[(NA == 1) ? comp : i], a.P, lds, c, f, twl, w, tile); // ends with a barrier
+    xinv_lines<L>(a.in[(NA == 1) ? comp : i], a.P, lds, c, f, twl, w, tile, (NA == 1) ? a.mulx[comp] : nullptr); // ends with a barrier
     if (ACT(R1, f))
     {
 #pragma unroll
@@ -1081,6 +1107,18 @@ bool supported_len(uint32_t n) { return n == 16 || n == 32 || n == 64 || n == 12
     KW_LAUNCH_CHECK();                                                                                                 \
   } while (0)
 
+#define KW_FUSED_READY(ctx)                                                                                            \
+  do {                                                                                                                 \
+    KW_CHECK_CONSTS(ctx);                                                                                              \
+    if (!(ctx)->fused.ready) { kw_set_error("%s: kw_fused_create has not been called", __func__); return KW_ERR_STATE; } \
+  } while (0)
+
+#define KW_TRY(call)                                                                                                   \
+  do {                                                                                                                 \
+    kw_status st_ = (call);                                                                                            \
+    if (st_ != KW_OK) return st_;                                                                                      \
+  } while (0)
+
 kw_status launch_xfwd(kw_ctx* ctx, int narr, const float* const* in, float2* const* out)
 {
   const kw_constants& c = ctx->c;
@@ -1100,16 +1138,24 @@ kw_status launch_xfwd(kw_ctx* ctx, int narr, const float* const* in, float2* con
 
 // y-pass.  pack_out / pack_in select the packed (per-peer-chunk) row layout on that side; with one rank both layouts
 // coincide and the pass may run in place.
+// mul: optional per-array factor (see PassArgs).  ordered: the arrays must be taken in list order by one block (a later
+// one overwrites, in place, the input of an earlier one) — true for the pressure-gradient pair below.
 kw_status launch_ypass(kw_ctx* ctx, int dir, int narr, float2* const* in, float2* const* out, bool pack_in, bool pack_out,
-                       uint32_t z0 = 0, uint32_t nzc = 0)
+                       uint32_t z0 = 0, uint32_t nzc = 0, const float2* const* mul = nullptr, bool ordered = false)
 {
   const kw_constants& c = ctx->c;
   const auto& f = ctx->fused;
-  static const char* const names[2][3] = { { "k_ypass_fwd[1]", "k_ypass_fwd[2]", "k_ypass_fwd[3]" },
-                                           { "k_ypass_inv[1]", "k_ypass_inv[2]", "k_ypass_inv[3]" } };
-  KW_PROF(ctx, names[dir < 0 ? 0 : 1][narr - 1]);
+  if (ordered && narr > 1 && (!f.ypass_loop || (c.ny == 512 && f.split512)))
+  { // one array per block in these kernels: order by launch instead
+    KW_TRY(launch_ypass(ctx, dir, 1, in, out, pack_in, pack_out, z0, nzc, mul, false));
+    return launch_ypass(ctx, dir, narr - 1, in + 1, out + 1, pack_in, pack_out, z0, nzc, mul ? mul + 1 : nullptr, true);
+  }
+  static const char* const names[3][3] = { { "k_ypass_fwd[1]", "k_ypass_fwd[2]", "k_ypass_fwd[3]" },
+                                           { "k_ypass_inv[1]", "k_ypass_inv[2]", "k_ypass_inv[3]" },
+                                           { "k_ypass_inv_pgrad[1]", "k_ypass_inv_pgrad[2]", "k_ypass_inv_pgrad[3]" } };
+  KW_PROF(ctx, names[dir < 0 ? 0 : (mul != nullptr ? 2 : 1)][narr - 1]);
   PassArgs a{};
-  for (int i = 0; i < narr; i++) { a.in[i] = in[i]; a.out[i] = out[i]; }
+  for (int i = 0; i < narr; i++) { a.in[i] = in[i]; a.out[i] = out[i]; a.mul[i] = mul ? mul[i] : nullptr; }
   a.tw  = f.tw[1];
   a.nxc = c.nx_complex;
   a.P   = f.P;
@@ -1193,18 +1239,6 @@ template<int EPI, bool CHAIN = false> kw_status launch_xinv(kw_ctx* ctx, int nco
   return KW_OK;
 }
 
-#define KW_FUSED_READY(ctx)                                                                                            \
-  do {                                                                                                                 \
-    KW_CHECK_CONSTS(ctx);                                                                                              \
-    if (!(ctx)->fused.ready) { kw_set_error("%s: kw_fused_create has not been called", __func__); return KW_ERR_STATE; } \
-  } while (0)
-
-#define KW_TRY(call)                                                                                                   \
-  do {                                                                                                                 \
-    kw_status st_ = (call);                                                                                            \
-    if (st_ != KW_OK) return st_;                                                                                      \
-  } while (0)
-
 // split-phase exchange of scratch array `slot`: start is ordered after the work enqueued so far; wait orders later
 // work after its completion.  Without asynchronous callbacks, start is the blocking exchange and wait a no-op.
 kw_status xstart(kw_ctx* ctx, int slot, float2* send, float2* recv)
@@ -1267,7 +1301,9 @@ kw_status forward_xy(kw_ctx* ctx, int narr, const float* const* in, int s0 = 0)
 // Single rank: the plane-local tail of a stage — y-inverse, x-inverse + epilogue and, when the epilogue chains the
 // x-spectra of its results into S[0..nchain), their forward y-pass — runs per chunk of planes, so that what one kernel
 // writes is still in the Infinity Cache when the next one reads it.
-template<int EPI, bool CHAIN> kw_status plane_local_tail(kw_ctx* ctx, int narr, int ncomp, const XinvArgs& x, int nchain)
+template<int EPI, bool CHAIN> kw_status plane_local_tail(kw_ctx* ctx, int narr, int ncomp, const XinvArgs& x, int nchain,
+                                                         float2* const* yin = nullptr, float2* const* yout = nullptr,
+                                                         const float2* const* ymul = nullptr)
 {
   auto& f = ctx->fused;
   const kw_constants& c = ctx->c;
@@ -1276,12 +1312,41 @@ template<int EPI, bool CHAIN> kw_status plane_local_tail(kw_ctx* ctx, int narr, 
   const uint32_t nzc = c.nz / nch;
   for (uint32_t ch = 0; ch < nch; ch++)
   {
-    KW_TRY(launch_ypass(ctx, +1, narr, f.s, f.s, false, false, ch * nzc, nzc));
+    KW_TRY(launch_ypass(ctx, +1, narr, yin ? yin : f.s, yout ? yout : f.s, false, false, ch * nzc, nzc, ymul, ymul != nullptr));
     KW_TRY((launch_xinv<EPI, CHAIN>(ctx, ncomp, x, ch * nzc, nzc)));
     if (CHAIN) KW_TRY(launch_ypass(ctx, -1, nchain, f.s, f.s, false, false, ch * nzc, nzc));
   }
   if (CHAIN) f.y_done = nchain;
   return KW_OK;
+}
+
+// Way back of the pressure gradient after launch_zfused<Z_PGRAD>: S[0] = Q = F_z^-1{kappa F{p}}, S[2] = G_z (x and y
+// still transformed).  d/dx and d/dy share Q: the y-inverse produces F_y^-1{ddy Q} into S[1] and F_y^-1{Q} into S[0]
+// (one read of Q), the x-inverse of component 0 applies ddx(kx) to its rows.  Two transposes instead of three in slab
+// mode, one array less written by the z-pass and read by the y-pass everywhere.
+template<int EPI, bool CHAIN> kw_status gradient_tail(kw_ctx* ctx, XinvArgs x, const float2* ddx, const float2* ddy)
+{
+  auto& f = ctx->fused;
+  x.mulx[0] = ddx;
+  const float2* mul[3] = { ddy, nullptr, nullptr };
+  if (f.slab)
+  {
+    KW_TRY(xstart(ctx, 0, f.s[0], f.t[0]));
+    KW_TRY(xstart(ctx, 2, f.s[2], f.t[2]));
+    KW_TRY(xwait(ctx, 0));
+    float2* yin[2]  = { f.t[0], f.t[0] };
+    float2* yout[2] = { f.s[1], f.s[0] };
+    KW_TRY(launch_ypass(ctx, +1, 2, yin, yout, true, false, 0, 0, mul, false)); // out of place: no ordering needed
+    x.comp0 = 0;
+    KW_TRY((launch_xinv<EPI, CHAIN>(ctx, 2, x)));
+    KW_TRY(xwait(ctx, 2));
+    KW_TRY(launch_ypass(ctx, +1, 1, f.t + 2, f.s + 2, true, false));
+    x.comp0 = 2;
+    return launch_xinv<EPI, CHAIN>(ctx, 1, x);
+  }
+  float2* yin[3]  = { f.s[0], f.s[0], f.s[2] };
+  float2* yout[3] = { f.s[1], f.s[0], f.s[2] };
+  return plane_local_tail<EPI, CHAIN>(ctx, 3, 3, x, CHAIN ? 3 : 0, yin, yout, mul);
 }
 
 // inverse half: transpose back, y-inverse; leaves [nz][ny][P] spectra (x still transformed) in S[]
@@ -1497,37 +1562,10 @@ kw_status kw_fused_velocity(kw_ctx* ctx, const float* p, float* ux, float* uy, f
   const float* dt[3] = { dtx, dty, dtz };
   const float* pml[3] = { pmlx, pmly, pmlz };
   for (int i = 0; i < 3; i++) { x.in[i] = S[i]; x.out[i] = u[i]; x.m0[i] = dt[i]; x.m1[i] = pml[i]; x.fout[i] = S[i]; }
-  if (ctx->fused.slab)
-  { // slab mode: the three transposes back are pipelined against the y-inverse / x-inverse of the previous component
-    auto& f = ctx->fused;
-    for (int i = 0; i < 3; i++) KW_TRY(xstart(ctx, i, f.s[i], f.t[i]));
-    for (int i = 0; i < 3; i++)
-    {
-      KW_TRY(xwait(ctx, i));
-      KW_TRY(launch_ypass(ctx, +1, 1, f.t + i, f.s + i, true, false));
-      x.comp0 = i;
-      if (chain_u_spectra) KW_TRY((launch_xinv<EPI_VELOCITY, true>(ctx, 1, x)));
-      else KW_TRY(launch_xinv<EPI_VELOCITY>(ctx, 1, x));
-    }
-    return KW_OK;
-  }
-  if (ctx->fused.per_array && !chain_u_spectra)
-  { // A/B knob: whole chain per array
-    for (int i = 0; i < 3; i++)
-    {
-      KW_TRY(inverse_y(ctx, 1, i));
-      x.comp0 = i;
-      KW_TRY(launch_xinv<EPI_VELOCITY>(ctx, 1, x));
-    }
-  }
-  else
-  {
-    // chained: the updated velocity rows are forward-transformed along x (and y) on the spot (valid as long as nothing
-    // else writes u before kw_fused_density(..., KW_FUSED_U_IN_SCRATCH))
-    if (chain_u_spectra) KW_TRY((plane_local_tail<EPI_VELOCITY, true>(ctx, 3, 3, x, 3)));
-    else KW_TRY((plane_local_tail<EPI_VELOCITY, false>(ctx, 3, 3, x, 0)));
-  }
-  return KW_OK;
+  // chained: the updated velocity rows are forward-transformed along x (and y) on the spot (valid as long as nothing
+  // else writes u before kw_fused_density(..., KW_FUSED_U_IN_SCRATCH))
+  if (chain_u_spectra) return gradient_tail<EPI_VELOCITY, true>(ctx, x, (const float2*)ddx, (const float2*)ddy);
+  return gradient_tail<EPI_VELOCITY, false>(ctx, x, (const float2*)ddx, (const float2*)ddy);
 }
 
 // A12 second half: u <- +0.5*dt/rho0_sg * ifftn(ddk_pos * kappa * fftn(p)) / N
@@ -1547,13 +1585,11 @@ kw_status kw_fused_initial_velocity(kw_ctx* ctx, const float* p, float* ux, floa
   z.op[0] = kappa_padded;
   z.dd[0] = (const float2*)ddx; z.dd[1] = (const float2*)ddy; z.dd[2] = (const float2*)ddz;
   KW_TRY(launch_zfused<Z_PGRAD>(ctx, 1, z));
-  KW_TRY(inverse_y(ctx, 3));
   XinvArgs x{};
   float* u[3] = { ux, uy, uz };
   const float* dt[3] = { dtx, dty, dtz };
   for (int i = 0; i < 3; i++) { x.in[i] = S[i]; x.out[i] = u[i]; x.m0[i] = dt[i]; }
-  KW_TRY(launch_xinv<EPI_INITVEL>(ctx, 3, x));
-  return KW_OK;
+  return gradient_tail<EPI_INITVEL, false>(ctx, x, (const float2*)ddx, (const float2*)ddy);
 }
 
 // A6-A9 (+ the term kernels of A11 when terms != 0): du = ifftn(ddk_neg*kappa*fftn(u))/N; rho update; pressure terms

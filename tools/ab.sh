@@ -6,7 +6,7 @@ L=k-wave-fluid-cuda_amd/lib
 for rep in 1 2; do
   for d in ab/*/; do
     v=$(basename $d)
-    cp ab/$v/*.so $L/
+    cp ab/$v/libkwave_hip.so $L/   # device layer only: the host layer of the working tree binds newer kwh_* symbols
     python bench.py --no-cpu "$@" > gpurun_out/ab_${v}_${rep}.json
     python - <<PY
 import json

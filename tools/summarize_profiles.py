@@ -110,7 +110,7 @@ def main():
     def per_array(kernel, arrays_per_step):
         t = by.get(kernel)
         return t["traffic_bytes"] * t["launches"] / steps / arrays_per_step if t else 0.0
-    yf, yi = per_array("k_ypass<256, -1, false, false>", 6), per_array("k_ypass<256, 1, false, false>", 8)
+    yf, yi = per_array("k_ypass<256, -1, false, false>", 6), per_array("k_ypass<256, 1, false, false>", 7.5)
     g = lambda k: by.get(k, {}).get("traffic_bytes", 0)
     entry = {
         "fused_velocity": g("k_xfwd<256>") + yf + g("k_zfused<256, 0>") + 3 * yi + 3 * g("k_xinv<256, 1, true>") / 1 + 3 * yf,
@@ -123,6 +123,7 @@ def main():
                    "k_zfused_vgrad[3]": g("k_zfused<256, 1>"), "k_zfused_absorb[2]": g("k_zfused<256, 2>"),
                    "k_xinv_velocity_chain": g("k_xinv<256, 1, true>"), "k_xinv_density_chain": g("k_xinv<256, 3, true>"),
                    "k_xinv_psum": g("k_xinv<256, 4, false>"), "k_xinv_psum_chain": g("k_xinv<256, 4, true>")}
+    bench_names["k_ypass_inv_pgrad[3]"] = 2.5 * yi
     for na in (1, 2, 3):
         bench_names[f"k_ypass_fwd[{na}]"] = na * yf
         bench_names[f"k_ypass_inv[{na}]"] = na * yi
