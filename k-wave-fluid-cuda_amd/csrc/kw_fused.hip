@@ -738,17 +738,34 @@ __device__ __forceinline__ void xinv_lines(const float2* __restrict__ src, uint3
   using G = Geo<L>;
   constexpr int R1 = G::R1, R2 = G::R2, HALF = L / 2 + 1;
   const uint32_t tile_row0 = tile * G::NL * 2;
-  for (int e = threadIdx.x; e < G::NL * HALF; e += G::THREADS)
+  // all row loads of the tile are requested before the first one is consumed (a load-use loop would expose the memory
+  // latency once per iteration); the last, partial iteration re-reads the final element instead of being predicated
+  constexpr int NE = (G::NL * HALF + G::THREADS - 1) / G::THREADS;
+  float2 A[NE], B[NE];
+#pragma unroll
+  for (int it = 0; it < NE; it++)
   {
-    const int    cc = e / HALF;
-    const int    k  = e - cc * HALF;
+    const int e  = min(static_cast<int>(threadIdx.x) + it * G::THREADS, G::NL * HALF - 1);
+    const int cc = e / HALF;
+    const int k  = e - cc * HALF;
     const uint32_t r = tile_row0 + 2 * cc;
-    float2       A  = src[r * P + k];
-    float2       B  = src[(r + 1) * P + k];
-    if (mulx != nullptr) { const float2 d = mulx[k]; A = cmulf(A, d); B = cmulf(B, d); }
-    if (k == 0 || k == L / 2) { A.y = 0.f; B.y = 0.f; } // C2R ignores the imaginary part of DC / Nyquist
-    lds[cc * G::ZP + k] = make_float2(A.x - B.y, A.y + B.x);
-    if (k != 0 && k != L / 2) lds[cc * G::ZP + L - k] = make_float2(A.x + B.y, B.x - A.y);
+    A[it] = src[r * P + k];
+    B[it] = src[(r + 1) * P + k];
+  }
+#pragma unroll
+  for (int it = 0; it < NE; it++)
+  {
+    const int e = static_cast<int>(threadIdx.x) + it * G::THREADS;
+    if (e < G::NL * HALF)
+    {
+      const int cc = e / HALF;
+      const int k  = e - cc * HALF;
+      float2 a = A[it], b = B[it];
+      if (mulx != nullptr) { const float2 d = mulx[k]; a = cmulf(a, d); b = cmulf(b, d); }
+      if (k == 0 || k == L / 2) { a.y = 0.f; b.y = 0.f; } // C2R ignores the imaginary part of DC / Nyquist
+      lds[cc * G::ZP + k] = make_float2(a.x - b.y, a.y + b.x);
+      if (k != 0 && k != L / 2) lds[cc * G::ZP + L - k] = make_float2(a.x + b.y, b.x - a.y);
+    }
   }
   lds_barrier();
   float2 v[R1];
@@ -1082,6 +1099,42 @@ template<int L, int LEVEL> __global__ __launch_bounds__(Geo<L>::THREADS) void k_
   {
 #pragma unroll
     for (int k2 = 0; k2 < R2; k2++) S[b + kx + k2 * (R1 * a.ain.estride * a.P)] = w[k2];
+  }
+}
+
+// memory pattern of k_xinv<velocity, chain> without its arithmetic: per block 32 spectrum rows in, 32 rows of two real
+// arrays in (float4), one real array out, 32 spectrum rows out
+template<int L> __global__ __launch_bounds__(Geo<L>::THREADS) void k_probe_xinv(XinvArgs a)
+{
+  using G = Geo<L>;
+  constexpr int HALF = L / 2 + 1, Q4 = L / 4, NQ = (2 * G::NL * Q4) / G::THREADS;
+  const uint32_t comp = blockIdx.y;
+  const uint32_t tile_row0 = blockIdx.x * G::NL * 2;
+  const float2* __restrict__ src = a.in[comp];
+  float2 acc = make_float2(0.f, 0.f);
+  for (int e = threadIdx.x; e < G::NL * HALF; e += G::THREADS)
+  {
+    const int cc = e / HALF, k = e - cc * HALF;
+    const uint32_t r = tile_row0 + 2 * cc;
+    const float2 A = src[r * a.P + k], B = src[(r + 1) * a.P + k];
+    acc.x += A.x + B.x; acc.y += A.y + B.y;
+  }
+  float4 keep[NQ];
+#pragma unroll
+  for (int q = 0; q < NQ; q++)
+  {
+    const uint32_t i = blockIdx.x * (2 * G::NL * L) + 4u * (threadIdx.x + q * G::THREADS);
+    const float4 u = ld4(a.out[comp] + i), d = ld4(a.m0[comp] + i);
+    keep[q] = make_float4(u.x + d.x + acc.x, u.y + d.y, u.z + d.z, u.w + d.w + acc.y);
+    st4(a.out[comp] + i, keep[q]);
+  }
+  float2* __restrict__ dst = a.fout[comp];
+  for (int e = threadIdx.x; e < G::NL * HALF; e += G::THREADS)
+  {
+    const int cc = e / HALF, k = e - cc * HALF;
+    const uint32_t r = tile_row0 + 2 * cc;
+    dst[r * a.P + k]       = make_float2(keep[0].x, acc.y);
+    dst[(r + 1) * a.P + k] = make_float2(keep[NQ - 1].y, acc.x);
   }
 }
 
@@ -1778,6 +1831,18 @@ kw_status kw_fused_probe(kw_ctx* ctx, int which, const float* op)
   else LAUNCH((k_probe_tile<LEN, 1>), grid, dim3(Geo<LEN>::THREADS), a)
     KW_LEN_SWITCH(c.ny, M)
 #undef M
+    return KW_OK;
+  }
+  if (which >= 20 && which <= 23)
+  { // op doubles as the real arrays: needs 6 * (N + pad) floats (u x3, dt/rho0 x3); 21..23 stagger the arrays by a pad
+    KW_REQUIRE(op != nullptr && c.nx == 256);
+    XinvArgs a{};
+    float* base = const_cast<float*>(op);
+    static const size_t pads[4] = { 0, 1024, 17408, 263168 };
+    const size_t N = static_cast<size_t>(c.nx) * c.ny * c.nz + pads[which - 20];
+    for (int i = 0; i < 3; i++) { a.in[i] = f.s[i]; a.fout[i] = f.s[i]; a.out[i] = base + i * N; a.m0[i] = base + (3 + i) * N; }
+    a.P = f.P;
+    LAUNCH((k_probe_xinv<256>), dim3(c.ny * c.nz / (2 * nl_of(c.nx)), 3, 1), dim3(Geo<256>::THREADS), a);
     return KW_OK;
   }
   if (which == 2)

@@ -30,17 +30,22 @@ def main(n=256, reps=30):
     names = {0: "y-pass (1 array)", 1: "line pass along z (1 array)", 2: "z-fused (1 array + operator)", 3: "y-pass (3 arrays)",
              10: "flat float4 copy in place", 11: "y tiles: load + store only", 12: "y tiles: + LDS exchange",
              13: "z tiles: load + store only", 14: "z tiles: + LDS exchange"}
-    for which in (10, 11, 12, 0, 13, 14, 1, 2, 3):
+    big = dev.array(np.ones(6 * (n ** 3 + 263168), dtype=np.float32))
+    names[20] = "x-inverse + velocity epilogue pattern (15 units)"
+    names[21], names[22], names[23] = "  same, arrays staggered by 4 KiB", "  same, staggered by 68 KiB", "  same, staggered by 1 MiB + 4 KiB"
+    for which in (10, 11, 12, 0, 13, 14, 1, 2, 3, 20, 21, 22, 23):
         for _ in range(3):
-            dev.call("fused_probe", which, op)
+            dev.call("fused_probe", which, big if which >= 20 else op)
         e0, e1 = dev.event(), dev.event()
         dev.record(e0)
         for _ in range(reps):
-            dev.call("fused_probe", which, op)
+            dev.call("fused_probe", which, big if which >= 20 else op)
         dev.record(e1)
         ms = dev.elapsed_ms(e0, e1) / reps
         arrays = 3 if which == 3 else 1
         traffic = 2 * cbytes * arrays + (ne.value * 4 if which == 2 else 0)
+        if which >= 20:
+            traffic = 6 * cbytes + 9 * 4 * n ** 3
         print(f"{names[which]:32s} {ms * 1e3:8.1f} us  {traffic / ms / 1e6:8.1f} GB/s")
     dev.close()
 
