@@ -730,7 +730,7 @@ struct XinvArgs
 };
 
 // standalone inverse of one array for this block's 32 rows; thread (c, f<R1) ends with x[f + R1*k2] of rows (2c, 2c+1)
-template<int L>
+template<int L, int NGRP = 1>
 __device__ __forceinline__ void xinv_lines(const float2* __restrict__ src, uint32_t P, float2* lds, int c, int f,
                                            const float2* tw, float2 (&w)[Fac<L>::R2], uint32_t tile,
                                            const float2* __restrict__ mulx = nullptr)
@@ -741,30 +741,35 @@ __device__ __forceinline__ void xinv_lines(const float2* __restrict__ src, uint3
   // all row loads of the tile are requested before the first one is consumed (a load-use loop would expose the memory
   // latency once per iteration); the last, partial iteration re-reads the final element instead of being predicated
   constexpr int NE = (G::NL * HALF + G::THREADS - 1) / G::THREADS;
-  float2 A[NE], B[NE];
+  constexpr int NG = (NE + NGRP - 1) / NGRP; // iterations per group (NGRP > 1: fewer loads in flight, fewer registers)
 #pragma unroll
-  for (int it = 0; it < NE; it++)
+  for (int g0 = 0; g0 < NE; g0 += NG)
   {
-    const int e  = min(static_cast<int>(threadIdx.x) + it * G::THREADS, G::NL * HALF - 1);
-    const int cc = e / HALF;
-    const int k  = e - cc * HALF;
-    const uint32_t r = tile_row0 + 2 * cc;
-    A[it] = src[r * P + k];
-    B[it] = src[(r + 1) * P + k];
-  }
+    float2 A[NG], B[NG];
 #pragma unroll
-  for (int it = 0; it < NE; it++)
-  {
-    const int e = static_cast<int>(threadIdx.x) + it * G::THREADS;
-    if (e < G::NL * HALF)
+    for (int it = 0; it < NG; it++)
     {
+      const int e  = min(static_cast<int>(threadIdx.x) + (g0 + it) * G::THREADS, G::NL * HALF - 1);
       const int cc = e / HALF;
       const int k  = e - cc * HALF;
-      float2 a = A[it], b = B[it];
-      if (mulx != nullptr) { const float2 d = mulx[k]; a = cmulf(a, d); b = cmulf(b, d); }
-      if (k == 0 || k == L / 2) { a.y = 0.f; b.y = 0.f; } // C2R ignores the imaginary part of DC / Nyquist
-      lds[cc * G::ZP + k] = make_float2(a.x - b.y, a.y + b.x);
-      if (k != 0 && k != L / 2) lds[cc * G::ZP + L - k] = make_float2(a.x + b.y, b.x - a.y);
+      const uint32_t r = tile_row0 + 2 * cc;
+      A[it] = src[r * P + k];
+      B[it] = src[(r + 1) * P + k];
+    }
+#pragma unroll
+    for (int it = 0; it < NG; it++)
+    {
+      const int e = static_cast<int>(threadIdx.x) + (g0 + it) * G::THREADS;
+      if (g0 + it < NE && e < G::NL * HALF)
+      {
+        const int cc = e / HALF;
+        const int k  = e - cc * HALF;
+        float2 a = A[it], b = B[it];
+        if (mulx != nullptr) { const float2 d = mulx[k]; a = cmulf(a, d); b = cmulf(b, d); }
+        if (k == 0 || k == L / 2) { a.y = 0.f; b.y = 0.f; } // C2R ignores the imaginary part of DC / Nyquist
+        lds[cc * G::ZP + k] = make_float2(a.x - b.y, a.y + b.x);
+        if (k != 0 && k != L / 2) lds[cc * G::ZP + L - k] = make_float2(a.x + b.y, b.x - a.y);
+      }
     }
   }
   lds_barrier();
@@ -802,7 +807,9 @@ __device__ __forceinline__ void   st4(float* p, const float4& v) { *reinterpret_
 // The inverse leaves each thread with x = f + R1*k2 of two rows — a 64-B-segment pattern.  The results are restaged
 // through LDS as a plain real tile [32 rows][L] and re-read as float4 in a row-contiguous mapping, so that every
 // epilogue access to the state / medium arrays is a 16-B-per-lane coalesced access.
-template<int L, int EPI, bool CHAIN> __global__ __launch_bounds__(Geo<L>::THREADS) void k_xinv(XinvArgs a)
+// (the 256-point density epilogue sits two registers above the 3-waves-per-SIMD step: ask the allocator for that step)
+template<int L, int EPI, bool CHAIN>
+__global__ __launch_bounds__(Geo<L>::THREADS, (EPI == EPI_DENSITY && L == 256) ? 3 : 1) void k_xinv(XinvArgs a)
 {
   using G = Geo<L>;
   constexpr int R1 = G::R1, R2 = G::R2;
@@ -821,12 +828,15 @@ template<int L, int EPI, bool CHAIN> __global__ __launch_bounds__(Geo<L>::THREAD
   const uint32_t tile = blockIdx.x + a.tile0;
   float4 res[NA][NQ];
   constexpr int NF = CHAIN ? ((EPI == EPI_DENSITY) ? 2 : 1) : 1; // chained forward transforms
-  float4 fw[NF][NQ];
+  // rows to chain: kept in registers, except the first of the density epilogue's two, which goes straight into the
+  // real tile in LDS (free once the last inverse has been read out) — 32 registers less at the kernel's widest point
+  constexpr bool FW0_IN_LDS = CHAIN && (EPI == EPI_DENSITY);
+  float4 fw[FW0_IN_LDS ? 1 : NF][NQ];
 #pragma unroll
   for (int i = 0; i < NA; i++)
   {
     float2 w[R2];
-    xinv_lines<L>(a.in[(NA == 1) ? comp : i], a.P, lds, c, f, twl, w, tile, (NA == 1) ? a.mulx[comp] : nullptr); // ends with a barrier
+    xinv_lines<L, (EPI == EPI_DENSITY) ? 2 : 1>(a.in[(NA == 1) ? comp : i], a.P, lds, c, f, twl, w, tile, (NA == 1) ? a.mulx[comp] : nullptr); // ends with a barrier
     if (ACT(R1, f))
     {
 #pragma unroll
@@ -850,166 +860,202 @@ template<int L, int EPI, bool CHAIN> __global__ __launch_bounds__(Geo<L>::THREAD
 
   const kw_constants& k = a.c;
   const uint32_t tile_row0 = tile * G::NL * 2;
+  // The operands of the epilogue are requested for a group of GQ float4 per thread before the first one is used: a
+  // load - use - store loop per float4 exposes one memory round trip each time (and vmcnt also waits for the stores
+  // issued before the loads).  GQ is bounded by the register budget of each epilogue.
+  constexpr int GQ = (EPI == EPI_DENSITY) ? 1 : (EPI == EPI_PSUM) ? 2 : (NQ >= 4 ? 4 : NQ);
+  static_assert(G::THREADS % Q4 == 0 && NQ % GQ == 0, "x is the same for every float4 of a thread");
+  const uint32_t x = 4u * (threadIdx.x % Q4);
+  float4 pmlx4 = make_float4(1.f, 1.f, 1.f, 1.f);
+  if ((EPI == EPI_VELOCITY && comp == 0) || EPI == EPI_DENSITY) pmlx4 = ld4(a.m1[0] + x);
+  const bool hetRho0 = (EPI == EPI_DENSITY) && (a.m0[0] != nullptr);
+  const bool hetBonA = (EPI == EPI_DENSITY) && (a.terms == 2) && (a.m0[1] != nullptr);
 #pragma unroll
-  for (int q = 0; q < NQ; q++)
+  for (int q0 = 0; q0 < NQ; q0 += GQ)
   {
-    const int      e   = threadIdx.x + q * G::THREADS;
-    const int      row = e / Q4;
-    const uint32_t x   = 4u * static_cast<uint32_t>(e - row * Q4);
-    const uint32_t r   = tile_row0 + row;
-    const uint32_t z   = r / k.ny;
-    const uint32_t y   = r - z * k.ny;
-    const uint32_t i   = r * L + x;
-    if (EPI == EPI_STORE)
+    float4 op0[GQ], op1[GQ], op2[GQ], op3[GQ], op4[GQ];
+    float  sy[GQ], sz[GQ];
+#pragma unroll
+    for (int g = 0; g < GQ; g++)
     {
-      st4(a.out[comp] + i, res[0][q]);
+      const int      e   = threadIdx.x + (q0 + g) * G::THREADS;
+      const uint32_t r   = tile_row0 + e / Q4;
+      const uint32_t z   = r / k.ny;
+      const uint32_t y   = r - z * k.ny;
+      const uint32_t i   = r * L + x;
+      if (EPI == EPI_VELOCITY)
+      {
+        op0[g] = ld4(a.out[comp] + i);
+        if (a.m0[comp] != nullptr) op1[g] = ld4(a.m0[comp] + i);
+        if (comp == 1) sy[g] = a.m1[1][y];
+        if (comp == 2) sy[g] = a.m1[2][z];
+      }
+      else if (EPI == EPI_INITVEL)
+      {
+        if (a.m0[comp] != nullptr) op1[g] = ld4(a.m0[comp] + i);
+      }
+      else if (EPI == EPI_DENSITY)
+      {
+        op0[g] = ld4(a.out[0] + i);
+        op1[g] = ld4(a.out[1] + i);
+        op2[g] = ld4(a.out[2] + i);
+        if (hetRho0) op3[g] = ld4(a.m0[0] + i);
+        if (hetBonA) op4[g] = ld4(a.m0[1] + i);
+        sy[g] = a.m1[1][y];
+        sz[g] = a.m1[2][z];
+      }
+      else if (EPI == EPI_PSUM)
+      {
+        op0[g] = ld4(a.m0[0] + i);
+        if (a.m0[1] != nullptr) op1[g] = ld4(a.m0[1] + i);
+        if (a.m1[0] != nullptr) op2[g] = ld4(a.m1[0] + i);
+        if (a.m1[1] != nullptr) op3[g] = ld4(a.m1[1] + i);
+      }
     }
-    else if (EPI == EPI_VELOCITY)
-    { // SolverCudaKernels.cu:199-212 (heterogeneous) / :287-305 (homogeneous)
-      float*       u  = a.out[comp];
-      float4       vu = ld4(u + i);
-      const float4 g  = res[0][q];
-      float4       pml4;
-      if (comp == 0) pml4 = ld4(a.m1[0] + x);
-      else
-      {
-        const float s = (comp == 1) ? a.m1[1][y] : a.m1[2][z];
-        pml4          = make_float4(s, s, s, s);
-      }
-      if (a.m0[comp] != nullptr)
-      {
-        const float4 d = ld4(a.m0[comp] + i);
 #pragma unroll
-        for (int t = 0; t < 4; t++)
+    for (int g = 0; g < GQ; g++)
+    {
+      const int      q = q0 + g;
+      const int      e = threadIdx.x + q * G::THREADS;
+      const uint32_t r = tile_row0 + e / Q4;
+      const uint32_t i = r * L + x;
+      if (EPI == EPI_STORE)
+      {
+        st4(a.out[comp] + i, res[0][q]);
+      }
+      else if (EPI == EPI_VELOCITY)
+      { // SolverCudaKernels.cu:199-212 (heterogeneous) / :287-305 (homogeneous)
+        float4       vu   = op0[g];
+        const float4 gr   = res[0][q];
+        const float4 pml4 = (comp == 0) ? pmlx4 : make_float4(sy[g], sy[g], sy[g], sy[g]);
+        if (a.m0[comp] != nullptr)
         {
-          const float ee = k.fft_divider * f4get(g, t) * f4get(d, t);
-          const float pm = f4get(pml4, t);
-          f4put(vu, t, (f4get(vu, t) * pm - ee) * pm);
-        }
-      }
-      else
-      {
-        const float dtr     = (comp == 0) ? k.dt_rho0_sgx : (comp == 1) ? k.dt_rho0_sgy : k.dt_rho0_sgz;
-        const float divider = dtr * k.fft_divider;
+          const float4 d = op1[g];
 #pragma unroll
-        for (int t = 0; t < 4; t++)
-        {
-          const float pm = f4get(pml4, t);
-          f4put(vu, t, (f4get(vu, t) * pm - divider * f4get(g, t)) * pm);
-        }
-      }
-      st4(u + i, vu);
-      if constexpr (CHAIN) fw[0][q] = vu;
-    }
-    else if (EPI == EPI_INITVEL)
-    { // :957-980: u = ifft * (dtRho0Sg * (fftDivider*0.5)) | u = ifft * (fftDivider*0.5*dtRho0Sg)
-      const float4 g = res[0][q];
-      float4       o;
-      if (a.m0[comp] != nullptr)
-      {
-        const float4 d = ld4(a.m0[comp] + i);
-#pragma unroll
-        for (int t = 0; t < 4; t++) f4put(o, t, f4get(g, t) * (f4get(d, t) * (k.fft_divider * 0.5f)));
-      }
-      else
-      {
-        const float dtr = (comp == 0) ? k.dt_rho0_sgx : (comp == 1) ? k.dt_rho0_sgy : k.dt_rho0_sgz;
-#pragma unroll
-        for (int t = 0; t < 4; t++) f4put(o, t, f4get(g, t) * (k.fft_divider * 0.5f * dtr));
-      }
-      st4(a.out[comp] + i, o);
-    }
-    else if (EPI == EPI_DENSITY)
-    { // :1368-1392 (nonlinear) / :1480-1496 (linear); du already carries fftDivider (applied in k-space, :1220)
-      const float4 dux = res[0][q], duy = res[1][q], duz = res[2][q];
-      const float4 px4 = ld4(a.m1[0] + x);
-      const float  py = a.m1[1][y], pz = a.m1[2][z];
-      const float4 rx = ld4(a.out[0] + i), ry = ld4(a.out[1] + i), rz = ld4(a.out[2] + i);
-      const bool   hetRho0 = (a.m0[0] != nullptr);
-      float4       r04 = make_float4(k.rho0, k.rho0, k.rho0, k.rho0);
-      if (hetRho0) r04 = ld4(a.m0[0] + i);
-      float4 nrx, nry, nrz;
-#pragma unroll
-      for (int t = 0; t < 4; t++)
-      {
-        const float px = f4get(px4, t);
-        const float r0 = f4get(r04, t);
-        const float erx = f4get(rx, t), ery = f4get(ry, t), erz = f4get(rz, t);
-        if (a.nonlinear)
-        {
-          const float sumRhosDt = (2.0f * (erx + ery + erz) + r0) * k.dt;
-          f4put(nrx, t, px * ((px * erx) - sumRhosDt * f4get(dux, t)));
-          f4put(nry, t, py * ((py * ery) - sumRhosDt * f4get(duy, t)));
-          f4put(nrz, t, pz * ((pz * erz) - sumRhosDt * f4get(duz, t)));
+          for (int t = 0; t < 4; t++)
+          {
+            const float ee = k.fft_divider * f4get(gr, t) * f4get(d, t);
+            const float pm = f4get(pml4, t);
+            f4put(vu, t, (f4get(vu, t) * pm - ee) * pm);
+          }
         }
         else
         {
-          const float dtRho0 = hetRho0 ? k.dt * r0 : k.dt_rho0;
-          f4put(nrx, t, px * (px * erx - dtRho0 * f4get(dux, t)));
-          f4put(nry, t, py * (py * ery - dtRho0 * f4get(duy, t)));
-          f4put(nrz, t, pz * (pz * erz - dtRho0 * f4get(duz, t)));
+          const float dtr     = (comp == 0) ? k.dt_rho0_sgx : (comp == 1) ? k.dt_rho0_sgy : k.dt_rho0_sgz;
+          const float divider = dtr * k.fft_divider;
+#pragma unroll
+          for (int t = 0; t < 4; t++)
+          {
+            const float pm = f4get(pml4, t);
+            f4put(vu, t, (f4get(vu, t) * pm - divider * f4get(gr, t)) * pm);
+          }
         }
+        st4(a.out[comp] + i, vu);
+        if constexpr (CHAIN) fw[0][q] = vu;
       }
-      st4(a.out[0] + i, nrx);
-      st4(a.out[1] + i, nry);
-      st4(a.out[2] + i, nrz);
-      if (a.aux[0] != nullptr)
-      {
-        st4(a.aux[0] + i, dux);
-        st4(a.aux[1] + i, duy);
-        st4(a.aux[2] + i, duz);
+      else if (EPI == EPI_INITVEL)
+      { // :957-980: u = ifft * (dtRho0Sg * (fftDivider*0.5)) | u = ifft * (fftDivider*0.5*dtRho0Sg)
+        const float4 gr = res[0][q];
+        float4       o;
+        if (a.m0[comp] != nullptr)
+        {
+          const float4 d = op1[g];
+#pragma unroll
+          for (int t = 0; t < 4; t++) f4put(o, t, f4get(gr, t) * (f4get(d, t) * (k.fft_divider * 0.5f)));
+        }
+        else
+        {
+          const float dtr = (comp == 0) ? k.dt_rho0_sgx : (comp == 1) ? k.dt_rho0_sgy : k.dt_rho0_sgz;
+#pragma unroll
+          for (int t = 0; t < 4; t++) f4put(o, t, f4get(gr, t) * (k.fft_divider * 0.5f * dtr));
+        }
+        st4(a.out[comp] + i, o);
       }
-      if (a.terms == 2)
-      { // :1588-1601 with the updated densities
-        float4 b4 = make_float4(k.b_on_a, k.b_on_a, k.b_on_a, k.b_on_a);
-        if (a.m0[1] != nullptr) b4 = ld4(a.m0[1] + i);
-        float4 o0, o1, o2;
+      else if (EPI == EPI_DENSITY)
+      { // :1368-1392 (nonlinear) / :1480-1496 (linear); du already carries fftDivider (applied in k-space, :1220)
+        const float4 dux = res[0][q], duy = res[1][q], duz = res[2][q];
+        const float  py = sy[g], pz = sz[g];
+        const float4 rx = op0[g], ry = op1[g], rz = op2[g];
+        const float4 r04 = hetRho0 ? op3[g] : make_float4(k.rho0, k.rho0, k.rho0, k.rho0);
+        float4 nrx, nry, nrz;
 #pragma unroll
         for (int t = 0; t < 4; t++)
         {
-          const float eBonA   = f4get(b4, t);
-          const float r0      = f4get(r04, t);
-          const float eRhoSum = (f4get(nrx, t) + f4get(nry, t) + f4get(nrz, t));
-          const float eDuSum  = (f4get(dux, t) + f4get(duy, t) + f4get(duz, t));
-          f4put(o0, t, eRhoSum);
-          f4put(o1, t, ((eBonA * eRhoSum * eRhoSum) / (2.0f * r0)) + eRhoSum);
-          f4put(o2, t, r0 * eDuSum);
+          const float px = f4get(pmlx4, t);
+          const float r0 = f4get(r04, t);
+          const float erx = f4get(rx, t), ery = f4get(ry, t), erz = f4get(rz, t);
+          if (a.nonlinear)
+          {
+            const float sumRhosDt = (2.0f * (erx + ery + erz) + r0) * k.dt;
+            f4put(nrx, t, px * ((px * erx) - sumRhosDt * f4get(dux, t)));
+            f4put(nry, t, py * ((py * ery) - sumRhosDt * f4get(duy, t)));
+            f4put(nrz, t, pz * ((pz * erz) - sumRhosDt * f4get(duz, t)));
+          }
+          else
+          {
+            const float dtRho0 = hetRho0 ? k.dt * r0 : k.dt_rho0;
+            f4put(nrx, t, px * (px * erx - dtRho0 * f4get(dux, t)));
+            f4put(nry, t, py * (py * ery - dtRho0 * f4get(duy, t)));
+            f4put(nrz, t, pz * (pz * erz - dtRho0 * f4get(duz, t)));
+          }
         }
-        st4(a.t[1] + i, o1); // the nonlinear term is read again by the pressure sum
-        if constexpr (CHAIN) { fw[0][q] = o2; fw[1][q] = o0; }
-        else { st4(a.t[0] + i, o0); st4(a.t[2] + i, o2); }
+        st4(a.out[0] + i, nrx);
+        st4(a.out[1] + i, nry);
+        st4(a.out[2] + i, nrz);
+        if (a.aux[0] != nullptr)
+        {
+          st4(a.aux[0] + i, dux);
+          st4(a.aux[1] + i, duy);
+          st4(a.aux[2] + i, duz);
+        }
+        if (a.terms == 2)
+        { // :1588-1601 with the updated densities
+          const float4 b4 = hetBonA ? op4[g] : make_float4(k.b_on_a, k.b_on_a, k.b_on_a, k.b_on_a);
+          float4 o0, o1, o2;
+#pragma unroll
+          for (int t = 0; t < 4; t++)
+          {
+            const float eBonA   = f4get(b4, t);
+            const float r0      = f4get(r04, t);
+            const float eRhoSum = (f4get(nrx, t) + f4get(nry, t) + f4get(nrz, t));
+            const float eDuSum  = (f4get(dux, t) + f4get(duy, t) + f4get(duz, t));
+            f4put(o0, t, eRhoSum);
+            f4put(o1, t, ((eBonA * eRhoSum * eRhoSum) / (2.0f * r0)) + eRhoSum);
+            f4put(o2, t, r0 * eDuSum);
+          }
+          st4(a.t[1] + i, o1); // the nonlinear term is read again by the pressure sum
+          if constexpr (CHAIN) { *reinterpret_cast<float4*>(&ldsr[(e / Q4) * RP + x]) = o2; fw[0][q] = o0; }
+          else { st4(a.t[0] + i, o0); st4(a.t[2] + i, o2); }
+        }
+        else if (a.terms == 1)
+        { // :1733-1741
+          float4 o0, o1;
+#pragma unroll
+          for (int t = 0; t < 4; t++)
+          {
+            f4put(o0, t, f4get(nrx, t) + f4get(nry, t) + f4get(nrz, t));
+            const float duSum = f4get(dux, t) + f4get(duy, t) + f4get(duz, t);
+            f4put(o1, t, f4get(r04, t) * duSum);
+          }
+          st4(a.t[0] + i, o0); // the density sum is read again by the pressure sum
+          if constexpr (CHAIN) { *reinterpret_cast<float4*>(&ldsr[(e / Q4) * RP + x]) = o1; fw[0][q] = o0; }
+          else st4(a.t[1] + i, o1);
+        }
       }
-      else if (a.terms == 1)
-      { // :1733-1741
-        float4 o0, o1;
+      else if (EPI == EPI_PSUM)
+      { // :1877 / :1978: p = c2*(first + (fftDivider*((tauTerm*tau) - (etaTerm*eta))))
+        const float4 tt = res[0][q], et = res[1][q];
+        const float4 fi = op0[g];
+        const float4 c24  = (a.m0[1] != nullptr) ? op1[g] : make_float4(k.c2, k.c2, k.c2, k.c2);
+        const float4 tau4 = (a.m1[0] != nullptr) ? op2[g] : make_float4(k.absorb_tau, k.absorb_tau, k.absorb_tau, k.absorb_tau);
+        const float4 eta4 = (a.m1[1] != nullptr) ? op3[g] : make_float4(k.absorb_eta, k.absorb_eta, k.absorb_eta, k.absorb_eta);
+        float4 o;
 #pragma unroll
         for (int t = 0; t < 4; t++)
-        {
-          f4put(o0, t, f4get(nrx, t) + f4get(nry, t) + f4get(nrz, t));
-          const float duSum = f4get(dux, t) + f4get(duy, t) + f4get(duz, t);
-          f4put(o1, t, f4get(r04, t) * duSum);
-        }
-        st4(a.t[0] + i, o0); // the density sum is read again by the pressure sum
-        if constexpr (CHAIN) { fw[0][q] = o1; fw[1][q] = o0; }
-        else st4(a.t[1] + i, o1);
+          f4put(o, t, f4get(c24, t) * (f4get(fi, t) + (k.fft_divider * ((f4get(tt, t) * f4get(tau4, t)) - (f4get(et, t) * f4get(eta4, t))))));
+        st4(a.out[0] + i, o);
+        if constexpr (CHAIN) fw[0][q] = o;
       }
-    }
-    else if (EPI == EPI_PSUM)
-    { // :1877 / :1978: p = c2*(first + (fftDivider*((tauTerm*tau) - (etaTerm*eta))))
-      const float4 tt = res[0][q], et = res[1][q];
-      const float4 fi = ld4(a.m0[0] + i);
-      float4 c24  = make_float4(k.c2, k.c2, k.c2, k.c2);
-      float4 tau4 = make_float4(k.absorb_tau, k.absorb_tau, k.absorb_tau, k.absorb_tau);
-      float4 eta4 = make_float4(k.absorb_eta, k.absorb_eta, k.absorb_eta, k.absorb_eta);
-      if (a.m0[1] != nullptr) c24 = ld4(a.m0[1] + i);
-      if (a.m1[0] != nullptr) tau4 = ld4(a.m1[0] + i);
-      if (a.m1[1] != nullptr) eta4 = ld4(a.m1[1] + i);
-      float4 o;
-#pragma unroll
-      for (int t = 0; t < 4; t++)
-        f4put(o, t, f4get(c24, t) * (f4get(fi, t) + (k.fft_divider * ((f4get(tt, t) * f4get(tau4, t)) - (f4get(et, t) * f4get(eta4, t))))));
-      st4(a.out[0] + i, o);
-      if constexpr (CHAIN) fw[0][q] = o;
     }
   }
 
@@ -1021,13 +1067,16 @@ template<int L, int EPI, bool CHAIN> __global__ __launch_bounds__(Geo<L>::THREAD
 #pragma unroll
     for (int jf = 0; jf < NF; jf++)
     {
-#pragma unroll
-      for (int q = 0; q < NQ; q++)
+      if (!(FW0_IN_LDS && jf == 0))
       {
-        const int e   = threadIdx.x + q * G::THREADS;
-        const int row = e / Q4;
-        const int x4  = e - row * Q4;
-        *reinterpret_cast<float4*>(&ldsr[row * RP + 4 * x4]) = fw[jf][q];
+#pragma unroll
+        for (int q = 0; q < NQ; q++)
+        {
+          const int e   = threadIdx.x + q * G::THREADS;
+          const int row = e / Q4;
+          const int x4  = e - row * Q4;
+          *reinterpret_cast<float4*>(&ldsr[row * RP + 4 * x4]) = fw[FW0_IN_LDS ? 0 : jf][q];
+        }
       }
       lds_barrier();
       float2 v[R1c];
