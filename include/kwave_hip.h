@@ -314,7 +314,10 @@ KW_API kw_status kw_fused_initial_velocity(kw_ctx* ctx, const float* p, float* u
 /* computeVelocityGradient + computeDensity{Nonlinear,Linear} (KSpaceFirstOrderSolver.cpp:2126-2173; .cu:1210-1239,
  * 1358-1393, 1470-1497) and, when terms != 0, computePressureTerms{Linear(1),Nonlinear(2)} (.cu:1577-1602,1724-1742)
  * on the updated densities.  duxdx..duzdz may be NULL (gradients not stored).  terms==1: t0 = sum rho,
- * t1 = rho0 * sum du; terms==2: t0 = sum rho, t1 = nonlinear term, t2 = rho0 * sum du. */
+ * t1 = rho0 * sum du; terms==2: t0 = sum rho, t1 = nonlinear term, t2 = rho0 * sum du.
+ * terms==3 (lossless media): the equation of state itself, sumPressure{Nonlinear,Linear}Lossless (.cu:2067-2084,
+ * 2224-2236): t0 = p (output), t1 = c2 array or NULL for the scalar (INPUT, not written), t2 unused; with
+ * KW_FUSED_CHAIN_TERMS the spectrum of the new p is left for kw_fused_velocity(KW_FUSED_P_IN_SCRATCH). */
 KW_API kw_status kw_fused_density(kw_ctx* ctx, int nonlinear, const float* ux_sgx, const float* uy_sgy,
                                   const float* uz_sgz, float* rho_x, float* rho_y, float* rho_z, const float* pml_x,
                                   const float* pml_y, const float* pml_z, const float* rho0,

@@ -808,9 +808,11 @@ __device__ __forceinline__ void   st4(float* p, const float4& v) { *reinterpret_
 // through LDS as a plain real tile [32 rows][L] and re-read as float4 in a row-contiguous mapping, so that every
 // epilogue access to the state / medium arrays is a 16-B-per-lane coalesced access.
 // (the 256-point density epilogue sits two registers above the 3-waves-per-SIMD step: ask the allocator for that step)
-template<int L, int EPI, bool CHAIN>
+// TERMS: compile-time value of a.terms for the density epilogue (one specialised kernel per pressure-term mode)
+template<int L, int EPI, bool CHAIN, int TERMS = 0>
 __global__ __launch_bounds__(Geo<L>::THREADS, (EPI == EPI_DENSITY && L == 256) ? 3 : 1) void k_xinv(XinvArgs a)
 {
+  constexpr int terms = TERMS;
   using G = Geo<L>;
   constexpr int R1 = G::R1, R2 = G::R2;
   constexpr int NA  = (EPI == EPI_DENSITY) ? 3 : (EPI == EPI_PSUM) ? 2 : 1;
@@ -869,11 +871,12 @@ __global__ __launch_bounds__(Geo<L>::THREADS, (EPI == EPI_DENSITY && L == 256) ?
   float4 pmlx4 = make_float4(1.f, 1.f, 1.f, 1.f);
   if ((EPI == EPI_VELOCITY && comp == 0) || EPI == EPI_DENSITY) pmlx4 = ld4(a.m1[0] + x);
   const bool hetRho0 = (EPI == EPI_DENSITY) && (a.m0[0] != nullptr);
-  const bool hetBonA = (EPI == EPI_DENSITY) && (a.terms == 2) && (a.m0[1] != nullptr);
+  const bool hetBonA = (EPI == EPI_DENSITY) && (terms == 2 || (terms == 3 && a.nonlinear)) && (a.m0[1] != nullptr);
+  const bool hetC2   = (EPI == EPI_DENSITY) && (terms == 3) && (a.m0[2] != nullptr);
 #pragma unroll
   for (int q0 = 0; q0 < NQ; q0 += GQ)
   {
-    float4 op0[GQ], op1[GQ], op2[GQ], op3[GQ], op4[GQ];
+    float4 op0[GQ], op1[GQ], op2[GQ], op3[GQ], op4[GQ], op5[GQ];
     float  sy[GQ], sz[GQ];
 #pragma unroll
     for (int g = 0; g < GQ; g++)
@@ -901,6 +904,7 @@ __global__ __launch_bounds__(Geo<L>::THREADS, (EPI == EPI_DENSITY && L == 256) ?
         op2[g] = ld4(a.out[2] + i);
         if (hetRho0) op3[g] = ld4(a.m0[0] + i);
         if (hetBonA) op4[g] = ld4(a.m0[1] + i);
+        if (hetC2) op5[g] = ld4(a.m0[2] + i);
         sy[g] = a.m1[1][y];
         sz[g] = a.m1[2][z];
       }
@@ -1008,7 +1012,7 @@ __global__ __launch_bounds__(Geo<L>::THREADS, (EPI == EPI_DENSITY && L == 256) ?
           st4(a.aux[1] + i, duy);
           st4(a.aux[2] + i, duz);
         }
-        if (a.terms == 2)
+        if (terms == 2)
         { // :1588-1601 with the updated densities
           const float4 b4 = hetBonA ? op4[g] : make_float4(k.b_on_a, k.b_on_a, k.b_on_a, k.b_on_a);
           float4 o0, o1, o2;
@@ -1027,7 +1031,23 @@ __global__ __launch_bounds__(Geo<L>::THREADS, (EPI == EPI_DENSITY && L == 256) ?
           if constexpr (CHAIN) { *reinterpret_cast<float4*>(&ldsr[(e / Q4) * RP + x]) = o2; fw[0][q] = o0; }
           else { st4(a.t[0] + i, o0); st4(a.t[2] + i, o2); }
         }
-        else if (a.terms == 1)
+        else if (terms == 3)
+        { // lossless equation of state on the updated densities: sumPressureNonlinearLossless (:2067-2084) /
+          // sumPressureLinearLossless (:2224-2236); the new p is chained like the pressure sum's
+          const float4 b4  = hetBonA ? op4[g] : make_float4(k.b_on_a, k.b_on_a, k.b_on_a, k.b_on_a);
+          const float4 c24 = hetC2 ? op5[g] : make_float4(k.c2, k.c2, k.c2, k.c2);
+          float4 pn;
+#pragma unroll
+          for (int t = 0; t < 4; t++)
+          {
+            const float rhoSum = f4get(nrx, t) + f4get(nry, t) + f4get(nrz, t);
+            if (a.nonlinear) f4put(pn, t, f4get(c24, t) * (rhoSum + (f4get(b4, t) * (rhoSum * rhoSum) / (2.0f * f4get(r04, t)))));
+            else f4put(pn, t, f4get(c24, t) * rhoSum);
+          }
+          st4(a.t[0] + i, pn);
+          if constexpr (CHAIN) *reinterpret_cast<float4*>(&ldsr[(e / Q4) * RP + x]) = pn;
+        }
+        else if (terms == 1)
         { // :1733-1741
           float4 o0, o1;
 #pragma unroll
@@ -1067,6 +1087,7 @@ __global__ __launch_bounds__(Geo<L>::THREADS, (EPI == EPI_DENSITY && L == 256) ?
 #pragma unroll
     for (int jf = 0; jf < NF; jf++)
     {
+      if (EPI == EPI_DENSITY && jf == 1 && terms == 3) break; // lossless: only p is chained
       if (!(FW0_IN_LDS && jf == 0))
       {
 #pragma unroll
@@ -1323,7 +1344,8 @@ template<int MODE> kw_status launch_zfused(kw_ctx* ctx, int narr, ZArgs a)
   return KW_OK;
 }
 
-template<int EPI, bool CHAIN = false> kw_status launch_xinv(kw_ctx* ctx, int ncomp, XinvArgs a, uint32_t z0 = 0, uint32_t nzc = 0)
+template<int EPI, bool CHAIN = false, int TERMS = 0>
+kw_status launch_xinv(kw_ctx* ctx, int ncomp, XinvArgs a, uint32_t z0 = 0, uint32_t nzc = 0)
 {
   const kw_constants& c = ctx->c;
   static const char* const names[5][2] = { { "k_xinv_store", "k_xinv_store" }, { "k_xinv_velocity", "k_xinv_velocity_chain" },
@@ -1335,7 +1357,7 @@ template<int EPI, bool CHAIN = false> kw_status launch_xinv(kw_ctx* ctx, int nco
   a.P  = ctx->fused.P;
   a.tile0 = z0 * c.ny / (2 * nl_of(c.nx));
   const dim3 grid(c.ny * (nzc ? nzc : c.nz) / (2 * nl_of(c.nx)), ncomp, 1);
-#define M(LEN) LAUNCH((k_xinv<LEN, EPI, CHAIN>), grid, dim3(Geo<LEN>::THREADS), a)
+#define M(LEN) LAUNCH((k_xinv<LEN, EPI, CHAIN, TERMS>), grid, dim3(Geo<LEN>::THREADS), a)
   KW_LEN_SWITCH(c.nx, M)
 #undef M
   return KW_OK;
@@ -1403,7 +1425,8 @@ kw_status forward_xy(kw_ctx* ctx, int narr, const float* const* in, int s0 = 0)
 // Single rank: the plane-local tail of a stage — y-inverse, x-inverse + epilogue and, when the epilogue chains the
 // x-spectra of its results into S[0..nchain), their forward y-pass — runs per chunk of planes, so that what one kernel
 // writes is still in the Infinity Cache when the next one reads it.
-template<int EPI, bool CHAIN> kw_status plane_local_tail(kw_ctx* ctx, int narr, int ncomp, const XinvArgs& x, int nchain,
+template<int EPI, bool CHAIN, int TERMS = 0>
+kw_status plane_local_tail(kw_ctx* ctx, int narr, int ncomp, const XinvArgs& x, int nchain,
                                                          float2* const* yin = nullptr, float2* const* yout = nullptr,
                                                          const float2* const* ymul = nullptr)
 {
@@ -1415,7 +1438,7 @@ template<int EPI, bool CHAIN> kw_status plane_local_tail(kw_ctx* ctx, int narr, 
   for (uint32_t ch = 0; ch < nch; ch++)
   {
     KW_TRY(launch_ypass(ctx, +1, narr, yin ? yin : f.s, yout ? yout : f.s, false, false, ch * nzc, nzc, ymul, ymul != nullptr));
-    KW_TRY((launch_xinv<EPI, CHAIN>(ctx, ncomp, x, ch * nzc, nzc)));
+    KW_TRY((launch_xinv<EPI, CHAIN, TERMS>(ctx, ncomp, x, ch * nzc, nzc)));
     if (CHAIN) KW_TRY(launch_ypass(ctx, -1, nchain, f.s, f.s, false, false, ch * nzc, nzc));
   }
   if (CHAIN) f.y_done = nchain;
@@ -1708,8 +1731,9 @@ kw_status kw_fused_density(kw_ctx* ctx, int nonlinear, const float* ux, const fl
   KW_REQUIRE(!chain_terms || terms != 0);
   KW_REQUIRE(ux && uy && uz && rx && ry && rz && pmlx && pmly && pmlz && kappa_padded && ddx && ddy && ddz);
   KW_REQUIRE((duxdx == nullptr) == (duydy == nullptr) && (duxdx == nullptr) == (duzdz == nullptr));
-  KW_REQUIRE(terms >= 0 && terms <= 2);
-  KW_REQUIRE(terms == 0 || (t0 && t1 && (terms == 1 || t2)));
+  KW_REQUIRE(terms >= 0 && terms <= 3);
+  KW_REQUIRE(terms == 0 || terms == 3 || (t0 && t1 && (terms == 1 || t2)));
+  KW_REQUIRE(terms != 3 || t0 != nullptr);
   float2** S = ctx->fused.s;
   const float* in3[3] = { ux, uy, uz };
   ZArgs z{};
@@ -1744,17 +1768,30 @@ kw_status kw_fused_density(kw_ctx* ctx, int nonlinear, const float* ux, const fl
   for (int i = 0; i < 3; i++) { x.in[i] = S[i]; x.out[i] = rho[i]; x.m1[i] = pml[i]; x.aux[i] = du[i]; x.t[i] = t[i]; }
   x.m0[0]     = rho0;
   x.m0[1]     = bona;
+  x.m0[2]     = (terms == 3) ? t1 : nullptr; // lossless pressure: t0 = p (out), t1 = c2 array or NULL (in)
   x.nonlinear = nonlinear;
   x.terms     = terms;
   x.fout[0]   = S[0]; // chained: x-spectrum of rho0 * sum(du)
   x.fout[1]   = S[1]; //          x-spectrum of sum(rho)
-  if (tail_chunked)
+  // one specialised kernel per pressure-term mode
+#define DENSITY_TAIL(T)                                                                                                \
+  do {                                                                                                                 \
+    if (tail_chunked)                                                                                                  \
+    {                                                                                                                  \
+      if (chain_terms) KW_TRY((plane_local_tail<EPI_DENSITY, true, (T) == 0 ? 1 : (T)>(ctx, 3, 1, x, (T) == 3 ? 1 : 2))); \
+      else KW_TRY((plane_local_tail<EPI_DENSITY, false, (T)>(ctx, 3, 1, x, 0)));                                       \
+    }                                                                                                                  \
+    else if (chain_terms) KW_TRY((launch_xinv<EPI_DENSITY, true, (T) == 0 ? 1 : (T)>(ctx, 1, x)));                      \
+    else KW_TRY((launch_xinv<EPI_DENSITY, false, (T)>(ctx, 1, x)));                                                    \
+  } while (0)
+  switch (terms)
   {
-    if (chain_terms) KW_TRY((plane_local_tail<EPI_DENSITY, true>(ctx, 3, 1, x, 2)));
-    else KW_TRY((plane_local_tail<EPI_DENSITY, false>(ctx, 3, 1, x, 0)));
+    case 0: DENSITY_TAIL(0); break; // (chain_terms requires terms != 0: checked above)
+    case 1: DENSITY_TAIL(1); break;
+    case 2: DENSITY_TAIL(2); break;
+    default: DENSITY_TAIL(3); break;
   }
-  else if (chain_terms) KW_TRY((launch_xinv<EPI_DENSITY, true>(ctx, 1, x)));
-  else KW_TRY(launch_xinv<EPI_DENSITY>(ctx, 1, x));
+#undef DENSITY_TAIL
   return KW_OK;
 }
 

@@ -1,6 +1,7 @@
 // KSpaceFirstOrderSolver.cpp — see KSpaceFirstOrderSolver.h.  Sequencing follows
 // KSpaceSolver/KSpaceFirstOrderSolver.cpp:864-943 (loop), :2087-2396 (step pieces), :2404-2703 (generators).
 #include "KSpaceFirstOrderSolver.h"
+#include <cstdlib>
 
 #include <cmath>
 #include <limits>
@@ -227,13 +228,26 @@ void KSpaceFirstOrderSolver::fusedDensity(bool nonlinear)
   const bool absorbing     = mParameters.getAbsorbingFlag() != 0;
   const bool pSourceActive = mParameters.getPressureSourceFlag() > mParameters.getTimeIndex();
   mTermsFused              = absorbing && !pSourceActive;
+  // lossless media: the equation of state (computePressure*'s lossless branch) is part of the density kernel, and the
+  // spectrum of the new p is chained unless p is about to be overwritten by the initial pressure source (step 0)
+  static const bool kNoLosslessFusion = (std::getenv("KW_FUSED_NO_LOSSLESS_P") != nullptr); // A/B knob
+  mPressureFused           = !absorbing && !pSourceActive && !kNoLosslessFusion;
+  const bool chainP        = mPressureFused &&
+                             !((mParameters.getTimeIndex() == 0) && (mParameters.getInitialPressureSourceFlag() == 1));
   const bool storeDu       = absorbing && pSourceActive; // the stand-alone terms kernel will need the gradients
-  const int  terms         = mTermsFused ? (nonlinear ? 2 : 1) : 0;
-  const int  flags         = (mVelocityChained ? KW_FUSED_U_IN_SCRATCH : 0) | (mTermsFused ? KW_FUSED_CHAIN_TERMS : 0);
+  const int  terms         = mTermsFused ? (nonlinear ? 2 : 1) : (mPressureFused ? 3 : 0);
+  const int  flags         = (mVelocityChained ? KW_FUSED_U_IN_SCRATCH : 0) |
+                             ((mTermsFused || chainP) ? KW_FUSED_CHAIN_TERMS : 0);
   // aliasing of the temporaries as in :2184-2190 (nonlinear) / :2221-2225 (linear)
   float* t0 = getTemp1RealND().getDeviceData();
   float* t1 = getTemp2RealND().getDeviceData();
   float* t2 = getTemp3RealND().getDeviceData();
+  if (mPressureFused)
+  {
+    t0 = getP().getDeviceData();
+    t1 = const_cast<float*>(c.realDeviceOrNull(MI::kC2)); // input in this mode (see kw_fused_density)
+    mPressureInScratch = chainP;
+  }
   kwCheck(kw_fused_density(mParameters.getHipParameters().getContext(), nonlinear ? 1 : 0,
                            real(MI::kUxSgx).getDeviceData(), real(MI::kUySgy).getDeviceData(),
                            real(MI::kUzSgz).getDeviceData(), real(MI::kRhoX).getDeviceData(),
@@ -293,7 +307,7 @@ template<SD sd> void KSpaceFirstOrderSolver::computePressureNonlinear()
     getTempHipFftY().computeC2RFftND(absorbEtaTerm);
     SolverHipKernels::sumPressureTermsNonlinear(nonlinearTerm, absorbTauTerm, absorbEtaTerm, mMatrixContainer);
   }
-  else
+  else if (!(mFused && mPressureFused))
   {
     SolverHipKernels::sumPressureNonlinearLossless<sd>(mMatrixContainer);
   }
@@ -331,7 +345,7 @@ template<SD sd> void KSpaceFirstOrderSolver::computePressureLinear()
     getTempHipFftY().computeC2RFftND(absorbEtaTerm);
     SolverHipKernels::sumPressureTermsLinear(absorbTauTerm, absorbEtaTerm, densitySum, mMatrixContainer);
   }
-  else
+  else if (!(mFused && mPressureFused))
   {
     SolverHipKernels::sumPressureLinearLossless<sd>(mMatrixContainer);
   }

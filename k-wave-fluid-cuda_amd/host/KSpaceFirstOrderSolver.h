@@ -87,6 +87,7 @@ class KSpaceFirstOrderSolver
   bool                  mFused    = false;   // fused pipeline active for this grid
   bool                  mTermsFused = false; // pressure terms of this step already produced by the density stage
   bool                  mVelocityChained = false; // x-spectra of u handed over by the velocity stage this step
+  bool mPressureFused = false;     // lossless: p of this step already produced by the density stage
   bool mPressureInScratch = false; // the spectrum of p is still in the pipeline scratch (chained by the pressure sum)
   float*                mKappaPadded = nullptr;
   float*                mNabla1Padded = nullptr;
