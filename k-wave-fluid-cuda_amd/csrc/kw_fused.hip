@@ -1172,6 +1172,28 @@ template<int L, int LEVEL> __global__ __launch_bounds__(Geo<L>::THREADS) void k_
   }
 }
 
+// tile loads + stores with 256-B row segments (two complex = one float4 per lane, 16 lanes per row, 32 columns per tile)
+template<int L> __global__ __launch_bounds__(256) void k_probe_tile_wide(PassArgs a)
+{
+  constexpr int R = 16;                    // rows per thread
+  const int      c   = threadIdx.x % 16;   // float4 column within the 32-column tile
+  const int      j   = threadIdx.x / 16;
+  const uint32_t kx  = blockIdx.x * 32 + 2 * c;
+  const uint32_t kxl = min(kx, (a.P - 2u));
+  const uint32_t z   = blockIdx.y;
+  float4* __restrict__ S = reinterpret_cast<float4*>(a.out[0]);
+  const uint32_t b = ((z * a.ain.zmul + j * a.ain.estride) * a.P + kxl) / 2;
+  const uint32_t step = (R * a.ain.estride * a.P) / 2;
+  float4 v[R];
+#pragma unroll
+  for (int n1 = 0; n1 < R; n1++) v[n1] = S[b + n1 * step];
+  if (kx < a.nxc)
+  {
+#pragma unroll
+    for (int n1 = 0; n1 < R; n1++) { v[n1].x += 1.f; S[b + n1 * step] = v[n1]; }
+  }
+}
+
 // memory pattern of k_xinv<velocity, chain> without its arithmetic: per block 32 spectrum rows in, 32 rows of two real
 // arrays in (float4), one real array out, 32 spectrum rows out
 template<int L> __global__ __launch_bounds__(Geo<L>::THREADS) void k_probe_xinv(XinvArgs a)
@@ -1917,6 +1939,17 @@ kw_status kw_fused_probe(kw_ctx* ctx, int which, const float* op)
   else LAUNCH((k_probe_tile<LEN, 1>), grid, dim3(Geo<LEN>::THREADS), a)
     KW_LEN_SWITCH(c.ny, M)
 #undef M
+    return KW_OK;
+  }
+  if (which == 15 || which == 16)
+  { // 15: y-line tiles, 16: z-line tiles, 32 columns wide
+    KW_REQUIRE(c.nz == c.ny && c.ny == 256);
+    PassArgs a{};
+    a.out[0] = f.s[0];
+    a.nxc = c.nx_complex;
+    a.P   = f.P;
+    a.ain = (which == 15) ? RowAddr{31u, 0xffffffffu, 0u, c.ny, 1u} : RowAddr{31u, 0xffffffffu, 0u, 1u, c.ny};
+    LAUNCH((k_probe_tile_wide<256>), dim3((f.P + 31) / 32, c.nz, 1), dim3(256), a);
     return KW_OK;
   }
   if (which >= 20 && which <= 23)

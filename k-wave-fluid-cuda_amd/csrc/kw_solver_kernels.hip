@@ -354,17 +354,20 @@ __global__ __launch_bounds__(256) void k_add_initial_pressure_source(kw_constant
   const VT v = Vec<V>::load(p0 + i);
   VT vc{};
   if (!kC2Scalar) vc = Vec<V>::load(c2 + i);
-  VT o;
+  VT o, zero;
+  // the initial density is split over the axes of the simulation: 3, or 2 when Nz == 1 (:873 dimScalingFactor)
+  const float dimScalingFactor = (c.nz == 1) ? 2.0f : 3.0f;
 #pragma unroll
   for (int k = 0; k < V; k++)
   {
     const float ec2 = kC2Scalar ? c.c2 : get(vc, k);
-    put(o, k, get(v, k) / (3.0f * ec2));
+    put(o, k, get(v, k) / (dimScalingFactor * ec2));
+    put(zero, k, 0.0f);
   }
   Vec<V>::store(p + i, v);
   Vec<V>::store(rx + i, o);
   Vec<V>::store(ry + i, o);
-  Vec<V>::store(rz + i, o);
+  Vec<V>::store(rz + i, (c.nz == 1) ? zero : o);
 }
 
 // SolverCudaKernels.cu:949-982
@@ -631,15 +634,15 @@ __global__ void k_add_velocity_source(uint32_t n, uint32_t mode, uint32_t many, 
 // SolverCudaKernels.cu:570-629
 __global__ void k_add_pressure_source(uint32_t n, uint32_t mode, uint32_t many, float* __restrict__ rx,
                                       float* __restrict__ ry, float* __restrict__ rz, const float* __restrict__ input,
-                                      const uint64_t* __restrict__ index, uint64_t t)
+                                      const uint64_t* __restrict__ index, uint64_t t, bool is3D)
 {
   const uint64_t index2D = (many == 0) ? t : t * n;
   for (size_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += static_cast<size_t>(gridDim.x) * blockDim.x)
   {
     const float    v = (many == 0) ? input[index2D] : input[index2D + i];
     const uint64_t j = index[i];
-    if (mode == KW_SRC_DIRICHLET) { rx[j] = v; ry[j] = v; rz[j] = v; }
-    else if (mode == KW_SRC_ADDITIVE_NO_CORRECTION) { rx[j] += v; ry[j] += v; rz[j] += v; }
+    if (mode == KW_SRC_DIRICHLET) { rx[j] = v; ry[j] = v; if (is3D) rz[j] = v; }
+    else if (mode == KW_SRC_ADDITIVE_NO_CORRECTION) { rx[j] += v; ry[j] += v; if (is3D) rz[j] += v; }
   }
 }
 
@@ -756,7 +759,7 @@ kw_status kw_add_pressure_source(kw_ctx* ctx, float* rx, float* ry, float* rz, c
   if (n == 0) return KW_OK;
   KW_REQUIRE(rx && ry && rz && input && index);
   LAUNCH(k_add_pressure_source, grid1d(n), dim3(256), n, ctx->c.pressure_source_mode, ctx->c.pressure_source_many, rx,
-         ry, rz, input, index, t);
+         ry, rz, input, index, t, ctx->c.nz != 1); // 2-D (Nz == 1): rho_x, rho_y only (:588-599, :611-622)
   return KW_OK;
 }
 
@@ -803,6 +806,14 @@ kw_status kw_add_pressure_scaled_source(kw_ctx* ctx, float* rx, float* ry, float
   KW_PROF(ctx, "add_pressure_scaled_source");
   KW_REQUIRE(rx && ry && rz && scaled);
   const kw_constants& c = ctx->c;
+  if (c.nz == 1)
+  { // 2-D: rho_x, rho_y only (:795-807, simulationDimension == k2D)
+    if (c.n_elements % 4 == 0 && all_aligned16(rx, ry, scaled))
+      LAUNCH((k_add_scaled_source<4, 2>), grid1d(c.n_elements / 4), dim3(256), c, rx, ry, (float*)nullptr, scaled);
+    else
+      LAUNCH((k_add_scaled_source<1, 2>), grid1d(c.n_elements), dim3(256), c, rx, ry, (float*)nullptr, scaled);
+    return KW_OK;
+  }
   if (c.n_elements % 4 == 0 && all_aligned16(rx, ry, rz, scaled))
     LAUNCH((k_add_scaled_source<4, 3>), grid1d(c.n_elements / 4), dim3(256), c, rx, ry, rz, scaled);
   else

@@ -312,6 +312,7 @@ void OutputStreamContainer::init(MatrixContainer& mc)
   using RO = BaseOutputStream::ReduceOperator;
   const Parameters& params = Parameters::getInstance();
   const bool haveMask = mc.has(MI::kSensorMaskIndex) || mc.has(MI::kSensorMaskCorners);
+  const bool is3D     = params.isSimulation3D(); // 2-D: no z-velocity streams (OutputStreamContainer.cpp:117-250)
 
   if (haveMask)
   {
@@ -330,7 +331,7 @@ void OutputStreamContainer::init(MatrixContainer& mc)
     {
       mContainer[OI::kVelocityXRaw] = createOutputStream(mc, MI::kUxSgx, kUxName, RO::kNone);
       mContainer[OI::kVelocityYRaw] = createOutputStream(mc, MI::kUySgy, kUyName, RO::kNone);
-      mContainer[OI::kVelocityZRaw] = createOutputStream(mc, MI::kUzSgz, kUzName, RO::kNone);
+      if (is3D) mContainer[OI::kVelocityZRaw] = createOutputStream(mc, MI::kUzSgz, kUzName, RO::kNone);
     }
     if (params.getStoreVelocityNonStaggeredRawFlag())
     {
@@ -348,7 +349,7 @@ void OutputStreamContainer::init(MatrixContainer& mc)
       {
         mContainer[a.x] = createOutputStream(mc, MI::kUxSgx, kUxName + a.suffix, a.op);
         mContainer[a.y] = createOutputStream(mc, MI::kUySgy, kUyName + a.suffix, a.op);
-        mContainer[a.z] = createOutputStream(mc, MI::kUzSgz, kUzName + a.suffix, a.op);
+        if (is3D) mContainer[a.z] = createOutputStream(mc, MI::kUzSgz, kUzName + a.suffix, a.op);
       }
   }
   // ---- compression streams (OutputStreamContainer.cpp:92-96,157-168,272-316); index masks only ----
@@ -379,13 +380,13 @@ void OutputStreamContainer::init(MatrixContainer& mc)
   {
     mContainer[OI::kVelocityXMaxAll] = new WholeDomainOutputStream(kUxName + "_max_all", mc.getMatrix<RealMatrix>(MI::kUxSgx), RO::kMax);
     mContainer[OI::kVelocityYMaxAll] = new WholeDomainOutputStream(kUyName + "_max_all", mc.getMatrix<RealMatrix>(MI::kUySgy), RO::kMax);
-    mContainer[OI::kVelocityZMaxAll] = new WholeDomainOutputStream(kUzName + "_max_all", mc.getMatrix<RealMatrix>(MI::kUzSgz), RO::kMax);
+    if (is3D) mContainer[OI::kVelocityZMaxAll] = new WholeDomainOutputStream(kUzName + "_max_all", mc.getMatrix<RealMatrix>(MI::kUzSgz), RO::kMax);
   }
   if (params.getStoreVelocityMinAllFlag())
   {
     mContainer[OI::kVelocityXMinAll] = new WholeDomainOutputStream(kUxName + "_min_all", mc.getMatrix<RealMatrix>(MI::kUxSgx), RO::kMin);
     mContainer[OI::kVelocityYMinAll] = new WholeDomainOutputStream(kUyName + "_min_all", mc.getMatrix<RealMatrix>(MI::kUySgy), RO::kMin);
-    mContainer[OI::kVelocityZMinAll] = new WholeDomainOutputStream(kUzName + "_min_all", mc.getMatrix<RealMatrix>(MI::kUzSgz), RO::kMin);
+    if (is3D) mContainer[OI::kVelocityZMinAll] = new WholeDomainOutputStream(kUzName + "_min_all", mc.getMatrix<RealMatrix>(MI::kUzSgz), RO::kMin);
   }
 }
 

@@ -39,7 +39,12 @@ void Parameters::init(const InputProvider& in, const Options& options)
       throw std::invalid_argument("Z-slab decomposition: non-staggered velocity / intensity streams are not supported yet");
   }
   if (!isSimulation3D())
-    throw std::invalid_argument("Only 3-D simulations are implemented in this build (2-D is a later scope row)");
+  { // 2-D (Nz == 1): what this build carries over from the 3-D path; the rest says so instead of computing nonsense
+    if (z != 1 || isSlabDecomposed())
+      throw std::invalid_argument("2-D simulations need Nz == 1 and a single GPU");
+    if (needsShiftedVelocity())
+      throw std::invalid_argument("2-D simulations: non-staggered velocity / compression / intensity streams are not implemented");
+  }
 
   in.readScalarValue(kNtName, mNt);
   if (mOptions.benchmarkTimeStepCount > 0) mNt = mOptions.benchmarkTimeStepCount; // Parameters.cpp:130-133
@@ -65,10 +70,15 @@ void Parameters::init(const InputProvider& in, const Options& options)
 
   in.readScalarValue(kPressureSourceFlagName, mPressureSourceFlag);
   in.readScalarValue(kInitialPressureSourceFlagName, mInitialPressureSourceFlag);
-  in.readScalarValue(kTransducerSourceFlagName, mTransducerSourceFlag);
+  // 2-D input files carry neither a transducer nor a z-velocity source (Parameters.cpp:300-320)
+  mTransducerSourceFlag = 0;
+  mVelocityZSourceFlag  = 0;
+  if (isSimulation3D() || in.datasetExists(kTransducerSourceFlagName)) in.readScalarValue(kTransducerSourceFlagName, mTransducerSourceFlag);
   in.readScalarValue(kVelocityXSourceFlagName, mVelocityXSourceFlag);
   in.readScalarValue(kVelocityYSourceFlagName, mVelocityYSourceFlag);
-  in.readScalarValue(kVelocityZSourceFlagName, mVelocityZSourceFlag);
+  if (isSimulation3D() || in.datasetExists(kVelocityZSourceFlagName)) in.readScalarValue(kVelocityZSourceFlagName, mVelocityZSourceFlag);
+  if (!isSimulation3D() && (mTransducerSourceFlag != 0 || mVelocityZSourceFlag != 0))
+    throw std::invalid_argument("2-D simulations have no transducer or z-velocity source");
   in.readScalarValue(kNonUniformGridFlagName, mNonUniformGridFlag);
   in.readScalarValue(kAbsorbingFlagName, mAbsorbingFlag);
   in.readScalarValue(kNonLinearFlagName, mNonLinearFlag);

@@ -61,7 +61,7 @@ void kwh_write_output(kwh_solver* s, const std::string& path)
   {
     writeFinal(MI::kUxSgx, kUxFinalName);
     writeFinal(MI::kUySgy, kUyFinalName);
-    writeFinal(MI::kUzSgz, kUzFinalName);
+    if (params.isSimulation3D()) writeFinal(MI::kUzSgz, kUzFinalName);
   }
   out.close();
 }

@@ -8,6 +8,7 @@
 #include "HipError.h"
 #include "CompressHelper.h"
 #include "HostSolverHandle.h"
+#include "MatrixNames.h"
 #include "KSpaceFirstOrderSolver.h"
 #include "kwave_host.h"
 
@@ -42,8 +43,13 @@ Parameters::Options kwh_convert_options(const kwh_options* o)
 }
 
 /// Parameters::init + selectDevice + allocateMemory + loadInputData (main.cpp:857-917) on any InputProvider
-void kwh_build_solver(kwh_solver& s, const InputProvider& input, const Parameters::Options& opt)
+void kwh_build_solver(kwh_solver& s, const InputProvider& fileInput, const Parameters::Options& opt)
 {
+  // Nz == 1 selects the 2-D simulation (Parameters.h:175-181 of the reference): complete the z datasets (see adapter)
+  size_t nz = 0;
+  fileInput.readScalarValue(kNzName, nz);
+  const Input2DAdapter adapter(fileInput);
+  const InputProvider& input = (nz == 1) ? static_cast<const InputProvider&>(adapter) : fileInput;
   Parameters& params = Parameters::getInstance();
   params.init(input, opt);
   params.selectDevice();

@@ -184,8 +184,9 @@ def make_problem(nx: int, ny: Optional[int] = None, nz: Optional[int] = None, *,
     pr.update(kspace_operators(nx, ny, nz, dx, dy, dz))
     eff = 0 if pml_off else pml_size
     for ax, nn, dd in (("x", nx, dx), ("y", ny, dy), ("z", nz, dz)):
-        pr[f"pml_{ax}"] = pml_vectors(nn, dd, dt, c_ref, eff, pml_alpha, False)
-        pr[f"pml_{ax}_sg{ax}"] = pml_vectors(nn, dd, dt, c_ref, eff, pml_alpha, True)
+        size = 0 if nn == 1 else eff  # a 2-D grid (Nz == 1) has no PML along z
+        pr[f"pml_{ax}"] = pml_vectors(nn, dd, dt, c_ref, size, pml_alpha, False)
+        pr[f"pml_{ax}_sg{ax}"] = pml_vectors(nn, dd, dt, c_ref, size, pml_alpha, True)
 
     # ---- sources ------------------------------------------------------------------------------
     for nm in ("ux_source_flag", "uy_source_flag", "uz_source_flag", "p_source_flag", "p0_source_flag",
@@ -265,3 +266,15 @@ def make_problem(nx: int, ny: Optional[int] = None, nz: Optional[int] = None, *,
 
 def is_scalar(a: np.ndarray) -> bool:
     return a.size == 1
+
+
+# datasets a k-Wave 2-D input file (Nz == 1) does not contain (MatrixContainer.cpp:102-200 creates them only for 3-D)
+Z_ONLY_DATASETS = ("ddz_k_shift_pos", "ddz_k_shift_neg", "z_shift_neg_r", "pml_z", "pml_z_sgz", "rho0_sgz",
+                   "uz_source_flag", "transducer_source_flag", "pml_z_size", "pml_z_alpha", "dz")
+
+
+def as_2d_file(pr: Dict[str, np.ndarray]) -> Dict[str, np.ndarray]:
+    """A problem built with nz == 1, reduced to what a 2-D input file holds (dz is kept: it is a mandatory scalar)."""
+    if int(np.asarray(pr["Nz"]).ravel()[0]) != 1:
+        raise ValueError("as_2d_file needs a problem with Nz == 1")
+    return {k: v for k, v in pr.items() if k not in Z_ONLY_DATASETS or k == "dz"}

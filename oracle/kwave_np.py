@@ -24,8 +24,27 @@ def _c(pairs: np.ndarray) -> np.ndarray:
     return p[:, 0] + 1j * p[:, 1]
 
 
+def complete_2d(pr: Dict[str, np.ndarray]) -> Dict[str, np.ndarray]:
+    """A 2-D problem (Nz == 1) as the degenerate 3-D one both restatements run: the z datasets a 2-D input file does not
+    have, with the values that make the 3-D formulas reduce to the reference's SD::k2D ones (zero z-gradient operators,
+    unit z-PML and z-shift, rho0_sgz = rho0_sgx; u_z and rho_z then stay zero)."""
+    if int(_sc(pr["Nz"])) != 1:
+        return pr
+    out = dict(pr)
+    zero_c = np.zeros((1, 1, 2), dtype=np.float32)
+    one = np.ones((1, 1, 1), dtype=np.float32)
+    out.setdefault("ddz_k_shift_pos", zero_c)
+    out.setdefault("ddz_k_shift_neg", zero_c)
+    out.setdefault("z_shift_neg_r", np.array([[[1.0, 0.0]]], dtype=np.float32))
+    out.setdefault("pml_z", one)
+    out.setdefault("pml_z_sgz", one)
+    out.setdefault("rho0_sgz", pr["rho0_sgx"])
+    return out
+
+
 class NumpySim:
     def __init__(self, pr: Dict[str, np.ndarray]):
+        pr = complete_2d(pr)
         self.pr = pr
         nx, ny, nz = (int(_sc(pr[k])) for k in ("Nx", "Ny", "Nz"))
         self.nx, self.ny, self.nz = nx, ny, nz
@@ -144,12 +163,13 @@ class NumpySim:
             idx = np.asarray(pr["p_source_index"], dtype=np.int64).reshape(-1) - 1
             mode = int(_sc(pr["p_source_mode"]))
             many = int(_sc(pr["p_source_many"]))
+            ndim = 2 if self.nz == 1 else 3  # SD::k2D: rho_x, rho_y only
             if mode == 2:
                 sc = self._scaled(pr["p_source_input"], idx, many)
-                self.rho = [r + sc for r in self.rho]
+                self.rho = [r + sc if a < ndim else r for a, r in enumerate(self.rho)]
             else:
                 v = self._src_values(pr["p_source_input"], idx.size, many)
-                for a in range(3):
+                for a in range(ndim):
                     flat = self.rho[a].reshape(-1)
                     if mode == 0:
                         flat[idx] = v
@@ -172,7 +192,8 @@ class NumpySim:
         if self.t == 0 and int(_sc(pr.get("p0_source_flag", 0))) == 1:
             p0 = np.asarray(pr["p0_source_input"], dtype=np.float64)
             self.p = p0.copy()
-            self.rho = [p0 / (3.0 * self.c2) for _ in range(3)]
+            ndim = 2 if self.nz == 1 else 3  # SolverCudaKernels.cu:873-876 dimScalingFactor
+            self.rho = [p0 / (ndim * self.c2) if a < ndim else np.zeros_like(p0) for a in range(3)]
             e = self.F(self.p) * self.kappa
             g = [self.Fi(e * self.ddx_pos), self.Fi(e * self.ddy_pos), self.Fi(e * self.ddz_pos)]
             self.u = [g[a] * self.dtrho[a] * d * 0.5 for a in range(3)]

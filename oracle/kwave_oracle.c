@@ -815,6 +815,7 @@ static void add_pressure_source(kwo_sim* s)
   const kwo_problem* pr = &s->pr;
   if (!(pr->p_source_flag > s->t)) return;
   const size_t n = pr->p_source_n;
+  const int is3d = (s->nz != 1); /* 2-D (SD::k2D instantiations): the source goes to rho_x and rho_y only */
   if (pr->p_source_mode != KWO_SRC_ADDITIVE)
   {
     const size_t index2D = (pr->p_source_many == 0) ? s->t : s->t * n;
@@ -822,8 +823,8 @@ static void add_pressure_source(kwo_sim* s)
     {
       const float v = (pr->p_source_many == 0) ? pr->p_source_input[index2D] : pr->p_source_input[index2D + i];
       const size_t j = pr->p_source_index[i];
-      if (pr->p_source_mode == KWO_SRC_DIRICHLET) { s->rhox[j] = v; s->rhoy[j] = v; s->rhoz[j] = v; }
-      else { s->rhox[j] += v; s->rhoy[j] += v; s->rhoz[j] += v; }
+      if (pr->p_source_mode == KWO_SRC_DIRICHLET) { s->rhox[j] = v; s->rhoy[j] = v; if (is3d) s->rhoz[j] = v; }
+      else { s->rhox[j] += v; s->rhoy[j] += v; if (is3d) s->rhoz[j] += v; }
     }
   }
   else
@@ -833,7 +834,7 @@ static void add_pressure_source(kwo_sim* s)
     for (size_t i = 0; i < s->n; i++)
     {
       const float e = s->t1[i];
-      s->rhox[i] += e; s->rhoy[i] += e; s->rhoz[i] += e;
+      s->rhox[i] += e; s->rhoy[i] += e; if (is3d) s->rhoz[i] += e;
     }
   }
 }
@@ -952,8 +953,10 @@ static void add_initial_pressure_source(kwo_sim* s)
   {
     float tmp = s->p[i] = pr->p0_source_input[i];
     const float c2 = s->c2 ? s->c2[i] : s->c2_s;
-    tmp = tmp / (3.0f * c2);
-    s->rhox[i] = tmp; s->rhoy[i] = tmp; s->rhoz[i] = tmp;
+    /* SolverCudaKernels.cu:873-876: dimScalingFactor = 3 (k3D) or 2 (k2D, Nz == 1; rho_z does not exist there) */
+    const float dims = (s->nz == 1) ? 2.0f : 3.0f;
+    tmp = tmp / (dims * c2);
+    s->rhox[i] = tmp; s->rhoy[i] = tmp; s->rhoz[i] = (s->nz == 1) ? 0.0f : tmp;
   }
   kwo_fft_r2c_3d(s->p, (float*)s->cx, s->nx, s->ny, s->nz);
   pressure_gradient(s);

@@ -138,6 +138,8 @@ class OracleSim:
         L = lib()
         self._keep = []
         P = Problem()
+        from .kwave_np import complete_2d
+        pr = complete_2d(pr)  # Nz == 1: the z datasets a 2-D input does not carry
         nx, ny, nz = int(_sc(pr["Nx"])), int(_sc(pr["Ny"])), int(_sc(pr["Nz"]))
         self.nx, self.ny, self.nz = nx, ny, nz
         self.n = nx * ny * nz

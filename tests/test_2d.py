@@ -1,0 +1,128 @@
+"""2-D simulations (Nz == 1; the reference's SD::k2D instantiations): a 2-D input file carries no z
+datasets; the arithmetic differs from 3-D in the initial density split (p0 / (2 c^2), SolverCudaKernels.cu:873-876) and
+in sources going to rho_x, rho_y only (:588-622, :795-807)."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import rel_l2
+
+TOL = 1e-5
+
+
+def problem2d(syn, nx=48, ny=32, **kw):
+    kw.setdefault("nt", 40)
+    kw.setdefault("pml_size", 6)
+    kw.setdefault("sensor", "random")
+    pr = syn.as_2d_file(syn.make_problem(nx, ny, 1, **kw))
+    for name in syn.Z_ONLY_DATASETS:
+        assert name == "dz" or name not in pr
+    return pr
+
+
+# ---- CPU: the oracle's own pins in 2-D ---------------------------------------------------------------------------------
+def test_oracle_2d_closed_form(orc, syn):
+    """K1 in two dimensions: p(n dt) = Fi{cos(c |k| n dt) F{p0}} for the homogeneous lossless periodic box."""
+    from oracle.kwave_np import closed_form_pressure, complete_2d
+    pr = problem2d(syn, 64, 64, heterogeneous=False, nonlinear=False, absorbing=False, pml_off=True, source="p0", nt=120)
+    o = orc.OracleSim(pr)
+    o.step(1)
+    assert np.array_equal(o.field("p").reshape(-1), pr["p0_source_input"].reshape(-1))
+    # step-0 identity with the 2-D split: (rho_x + rho_y) c^2 == p0, rho_z == 0
+    c2 = float(pr["c0"].ravel()[0]) ** 2
+    assert rel_l2((o.field("rhox") + o.field("rhoy")) * c2, pr["p0_source_input"]) < 1e-6
+    assert not o.field("rhoz").any() and not o.field("uz").any()
+    o.step(100)
+    assert rel_l2(o.field("p"), closed_form_pressure(complete_2d(pr), 100)) < TOL
+    o.close()
+
+
+@pytest.mark.parametrize("kw", [
+    dict(nonlinear=True, absorbing=True, source="p0"),
+    dict(nonlinear=False, absorbing=False, source="p_source", source_mode=0, source_many=1),
+    dict(nonlinear=True, absorbing=False, source="p_source", source_mode=2),
+    dict(nonlinear=False, absorbing=True, source="u_source", source_mode=1),
+])
+def test_oracle_2d_c_vs_numpy(orc, syn, kw):
+    from oracle.kwave_np import NumpySim
+    pr = problem2d(syn, heterogeneous=True, **kw)
+    o, n = orc.OracleSim(pr), NumpySim(pr)
+    for _ in range(25):
+        o.step()
+        n.step()
+    assert rel_l2(o.field("p"), n.p) < 5e-6
+    assert rel_l2(o.field("ux"), n.u[0]) < 5e-6 and rel_l2(o.field("rhoy"), n.rho[1]) < 5e-6
+    assert not o.field("uz").any() and not o.field("rhoz").any()
+    o.close()
+
+
+# ---- GPU ---------------------------------------------------------------------------------------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("kw", [
+    dict(heterogeneous=True, nonlinear=True, absorbing=True, source="p0"),
+    dict(heterogeneous=False, nonlinear=False, absorbing=False, source="p0"),
+    dict(heterogeneous=True, nonlinear=False, absorbing=True, source="p_source", source_mode=1, source_many=1),
+    dict(heterogeneous=True, nonlinear=True, absorbing=False, source="p_source", source_mode=2),
+    dict(heterogeneous=True, nonlinear=True, absorbing=True, source="u_source", source_mode=0),
+])
+def test_gpu_2d_matches_oracle(orc, syn, kw):
+    from kwave_amd.solver import HostSolver
+    pr = problem2d(syn, **kw)
+    g = HostSolver(pr, p_raw=1, p_max=1, u_raw=1, u_rms=1, p_final=1)
+    o = orc.OracleSim(pr)
+    series = []
+    for _ in range(30):
+        o.step()
+        series.append(o.field("p").reshape(-1)[o.sensor_index].copy())
+    g.run(30)
+    g.finish()
+    for f in ("p", "ux", "uy", "rhox", "rhoy"):
+        assert rel_l2(g.field(f), o.field(f)) < TOL, f
+    assert not g.field("uz").any() and not g.field("rhoz").any()
+    assert rel_l2(g.stream("p"), np.array(series)) < TOL
+    # no z-velocity streams in 2-D (OutputStreamContainer.cpp:117-250)
+    names = g.stream_names()
+    assert "ux" in names and "uy" in names and "uz" not in names and "uz_rms" not in names
+    g.close()
+    o.close()
+
+
+@pytest.mark.gpu
+def test_gpu_2d_closed_form_and_rejections(syn):
+    from oracle.kwave_np import closed_form_pressure, complete_2d
+    from kwave_amd import capi
+    from kwave_amd.solver import HostSolver
+    pr = problem2d(syn, 64, 64, heterogeneous=False, nonlinear=False, absorbing=False, pml_off=True, source="p0", nt=120)
+    g = HostSolver(pr)
+    g.run(101)
+    assert rel_l2(g.field("p"), closed_form_pressure(complete_2d(pr), 100)) < TOL
+    g.close()
+    # what the 2-D path does not carry says so
+    with pytest.raises(capi.KWaveError):
+        HostSolver(pr, u_non_staggered_raw=1)
+
+
+@pytest.mark.gpu
+def test_gpu_2d_from_file(syn, tmp_path):
+    import kwave_amd  # noqa: F401
+    from kwave_amd import h5io
+    from kwave_amd.solver import HostSolver
+    if not os.path.exists(h5io.H5_LIB_PATH):
+        pytest.skip("HDF5 component not built")
+    pr = problem2d(syn, heterogeneous=True, nonlinear=True, absorbing=True, source="p0", nt=20)
+    path_in, path_out = str(tmp_path / "in2d.h5"), str(tmp_path / "out2d.h5")
+    h5io.write_input_file(pr, path_in)
+    mem = HostSolver(pr, p_raw=1, u_final=1)
+    mem.run(20)
+    mem.finish()
+    fs = h5io.FileSolver(path_in, p_raw=1, u_final=1)
+    fs.run(20)
+    fs.finish()
+    assert np.array_equal(fs.field("p"), mem.field("p")) and np.array_equal(fs.stream("p"), mem.stream("p"))
+    fs.write_output(path_out)
+    assert h5io.dataset_info(path_out, "ux_final")[0] == (48, 32, 1)
+    with pytest.raises(Exception):
+        h5io.dataset_info(path_out, "uz_final")
+    fs.close()
+    mem.close()

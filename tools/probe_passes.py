@@ -33,7 +33,8 @@ def main(n=256, reps=30):
     big = dev.array(np.ones(6 * (n ** 3 + 263168), dtype=np.float32))
     names[20] = "x-inverse + velocity epilogue pattern (15 units)"
     names[21], names[22], names[23] = "  same, arrays staggered by 4 KiB", "  same, staggered by 68 KiB", "  same, staggered by 1 MiB + 4 KiB"
-    for which in (10, 11, 12, 0, 13, 14, 1, 2, 3, 20, 21, 22, 23):
+    names[15], names[16] = "y tiles, 256-B segments: load + store", "z tiles, 256-B segments: load + store"
+    for which in (10, 11, 15, 12, 0, 13, 16, 14, 1, 2, 3, 20):
         for _ in range(3):
             dev.call("fused_probe", which, big if which >= 20 else op)
         e0, e1 = dev.event(), dev.event()
