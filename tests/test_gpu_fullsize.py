@@ -1,0 +1,81 @@
+"""Parity at the benchmark's full size (256^3, BASELINE configs 3 / 5 grid) through properties that do not need the CPU
+oracle to finish a 256^3 run: the fp64 closed form of the lossless homogeneous problem (K1), agreement of the two
+independent device implementations of the step (hand-written fused FFT passes vs rocFFT + one kernel per reference
+kernel), linearity in the source amplitude for the linear medium, and bit-exact sampling of what is on the device."""
+import numpy as np
+import pytest
+
+from conftest import rel_l2
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5
+N = 256
+
+
+def gpu(pr, **kw):
+    import kwave_amd  # noqa: F401
+    from kwave_amd.solver import HostSolver
+    return HostSolver(pr, **kw)
+
+
+def test_k1_closed_form_256(syn):
+    from oracle.kwave_np import closed_form_pressure
+    pr = syn.make_problem(N, heterogeneous=False, nonlinear=False, absorbing=False, pml_off=True, source="p0", nt=70)
+    g = gpu(pr)
+    g.run(61)
+    assert rel_l2(g.field("p"), closed_form_pressure(pr, 60)) < TOL
+    g.close()
+
+
+def test_config3_fused_pipeline_equals_rocfft_path_256(syn):
+    """heterogeneous c0 / rho0 / BonA / alpha_coeff, absorbing + nonlinear, the bench workload: 30 steps"""
+    pr = syn.make_problem(N, heterogeneous=True, nonlinear=True, absorbing=True, source="p0", nt=40)
+    a = gpu(pr, p_raw=1, p_max=1, fused_kernels=True)
+    a.run(30)
+    a.finish()
+    fields_a = {f: a.field(f) for f in ("p", "ux", "uz", "rhoy")}
+    series_a, max_a = a.stream("p"), a.stream("p_max")
+    # bit-exact sampling of the device field (sensor = the z = N/2 plane, 65 536 points)
+    mask = pr["sensor_mask_index"].reshape(-1).astype(np.int64) - 1
+    assert np.array_equal(series_a[-1], fields_a["p"].reshape(-1)[mask])
+    assert np.array_equal(max_a, series_a.max(axis=0))
+    a.close()
+    b = gpu(pr, p_raw=1, p_max=1, fused_kernels=False)
+    b.run(30)
+    b.finish()
+    for f, va in fields_a.items():
+        assert rel_l2(va, b.field(f)) < TOL, f
+    assert rel_l2(series_a, b.stream("p")) < TOL
+    b.close()
+
+
+def test_linearity_256(syn):
+    """linear lossless heterogeneous medium: the field scales with the source amplitude"""
+    pr = syn.make_problem(N, heterogeneous=True, nonlinear=False, absorbing=False, source="p0", nt=30)
+    a = gpu(pr)
+    a.run(20)
+    pa = a.field("p")
+    a.close()
+    pr2 = dict(pr)
+    pr2["p0_source_input"] = (0.25 * pr["p0_source_input"]).astype(np.float32)  # exact in fp32
+    b = gpu(pr2)
+    b.run(20)
+    assert rel_l2(4.0 * b.field("p"), pa) < 1e-6
+    b.close()
+
+
+def test_config4_fused_pipeline_equals_rocfft_path_512(syn):
+    """BASELINE config 4 grid (512^3): the 2 x 256 split y / z kernels and the 512-point x kernels against rocFFT"""
+    n = 512
+    pr = syn.make_problem(n, heterogeneous=True, nonlinear=True, absorbing=True, source="p0", nt=12, sensor="random")
+    a = gpu(pr, p_raw=1, fused_kernels=True)
+    a.run(8)
+    a.finish()
+    pa, ua, sa = a.field("p"), a.field("uy"), a.stream("p")
+    a.close()
+    b = gpu(pr, p_raw=1, fused_kernels=False)
+    b.run(8)
+    b.finish()
+    assert rel_l2(pa, b.field("p")) < TOL and rel_l2(ua, b.field("uy")) < TOL
+    assert rel_l2(sa, b.stream("p")) < TOL
+    b.close()
