@@ -214,6 +214,10 @@ KW_API kw_status kw_compute_pressure_gradient(kw_ctx* ctx, float* fft_x, float* 
 KW_API kw_status kw_compute_velocity_gradient(kw_ctx* ctx, float* fft_x, float* fft_y, float* fft_z,
                                               const float* kappa, const float* ddx_k_shift_neg,
                                               const float* ddy_k_shift_neg, const float* ddz_k_shift_neg);
+/* computeVelocityGradientShiftNonuniform (.cuh:293, .cu:1285-1320): du?d? *= d?ud?n[coord] on a non-uniform grid */
+KW_API kw_status kw_compute_velocity_gradient_shift_nonuniform(kw_ctx* ctx, float* duxdx, float* duydy, float* duzdz,
+                                                               const float* dxudxn, const float* dyudyn,
+                                                               const float* dzudzn);
 /* computeDensityNonlinear (.cuh:306, .cu:1358-1440) / computeDensityLinear (.cuh:320, .cu:1470-1545); rho0 NULL -> scalar */
 KW_API kw_status kw_compute_density_nonlinear(kw_ctx* ctx, float* rho_x, float* rho_y, float* rho_z,
                                               const float* pml_x, const float* pml_y, const float* pml_z,

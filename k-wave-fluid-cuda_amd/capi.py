@@ -110,6 +110,7 @@ _SIG: Dict[str, list] = {
     "kw_compute_initial_velocity": [_P] + [_P] * 6,
     "kw_compute_pressure_gradient": [_P] + [_P] * 7,
     "kw_compute_velocity_gradient": [_P] + [_P] * 7,
+    "kw_compute_velocity_gradient_shift_nonuniform": [_P] + [_P] * 6,
     "kw_compute_density_nonlinear": [_P] + [_P] * 10,
     "kw_compute_density_linear": [_P] + [_P] * 10,
     "kw_compute_pressure_terms_nonlinear": [_P] + [_P] * 11,

@@ -433,6 +433,27 @@ __global__ __launch_bounds__(256) void k_add_scaled_source(kw_constants c, float
   }
 }
 
+// SolverCudaKernels.cu:1285-1301: one x-row per block row (blockIdx.y = y + ny * z): y and z are block-uniform
+__global__ __launch_bounds__(256) void k_velocity_gradient_shift_nonuniform(kw_constants c, float* __restrict__ dux,
+                                                                             float* __restrict__ duy,
+                                                                             float* __restrict__ duz,
+                                                                             const float* __restrict__ nx,
+                                                                             const float* __restrict__ ny,
+                                                                             const float* __restrict__ nz)
+{
+  const uint32_t row = blockIdx.y;
+  const uint32_t z   = row / c.ny;
+  const uint32_t y   = row - z * c.ny;
+  const float    ey = ny[y], ez = nz[z];
+  for (uint32_t x = blockIdx.x * blockDim.x + threadIdx.x; x < c.nx; x += gridDim.x * blockDim.x)
+  {
+    const size_t i = static_cast<size_t>(row) * c.nx + x;
+    dux[i] *= nx[x];
+    duy[i] *= ey;
+    duz[i] *= ez;
+  }
+}
+
 // =====================================================================================================================
 // k-space kernels.  Flat over one z-plane (blockIdx.y = z), P complex values per lane (P = 2 -> 16 B).
 // =====================================================================================================================
@@ -900,6 +921,34 @@ kw_status kw_compute_velocity_gradient(kw_ctx* ctx, float* X, float* Y, float* Z
   else
     LAUNCH((k_velocity_gradient<1>), dim3((plane + 255) / 256, c.nz), dim3(256), c, X, Y, Z, kappa, (const float2*)ddx,
            (const float2*)ddy, (const float2*)ddz);
+  return KW_OK;
+}
+
+kw_status kw_compute_velocity_gradient_shift_nonuniform(kw_ctx* ctx, float* dux, float* duy, float* duz, const float* nx,
+                                                        const float* ny, const float* nz)
+{
+  KW_CHECK_CONSTS(ctx);
+  KW_PROF(ctx, "compute_velocity_gradient_shift_nonuniform");
+  KW_REQUIRE(dux && duy && duz && nx && ny && nz);
+  const kw_constants& c = ctx->c;
+  KW_REQUIRE(static_cast<uint64_t>(c.ny) * c.nz <= 65535u * 65535u);
+  // rows on grid.y would overflow 65535 for big grids: fold rows into grid.x/y = (x blocks, rows) only when they fit
+  const uint32_t rows = c.ny * c.nz;
+  if (rows <= 65535u)
+    LAUNCH(k_velocity_gradient_shift_nonuniform, dim3((c.nx + 255) / 256, rows), dim3(256), c, dux, duy, duz, nx, ny, nz);
+  else
+  { // one launch per z-range of at most 65535 rows
+    const uint32_t zstep = 65535u / c.ny;
+    for (uint32_t z0 = 0; z0 < c.nz; z0 += zstep)
+    {
+      const uint32_t nzc = (z0 + zstep <= c.nz) ? zstep : c.nz - z0;
+      const size_t   off = static_cast<size_t>(z0) * c.ny * c.nx;
+      kw_constants cc = c;
+      cc.nz = nzc;
+      LAUNCH(k_velocity_gradient_shift_nonuniform, dim3((c.nx + 255) / 256, nzc * c.ny), dim3(256), cc, dux + off,
+             duy + off, duz + off, nx, ny, nz + z0);
+    }
+  }
   return KW_OK;
 }
 

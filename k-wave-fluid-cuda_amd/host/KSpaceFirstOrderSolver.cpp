@@ -48,7 +48,9 @@ void KSpaceFirstOrderSolver::initializeFftPlans()
                               static_cast<uint32_t>(opt.nzGlobal), opt.exchangeFn, opt.exchangeUser));
   if (mParameters.isSlabDecomposed() && opt.exchangeStartFn != nullptr)
     kwCheck(kw_fused_set_slab_async(ctx, opt.exchangeStartFn, opt.exchangeWaitFn));
-  if (opt.fusedKernels || mParameters.isSlabDecomposed()) kwCheck(kw_fused_supported(ctx, &fusedOk));
+  // non-uniform grids run the launch-per-kernel path (their gradient scaling is a kernel of its own there, .cu:1285-1301)
+  if ((opt.fusedKernels && mParameters.getNonUniformGridFlag() == 0) || mParameters.isSlabDecomposed())
+    kwCheck(kw_fused_supported(ctx, &fusedOk));
   mFused = (fusedOk != 0);
   if (mParameters.isSlabDecomposed() && !mFused)
     throw std::invalid_argument("Z-slab decomposition needs the fused pipeline (power-of-two grid, Ny and Nz divisible by the rank count)");
@@ -111,7 +113,8 @@ template<SD sd> void KSpaceFirstOrderSolver::preProcessing()
   if (mParameters.getTransducerSourceFlag() != 0) index(MI::kDelayMask).recomputeIndicesToCPP();
   if (mParameters.getPressureSourceFlag() != 0) index(MI::kPressureSourceIndex).recomputeIndicesToCPP();
 
-  if (!mParameters.getRho0ScalarFlag())
+  if (mParameters.getNonUniformGridFlag() != 0) generateInitialDenisty();
+  else if (!mParameters.getRho0ScalarFlag())
   {
     real(MI::kDtRho0Sgx).scalarDividedBy(mParameters.getDt());
     real(MI::kDtRho0Sgy).scalarDividedBy(mParameters.getDt());
@@ -205,8 +208,8 @@ template<SD sd> void KSpaceFirstOrderSolver::computeVelocity()
   getTempHipFftX().computeC2RFftND(getTemp1RealND());
   getTempHipFftY().computeC2RFftND(getTemp2RealND());
   getTempHipFftZ().computeC2RFftND(getTemp3RealND());
-  if (mParameters.getRho0ScalarFlag()) SolverHipKernels::computeVelocityHomogeneousUniform<sd>(mMatrixContainer);
-  else SolverHipKernels::computeVelocityHeterogeneous<sd>(mMatrixContainer);
+  if (!mMatrixContainer.has(MI::kDtRho0Sgx)) SolverHipKernels::computeVelocityHomogeneousUniform<sd>(mMatrixContainer);
+  else SolverHipKernels::computeVelocityHeterogeneous<sd>(mMatrixContainer); // per-voxel dt/rho0_sg (heterogeneous or non-uniform grid)
 }
 
 template<SD sd> void KSpaceFirstOrderSolver::computeVelocityGradient()
@@ -219,6 +222,8 @@ template<SD sd> void KSpaceFirstOrderSolver::computeVelocityGradient()
   getTempHipFftX().computeC2RFftND(real(MI::kDuxdx));
   getTempHipFftY().computeC2RFftND(real(MI::kDuydy));
   getTempHipFftZ().computeC2RFftND(real(MI::kDuzdz));
+  if (mParameters.getNonUniformGridFlag() != 0) // :2145-2149
+    SolverHipKernels::computeVelocityGradientShiftNonuniform<sd>(mMatrixContainer);
 }
 
 // fused: velocity gradient + density update (+ pressure terms when no pressure source sits between them this step)
@@ -426,7 +431,7 @@ template<SD sd> void KSpaceFirstOrderSolver::addInitialPressureSource()
   getTempHipFftX().computeC2RFftND(real(MI::kUxSgx));
   getTempHipFftY().computeC2RFftND(real(MI::kUySgy));
   getTempHipFftZ().computeC2RFftND(real(MI::kUzSgz));
-  if (mParameters.getRho0ScalarFlag()) SolverHipKernels::computeInitialVelocityHomogeneousUniform<sd>(mMatrixContainer);
+  if (!mMatrixContainer.has(MI::kDtRho0Sgx)) SolverHipKernels::computeInitialVelocityHomogeneousUniform<sd>(mMatrixContainer);
   else SolverHipKernels::computeInitialVelocityHeterogeneous<sd>(mMatrixContainer);
 }
 
@@ -648,4 +653,40 @@ void KSpaceFirstOrderSolver::computeC2()
 #pragma omp parallel for schedule(static)
     for (size_t i = 0; i < size; i++) c2[i] = c2[i] * c2[i];
   }
+}
+
+// dt/rho0_sg on a non-uniform grid (KSpaceFirstOrderSolver.cpp:2650-2685 for heterogeneous density).  For a homogeneous
+// density the reference multiplies dt/rho0_sg * d?ud?n_sg? inside its own kernel variant (SolverCudaKernels.cu:372-410,
+// 1061-1083); here the product is stored per voxel and the heterogeneous kernels are used.
+void KSpaceFirstOrderSolver::generateInitialDenisty()
+{
+  const DimensionSizes d = mParameters.getFullDimensionSizes();
+  float* sgx = real(MI::kDtRho0Sgx).getHostData();
+  float* sgy = real(MI::kDtRho0Sgy).getHostData();
+  float* sgz = real(MI::kDtRho0Sgz).getHostData();
+  const float* nx = real(MI::kDxudxnSgx).getHostData();
+  const float* ny = real(MI::kDyudynSgy).getHostData();
+  const float* nz = real(MI::kDzudznSgz).getHostData();
+  const float dt = mParameters.getDt();
+  const bool scalar = mParameters.getRho0ScalarFlag();
+  const float sx = mParameters.getDtRho0SgxScalar(), sy = mParameters.getDtRho0SgyScalar(), sz = mParameters.getDtRho0SgzScalar();
+#pragma omp parallel for schedule(static)
+  for (size_t z = 0; z < d.nz; z++)
+    for (size_t y = 0; y < d.ny; y++)
+      for (size_t x = 0; x < d.nx; x++)
+      {
+        const size_t i = (z * d.ny + y) * d.nx + x;
+        if (scalar)
+        {
+          sgx[i] = sx * nx[x];
+          sgy[i] = sy * ny[y];
+          sgz[i] = sz * nz[z];
+        }
+        else
+        {
+          sgx[i] = (dt * nx[x]) / sgx[i];
+          sgy[i] = (dt * ny[y]) / sgy[i];
+          sgz[i] = (dt * nz[z]) / sgz[i];
+        }
+      }
 }

@@ -26,6 +26,7 @@ class KSpaceFirstOrderSolver
   virtual void compute();
 
   // ---- the same pipeline in pieces, so that bench.py / tests can time or inspect the loop alone ----
+  void generateInitialDenisty();        // dt/rho0_sg for non-uniform grids (:2650-2685; the reference's spelling)
   void prepare();                       // initializeFftPlans + preProcessing + constants + copyMatricesToDevice
   void runTimeSteps(size_t nSteps);     // body of computeMainLoop for nSteps (stops at Nt)
   void finish();                        // last delayed flush + postProcessing

@@ -26,6 +26,22 @@ void MatrixContainer::init()
   mContainer[MI::kDuxdx].set(MT::kReal, fullDims, kNoLoad, kNoCheckpoint, "duxdx");
   mContainer[MI::kDuydy].set(MT::kReal, fullDims, kNoLoad, kNoCheckpoint, "duydy");
   mContainer[MI::kDuzdz].set(MT::kReal, fullDims, kNoLoad, kNoCheckpoint, "duzdz");
+  if (params.getNonUniformGridFlag() != 0)
+  { // MatrixContainer.cpp:301-329
+    mContainer[MI::kDxudxn].set(MT::kReal, DimensionSizes(fullDims.nx, 1, 1), kLoad, kNoCheckpoint, kDxudxnName);
+    mContainer[MI::kDyudyn].set(MT::kReal, DimensionSizes(1, fullDims.ny, 1), kLoad, kNoCheckpoint, kDyudynName);
+    mContainer[MI::kDzudzn].set(MT::kReal, DimensionSizes(1, 1, fullDims.nz), kLoad, kNoCheckpoint, kDzudznName);
+    mContainer[MI::kDxudxnSgx].set(MT::kReal, DimensionSizes(fullDims.nx, 1, 1), kLoad, kNoCheckpoint, kDxudxnSgxName);
+    mContainer[MI::kDyudynSgy].set(MT::kReal, DimensionSizes(1, fullDims.ny, 1), kLoad, kNoCheckpoint, kDyudynSgyName);
+    mContainer[MI::kDzudznSgz].set(MT::kReal, DimensionSizes(1, 1, fullDims.nz), kLoad, kNoCheckpoint, kDzudznSgzName);
+    if (params.getRho0ScalarFlag())
+    { // homogeneous density on a non-uniform grid: dt/rho0_sg * d?ud?n_sg? as per-voxel arrays, built in pre-processing,
+      // so that the velocity kernels need no third variant (the reference has one: SolverCudaKernels.cu:372-410)
+      mContainer[MI::kDtRho0Sgx].set(MT::kReal, fullDims, kNoLoad, kNoCheckpoint, "dt_rho0_sgx_nonuniform");
+      mContainer[MI::kDtRho0Sgy].set(MT::kReal, fullDims, kNoLoad, kNoCheckpoint, "dt_rho0_sgy_nonuniform");
+      mContainer[MI::kDtRho0Sgz].set(MT::kReal, fullDims, kNoLoad, kNoCheckpoint, "dt_rho0_sgz_nonuniform");
+    }
+  }
   if (!params.getRho0ScalarFlag())
   {
     mContainer[MI::kRho0].set(MT::kReal, fullDims, kLoad, kNoCheckpoint, kRho0Name);

@@ -36,7 +36,8 @@ class MatrixContainer
     kAbsorbNabla2, kSensorMaskIndex, kSensorMaskCorners, kInitialPressureSourceInput, kPressureSourceInput,
     kTransducerSourceInput, kVelocityXSourceInput, kVelocityYSourceInput, kVelocityZSourceInput, kPressureSourceIndex,
     kVelocitySourceIndex, kDelayMask, kUxShifted, kUyShifted, kUzShifted, kXShiftNegR, kYShiftNegR, kZShiftNegR,
-    kTemp1RealND, kTemp2RealND, kTemp3RealND, kTempHipFftX, kTempHipFftY, kTempHipFftZ, kTempHipFftShift
+    kTemp1RealND, kTemp2RealND, kTemp3RealND, kTempHipFftX, kTempHipFftY, kTempHipFftZ, kTempHipFftShift,
+    kDxudxn, kDyudyn, kDzudzn, kDxudxnSgx, kDyudynSgy, kDzudznSgz
   };
 
   MatrixContainer() = default;

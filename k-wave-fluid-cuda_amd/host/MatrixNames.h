@@ -42,6 +42,8 @@ MatrixName kUxName = "ux", kUyName = "uy", kUzName = "uz";
 MatrixName kUxNonStaggeredName = "ux_non_staggered", kUyNonStaggeredName = "uy_non_staggered",
            kUzNonStaggeredName = "uz_non_staggered";
 MatrixName kUxFinalName = "ux_final", kUyFinalName = "uy_final", kUzFinalName = "uz_final";
+MatrixName kDxudxnName = "dxudxn", kDyudynName = "dyudyn", kDzudznName = "dzudzn", kDxudxnSgxName = "dxudxn_sgx",
+           kDyudynSgyName = "dyudyn_sgy", kDzudznSgzName = "dzudzn_sgz"; // non-uniform grid (MatrixNames.h:100-111)
 MatrixName kRhoXName = "rhox", kRhoYName = "rhoy", kRhoZName = "rhoz";
 MatrixName kUxSgxName = "ux_sgx", kUySgyName = "uy_sgy", kUzSgzName = "uz_sgz";
 MatrixName kTimeIndexName = "t_index";

@@ -82,8 +82,8 @@ void Parameters::init(const InputProvider& in, const Options& options)
   in.readScalarValue(kNonUniformGridFlagName, mNonUniformGridFlag);
   in.readScalarValue(kAbsorbingFlagName, mAbsorbingFlag);
   in.readScalarValue(kNonLinearFlagName, mNonLinearFlag);
-  if (mNonUniformGridFlag != 0)
-    throw std::invalid_argument("Non-uniform grids are not implemented in this build (later scope row)");
+  if (mNonUniformGridFlag != 0 && (isSlabDecomposed() || !isSimulation3D()))
+    throw std::invalid_argument("Non-uniform grids are implemented for single-GPU 3-D simulations only");
 
   mTransducerSourceInputSize = (mTransducerSourceFlag == 0) ? 0 : in.getDatasetSize(kTransducerSourceInputName);
   mVelocitySourceIndexSize   = 0;

@@ -90,6 +90,11 @@ template<SD sd> void computePressureGradient(const MatrixContainer& c)
                                        cplx(c, MI::kTempHipFftZ), real(c, MI::kKappa), cplx(c, MI::kDdxKShiftPosR),
                                        cplx(c, MI::kDdyKShiftPos), cplx(c, MI::kDdzKShiftPos)));
 }
+template<SD sd> void computeVelocityGradientShiftNonuniform(const MatrixContainer& c)
+{ // SolverCudaKernels.cuh:293; .cu:1303-1320
+  kwCheck(kw_compute_velocity_gradient_shift_nonuniform(ctx(), real(c, MI::kDuxdx), real(c, MI::kDuydy), real(c, MI::kDuzdz),
+                                                        real(c, MI::kDxudxn), real(c, MI::kDyudyn), real(c, MI::kDzudzn)));
+}
 template<SD sd> void computeVelocityGradient(const MatrixContainer& c)
 {
   kwCheck(kw_compute_velocity_gradient(ctx(), cplx(c, MI::kTempHipFftX), cplx(c, MI::kTempHipFftY),
@@ -182,6 +187,7 @@ template void computeInitialVelocityHeterogeneous<SD::k3D>(const MatrixContainer
 template void computeInitialVelocityHomogeneousUniform<SD::k3D>(const MatrixContainer&);
 template void computePressureGradient<SD::k3D>(const MatrixContainer&);
 template void computeVelocityGradient<SD::k3D>(const MatrixContainer&);
+template void computeVelocityGradientShiftNonuniform<SD::k3D>(const MatrixContainer&);
 template void computeDensityNonlinear<SD::k3D>(const MatrixContainer&);
 template void computeDensityLinear<SD::k3D>(const MatrixContainer&);
 template void computePressureTermsNonlinear<SD::k3D>(RealMatrix&, RealMatrix&, RealMatrix&, const MatrixContainer&);

@@ -30,6 +30,7 @@ template<SD simulationDimension = SD::k3D> void computeInitialVelocityHeterogene
 template<SD simulationDimension = SD::k3D> void computeInitialVelocityHomogeneousUniform(const MatrixContainer& container);
 template<SD simulationDimension = SD::k3D> void computePressureGradient(const MatrixContainer& container);
 template<SD simulationDimension = SD::k3D> void computeVelocityGradient(const MatrixContainer& container);
+template<SD simulationDimension = SD::k3D> void computeVelocityGradientShiftNonuniform(const MatrixContainer& container); // .cuh:293
 template<SD simulationDimension = SD::k3D> void computeDensityNonlinear(const MatrixContainer& container);
 template<SD simulationDimension = SD::k3D> void computeDensityLinear(const MatrixContainer& container);
 template<SD simulationDimension = SD::k3D>

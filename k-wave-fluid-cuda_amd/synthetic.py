@@ -105,7 +105,8 @@ def make_problem(nx: int, ny: Optional[int] = None, nz: Optional[int] = None, *,
                  pml_off: bool = False, dx: float = 2.0e-4, cfl: float = 0.3,
                  source_mode: int = 0, source_many: int = 0, sensor: str = "plane",
                  hetero_subset: Optional[dict] = None, seed: int = 0x5EED1234,
-                 nt_src: Optional[int] = None, zslab: Optional[tuple] = None) -> Dict[str, np.ndarray]:
+                 nt_src: Optional[int] = None, zslab: Optional[tuple] = None,
+                 nonuniform: bool = False) -> Dict[str, np.ndarray]:
     """Build one synthetic problem.
 
     source: "p0" (1 MPa Gaussian ball), "p_source" (1 MHz tone burst on plane x=12),
@@ -176,7 +177,15 @@ def make_problem(nx: int, ny: Optional[int] = None, nz: Optional[int] = None, *,
     for ax in "xyz":
         pr[f"pml_{ax}_size"] = scalar_u(0 if pml_off else pml_size)
         pr[f"pml_{ax}_alpha"] = scalar_f(pml_alpha)
-    pr["nonuniform_grid_flag"] = scalar_u(0)
+    pr["nonuniform_grid_flag"] = scalar_u(int(nonuniform))
+    if nonuniform:
+        # derivative scalings of a smoothly stretched grid (k-Wave's makeGrid/setNUGrid writes d(uniform)/d(non-uniform) on
+        # the regular and on the staggered points); any positive vectors exercise the kernels
+        for ax, nn in (("x", nx), ("y", ny), ("z", nz)):
+            t = np.arange(nn, dtype=np.float64)
+            shape = {"x": (1, 1, nn), "y": (1, nn, 1), "z": (nn, 1, 1)}[ax]
+            pr[f"d{ax}ud{ax}n"] = (1.0 + 0.15 * np.sin(two_pi * t / nn)).astype(F32).reshape(shape)
+            pr[f"d{ax}ud{ax}n_sg{ax}"] = (1.0 + 0.15 * np.sin(two_pi * (t + 0.5) / nn)).astype(F32).reshape(shape)
     pr["nonlinear_flag"] = scalar_u(int(nonlinear))
     pr["absorbing_flag"] = scalar_u(int(absorbing))
 

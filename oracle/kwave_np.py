@@ -58,6 +58,14 @@ class NumpySim:
         self.rho0 = f8("rho0") if pr["rho0"].size > 1 else _sc(pr["rho0"])
         self.dtrho = [self.dt / (f8(k) if pr[k].size > 1 else _sc(pr[k])) for k in ("rho0_sgx", "rho0_sgy", "rho0_sgz")]
         self.bona = (f8("BonA") if pr["BonA"].size > 1 else _sc(pr["BonA"])) if "BonA" in pr else 0.0
+        # non-uniform grid (MatrixContainer.cpp:301-329): dt/rho0_sg carries the staggered-grid derivative scaling
+        # (KSpaceFirstOrderSolver.cpp:2650-2685 / SolverCudaKernels.cu:372-410), the velocity gradient the regular one
+        self.nonuniform = int(_sc(pr.get("nonuniform_grid_flag", 0)))
+        self.dudn = None
+        if self.nonuniform:
+            sg = [f8("dxudxn_sgx").reshape(1, 1, -1), f8("dyudyn_sgy").reshape(1, -1, 1), f8("dzudzn_sgz").reshape(-1, 1, 1)]
+            self.dtrho = [self.dtrho[a] * sg[a] for a in range(3)]
+            self.dudn = [f8("dxudxn").reshape(1, 1, -1), f8("dyudyn").reshape(1, -1, 1), f8("dzudzn").reshape(-1, 1, 1)]
         # operators, broadcast shapes
         self.ddx_pos = _c(pr["ddx_k_shift_pos_r"]).reshape(1, 1, -1)
         self.ddy_pos = _c(pr["ddy_k_shift_pos"]).reshape(1, -1, 1)
@@ -152,6 +160,8 @@ class NumpySim:
         self.du[0] = self.Fi(self.F(self.u[0]) * kd * self.ddx_neg)
         self.du[1] = self.Fi(self.F(self.u[1]) * kd * self.ddy_neg)
         self.du[2] = self.Fi(self.F(self.u[2]) * kd * self.ddz_neg)
+        if self.dudn is not None:  # SolverCudaKernels.cu:1285-1301
+            self.du = [self.du[a] * self.dudn[a] for a in range(3)]
         # A9
         if self.nonlinear:
             s = (2.0 * (self.rho[0] + self.rho[1] + self.rho[2]) + self.rho0) * self.dt

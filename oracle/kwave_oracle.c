@@ -590,6 +590,19 @@ kwo_sim* kwo_create(const kwo_problem* prob)
       s->dtrho0sgy[i] = prob->dt / prob->rho0_sgy[i];
       s->dtrho0sgz[i] = prob->dt / prob->rho0_sgz[i];
     }
+    if (prob->dxudxn_sgx)
+    { /* non-uniform grid: generateInitialDenisty (KSpaceFirstOrderSolver.cpp:2650-2685): (dt * dxudxn_sgx[x]) / rho0_sgx */
+#pragma omp parallel for schedule(static)
+      for (size_t z = 0; z < s->nz; z++)
+        for (size_t y = 0; y < s->ny; y++)
+          for (size_t x = 0; x < s->nx; x++)
+          {
+            const size_t i = (z * s->ny + y) * s->nx + x;
+            s->dtrho0sgx[i] = (prob->dt * prob->dxudxn_sgx[x]) / prob->rho0_sgx[i];
+            s->dtrho0sgy[i] = (prob->dt * prob->dyudyn_sgy[y]) / prob->rho0_sgy[i];
+            s->dtrho0sgz[i] = (prob->dt * prob->dzudzn_sgz[z]) / prob->rho0_sgz[i];
+          }
+    }
   }
   else
   {
@@ -707,6 +720,15 @@ static void velocity_update(kwo_sim* s)
           const float gx = d * s->t1[i] * s->dtrho0sgx[i];
           const float gy = d * s->t2[i] * s->dtrho0sgy[i];
           const float gz = d * s->t3[i] * s->dtrho0sgz[i];
+          s->ux[i] = (s->ux[i] * ex - gx) * ex;
+          s->uy[i] = (s->uy[i] * ey - gy) * ey;
+          s->uz[i] = (s->uz[i] * ez - gz) * ez;
+        }
+        else if (s->pr.dxudxn_sgx)
+        { /* homogeneous, non-uniform grid: SolverCudaKernels.cu:372-410 */
+          const float gx = divX * s->pr.dxudxn_sgx[x] * s->t1[i];
+          const float gy = divY * s->pr.dyudyn_sgy[y] * s->t2[i];
+          const float gz = divZ * s->pr.dzudzn_sgz[z] * s->t3[i];
           s->ux[i] = (s->ux[i] * ex - gx) * ex;
           s->uy[i] = (s->uy[i] * ey - gy) * ey;
           s->uz[i] = (s->uz[i] * ez - gz) * ez;
@@ -978,8 +1000,24 @@ static void add_initial_pressure_source(kwo_sim* s)
   else
   {
     const float dX = d * 0.5f * s->dtrho0sgx_s, dY = d * 0.5f * s->dtrho0sgy_s, dZ = d * 0.5f * s->dtrho0sgz_s;
+    if (pr->dxudxn_sgx)
+    { /* computeInitialVelocityHomogeneousNonuniform (SolverCudaKernels.cu:1061-1083) */
 #pragma omp parallel for schedule(static)
-    for (size_t i = 0; i < n; i++) { s->ux[i] *= dX; s->uy[i] *= dY; s->uz[i] *= dZ; }
+      for (size_t z = 0; z < s->nz; z++)
+        for (size_t y = 0; y < s->ny; y++)
+          for (size_t x = 0; x < s->nx; x++)
+          {
+            const size_t i = (z * s->ny + y) * s->nx + x;
+            s->ux[i] *= dX * pr->dxudxn_sgx[x];
+            s->uy[i] *= dY * pr->dyudyn_sgy[y];
+            s->uz[i] *= dZ * pr->dzudzn_sgz[z];
+          }
+    }
+    else
+    {
+#pragma omp parallel for schedule(static)
+      for (size_t i = 0; i < n; i++) { s->ux[i] *= dX; s->uy[i] *= dY; s->uz[i] *= dZ; }
+    }
   }
 }
 
@@ -1010,6 +1048,19 @@ void kwo_step(kwo_sim* s)
   kwo_fft_c2r_3d((const float*)s->cx, s->duxdx, s->nx, s->ny, s->nz);
   kwo_fft_c2r_3d((const float*)s->cy, s->duydy, s->nx, s->ny, s->nz);
   kwo_fft_c2r_3d((const float*)s->cz, s->duzdz, s->nx, s->ny, s->nz);
+  if (pr->dxudxn)
+  { /* non-uniform grid: computeVelocityGradientShiftNonuniform (SolverCudaKernels.cu:1285-1301; …Solver.cpp:2145-2149) */
+#pragma omp parallel for schedule(static)
+    for (size_t z = 0; z < s->nz; z++)
+      for (size_t y = 0; y < s->ny; y++)
+        for (size_t x = 0; x < s->nx; x++)
+        {
+          const size_t i = (z * s->ny + y) * s->nx + x;
+          s->duxdx[i] *= pr->dxudxn[x];
+          s->duydy[i] *= pr->dyudyn[y];
+          s->duzdz[i] *= pr->dzudzn[z];
+        }
+  }
   density_update(s);
   add_pressure_source(s);
   pressure_update(s);

@@ -74,6 +74,14 @@ typedef struct kwo_problem
   float c0_s, rho0_s, rho0_sgx_s, rho0_sgy_s, rho0_sgz_s, bona_s, alpha_coeff_s;
   int32_t nonlinear_flag, absorbing_flag;
   int32_t p_source_mode, p_source_many, u_source_mode, u_source_many;
+  /* non-uniform grid (nonuniform_grid_flag; MatrixContainer.cpp:301-329): derivative scalings per axis, on the regular
+   * and on the staggered grid; all NULL on a uniform grid */
+  const float* dxudxn;      /* [nx] */
+  const float* dyudyn;      /* [ny] */
+  const float* dzudzn;      /* [nz] */
+  const float* dxudxn_sgx;  /* [nx] */
+  const float* dyudyn_sgy;  /* [ny] */
+  const float* dzudzn_sgz;  /* [nz] */
 } kwo_problem;
 
 typedef struct kwo_sim kwo_sim;

@@ -67,6 +67,8 @@ class Problem(C.Structure):
         ("nonlinear_flag", C.c_int32), ("absorbing_flag", C.c_int32),
         ("p_source_mode", C.c_int32), ("p_source_many", C.c_int32), ("u_source_mode", C.c_int32),
         ("u_source_many", C.c_int32),
+        ("dxudxn", C.c_void_p), ("dyudyn", C.c_void_p), ("dzudzn", C.c_void_p),
+        ("dxudxn_sgx", C.c_void_p), ("dyudyn_sgy", C.c_void_p), ("dzudzn_sgz", C.c_void_p),
     ]
 
 
@@ -178,6 +180,9 @@ class OracleSim:
             setattr(P, nm, _ptr(arr(nm)))
         for nm in ("dt", "dx", "dy", "dz", "c_ref"):
             setattr(P, nm, _sc(pr[nm]))
+        if int(_sc(pr.get("nonuniform_grid_flag", 0))):
+            for nm in ("dxudxn", "dyudyn", "dzudzn", "dxudxn_sgx", "dyudyn_sgy", "dzudzn_sgz"):
+                setattr(P, nm, _ptr(arr(nm)))
         P.alpha_power = _sc(pr["alpha_power"]) if "alpha_power" in pr else 0.0
         P.nonlinear_flag = int(_sc(pr["nonlinear_flag"]))
         P.absorbing_flag = int(_sc(pr["absorbing_flag"]))
