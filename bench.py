@@ -85,7 +85,7 @@ def alg_bytes(n: int, *, het=True, nonlinear=True, absorbing=True):
     return b, per
 
 
-def cpu_baseline(pr, n, budget_s=25.0):
+def cpu_baseline(pr, n, budget_s=20.0):
     """CPU oracle ("port" of the reference algorithm, own FFT — no FFTW/MKL in the image) on the host cores."""
     from oracle import oracle as orc
     cores = int(os.environ.get("OMP_NUM_THREADS", "0")) or orc.host_threads()
@@ -94,7 +94,7 @@ def cpu_baseline(pr, n, budget_s=25.0):
     t0 = time.time()
     sim.step(1)
     one = time.time() - t0
-    steps = max(1, min(20, int(budget_s / max(one, 1e-3)) - 1))
+    steps = max(1, min(100, int(budget_s / max(one, 1e-3)) - 1))
     t0 = time.time()
     sim.step(steps)
     dt = time.time() - t0
@@ -268,7 +268,7 @@ def main():
                                   f"nonlinear, p0 source, p_raw+p_max on one xy plane ({n * n} points)",
                       "grid": [n, n, n], "fused_kernels": not args.granular,
                       "fft": "rocFFT 3-D R2C/C2R" if args.granular else "hand-written fused FFT passes (kw_fused.hip)",
-                      "device": info.name.decode(), "baseline_ref": "BASELINE.md: 49.72 ms/step, TITAN X, "
+                      "device": (info.name.decode() or info.arch.decode()), "baseline_ref": "BASELINE.md: 49.72 ms/step, TITAN X, "
                       "kspaceFirstOrder3D-CUDA v1.1 (manual Table C.4)", "input_generation_s": round(t_gen, 1)},
            "roofline": roofline}
     if not args.no_cpu:
