@@ -101,9 +101,13 @@ def main():
         table.append({"kernel": k, "launches": f256[k][0], "FETCH_SIZE_bytes": round(f256[k][1]),
                       "WRITE_SIZE_bytes": round(w256[k][1]), "read_bytes_corrected": round(rd),
                       "traffic_bytes": round(rd + w256[k][1])})
-        if k == "k_xinv<256, 3, true>":
+        if k.startswith("k_xinv<256, 3, true"):
             steps = f256[k][0]
     by = {t["kernel"]: t for t in table}
+    for t in table:  # template arguments added later (k_xinv<L, EPI, CHAIN, TERMS>): also index by the 3-argument prefix
+        m = re.match(r"(k_xinv<256, \d, (?:true|false))", t["kernel"])
+        if m:
+            by.setdefault(m.group(1) + ">", t)
     per_step = sum(t["traffic_bytes"] * t["launches"] for t in table if t["kernel"].startswith("k_") and
                    not t["kernel"].startswith(("k_import", "k_add_initial", "k_xinv<256, 2"))) / max(steps or 1, 1)
 
