@@ -348,6 +348,10 @@ KW_API kw_status kw_fused_scale_source(kw_ctx* ctx, float* scaled_source, const 
 /* sampleIndex<op> (.cuh:58-62, .cu:83-126) */
 KW_API kw_status kw_sample_index(kw_ctx* ctx, kw_reduce_op op, float* sampling_buffer, const float* source_data,
                                  const uint64_t* sensor_data, uint64_t n_samples);
+/* the same for up to four operators of one field over one mask in one launch (e.g. -p --p_max): index and value are read
+ * once; each buffer gets exactly what its own sampleIndex<op> call would give */
+KW_API kw_status kw_sample_index_multi(kw_ctx* ctx, int n_ops, const kw_reduce_op* ops, float* const* sampling_buffers,
+                                       const float* source_data, const uint64_t* sensor_data, uint64_t n_samples);
 /* sampleCuboid<op> (.cuh:75-81, .cu:164-252): corners are 0-based inclusive (x,y,z), matrix_size = (nx,ny,nz) */
 KW_API kw_status kw_sample_cuboid(kw_ctx* ctx, kw_reduce_op op, float* sampling_buffer, const float* source_data,
                                   const uint32_t top_left[3], const uint32_t bottom_right[3],

@@ -137,6 +137,7 @@ _SIG: Dict[str, list] = {
     "kw_fused_scale_source": [_P, _P, _P],
     "kw_fused_probe": [_P, C.c_int, _P],
     "kw_sample_index": [_P, C.c_int, _P, _P, _P, _U64],
+    "kw_sample_index_multi": [_P, C.c_int, _P, _P, _P, _P, C.c_uint64],
     "kw_sample_cuboid": [_P, C.c_int, _P, _P, _P, _P, _P, _U64],
     "kw_sample_all": [_P, C.c_int, _P, _P, _U64],
     "kw_post_processing_rms": [_P, _P, C.c_float, _U64],

@@ -26,6 +26,32 @@ __global__ __launch_bounds__(256) void k_sample_index(float* __restrict__ buf, c
     reduce<op>(&buf[i], src[mask[i]]);
 }
 
+// several reduce operators of ONE field over ONE mask in a single launch (e.g. -p --p_max --p_rms): the index and the
+// gathered value are read once; per operator the arithmetic is exactly k_sample_index's
+struct MultiSampleArgs { float* buf[4]; int32_t op[4]; int32_t n_ops; };
+__global__ __launch_bounds__(256) void k_sample_index_multi(MultiSampleArgs a, const float* __restrict__ src,
+                                                             const uint64_t* __restrict__ mask, uint64_t n)
+{
+  for (uint64_t i = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n;
+       i += static_cast<uint64_t>(gridDim.x) * blockDim.x)
+  {
+    const float v = src[mask[i]];
+#pragma unroll
+    for (int o = 0; o < 4; o++)
+    {
+      if (o >= a.n_ops) break;
+      float* b = a.buf[o] + i;
+      switch (a.op[o])
+      {
+        case KW_OP_NONE: reduce<KW_OP_NONE>(b, v); break;
+        case KW_OP_RMS: reduce<KW_OP_RMS>(b, v); break;
+        case KW_OP_MAX: reduce<KW_OP_MAX>(b, v); break;
+        default: reduce<KW_OP_MIN>(b, v); break;
+      }
+    }
+  }
+}
+
 // cuboid-local x on threads, (y,z) rows on grid: no per-element division (the reference divides per element,
 // OutputStreamsCudaKernels.cu:164-188); the output index is the same cuboid-local linear index.
 template<kw_reduce_op op>
@@ -159,6 +185,27 @@ kw_status kw_sample_index(kw_ctx* ctx, kw_reduce_op op, float* buf, const float*
   if (n == 0) return KW_OK;
   KW_REQUIRE(buf && src && mask);
   DISPATCH_OP(op, k_sample_index, dim3(sampler_grid(ctx, n)), buf, src, mask, n);
+  return KW_OK;
+}
+
+kw_status kw_sample_index_multi(kw_ctx* ctx, int n_ops, const kw_reduce_op* ops, float* const* bufs, const float* src,
+                                const uint64_t* mask, uint64_t n)
+{
+  KW_CHECK_CTX(ctx);
+  KW_PROF(ctx, "sample_index");
+  KW_REQUIRE(n_ops >= 1 && n_ops <= 4 && ops && bufs);
+  if (n == 0) return KW_OK;
+  KW_REQUIRE(src && mask);
+  MultiSampleArgs a{};
+  a.n_ops = n_ops;
+  for (int o = 0; o < n_ops; o++)
+  {
+    KW_REQUIRE(bufs[o] != nullptr && ops[o] >= KW_OP_NONE && ops[o] <= KW_OP_MIN);
+    a.buf[o] = bufs[o];
+    a.op[o]  = static_cast<int32_t>(ops[o]);
+  }
+  hipLaunchKernelGGL(k_sample_index_multi, dim3(sampler_grid(ctx, n)), dim3(256), 0, ctx->stream, a, src, mask, n);
+  KW_LAUNCH_CHECK();
   return KW_OK;
 }
 

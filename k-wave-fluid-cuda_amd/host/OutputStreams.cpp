@@ -1,6 +1,7 @@
 // OutputStreams.cpp — see OutputStreams.h.
 #include "OutputStreams.h"
 
+#include <algorithm>
 #include <cstring>
 #include <limits>
 #include <stdexcept>
@@ -17,6 +18,12 @@ namespace OutputStreamsHipKernels
 void sampleIndex(ReduceOperator op, float* buf, const float* src, const size_t* mask, size_t n)
 {
   kwCheck(kw_sample_index(ctx(), static_cast<kw_reduce_op>(op), buf, src, (const uint64_t*)mask, n));
+}
+void sampleIndexMulti(int nOps, const ReduceOperator* ops, float* const* bufs, const float* src, const size_t* mask, size_t n)
+{
+  kw_reduce_op kops[4];
+  for (int o = 0; o < nOps && o < 4; o++) kops[o] = static_cast<kw_reduce_op>(ops[o]);
+  kwCheck(kw_sample_index_multi(ctx(), nOps, kops, bufs, src, (const uint64_t*)mask, n));
 }
 void sampleCuboid(ReduceOperator op, float* buf, const float* src, const DimensionSizes& tl, const DimensionSizes& br,
                   const DimensionSizes& size, size_t n)
@@ -156,10 +163,13 @@ void IndexOutputStream::create()
 }
 void IndexOutputStream::sample()
 {
-  const int b   = mSampledSteps & 1;
-  float*    dst = (mReduceOp == ReduceOperator::kNone) ? mDeviceRaw[b] : mDeviceBuffer;
-  OutputStreamsHipKernels::sampleIndex(kernelOp(), dst, mSourceMatrix.getDeviceData(), mSensorMask.getDeviceData(), mSize);
-  if (mReduceOp == ReduceOperator::kNone) rawSampleTail(ctx(), dst, mPinned[b], mEvent[b], mSize);
+  OutputStreamsHipKernels::sampleIndex(kernelOp(), sampleTarget(), mSourceMatrix.getDeviceData(), mSensorMask.getDeviceData(), mSize);
+  sampleDone();
+}
+void IndexOutputStream::sampleDone()
+{
+  const int b = mSampledSteps & 1;
+  if (mReduceOp == ReduceOperator::kNone) rawSampleTail(ctx(), mDeviceRaw[b], mPinned[b], mEvent[b], mSize);
   mSampledSteps++;
 }
 void IndexOutputStream::flushRaw()
@@ -396,7 +406,33 @@ void OutputStreamContainer::createStreams()
 }
 void OutputStreamContainer::sampleStreams()
 {
-  for (auto& it : mContainer) it.second->sample();
+  // index streams of the same field over the same mask (-p --p_max ...) share one launch; container order is kept
+  // within a group, and every buffer receives exactly what its own sampleIndex<op> launch would write
+  std::vector<BaseOutputStream*> done;
+  for (auto& it : mContainer)
+  {
+    auto* first = dynamic_cast<IndexOutputStream*>(it.second);
+    if (first == nullptr || std::find(done.begin(), done.end(), it.second) != done.end()) continue;
+    std::vector<IndexOutputStream*> group{first};
+    for (auto& jt : mContainer)
+    {
+      auto* other = dynamic_cast<IndexOutputStream*>(jt.second);
+      if (other != nullptr && other != first && group.size() < 4 && &other->source() == &first->source() &&
+          &other->mask() == &first->mask() && std::find(done.begin(), done.end(), jt.second) == done.end())
+        group.push_back(other);
+    }
+    if (group.size() > 1)
+    {
+      OutputStreamsHipKernels::ReduceOperator ops[4];
+      float* bufs[4];
+      for (size_t g = 0; g < group.size(); g++) { ops[g] = group[g]->kernelOperator(); bufs[g] = group[g]->sampleTarget(); }
+      OutputStreamsHipKernels::sampleIndexMulti(static_cast<int>(group.size()), ops, bufs, first->source().getDeviceData(),
+                                                first->mask().getDeviceData(), first->size());
+      for (IndexOutputStream* s : group) { s->sampleDone(); done.push_back(s); }
+    }
+  }
+  for (auto& it : mContainer)
+    if (std::find(done.begin(), done.end(), it.second) == done.end()) it.second->sample();
   // the reference runs these two passes inside the next step's flushRawStreams (OutputStreamContainer.cpp:380-403);
   // with device-resident accumulators they can follow the sampling immediately, in the same order
   for (auto& it : mContainer)

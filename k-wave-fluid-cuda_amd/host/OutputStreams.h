@@ -20,6 +20,8 @@ namespace OutputStreamsHipKernels
 {
 enum class ReduceOperator { kNone = 0, kRms = 1, kMax = 2, kMin = 3 };
 void sampleIndex(ReduceOperator op, float* samplingBuffer, const float* sourceData, const size_t* sensorData, size_t nSamples);
+void sampleIndexMulti(int nOps, const ReduceOperator* ops, float* const* samplingBuffers, const float* sourceData,
+                      const size_t* sensorData, size_t nSamples);
 void sampleCuboid(ReduceOperator op, float* samplingBuffer, const float* sourceData, const DimensionSizes& topLeftCorner,
                   const DimensionSizes& bottomRightCorner, const DimensionSizes& matrixSize, size_t nSamples);
 void sampleAll(ReduceOperator op, float* samplingBuffer, const float* sourceData, size_t nSamples);
@@ -76,6 +78,13 @@ class IndexOutputStream : public BaseOutputStream
   void create() override;
   void sample() override;   // IndexOutputStream.cpp:253-293
   void flushRaw() override; // IndexOutputStream.cpp:348-371 (raw branch)
+  /// sample() in two halves, so that the container can serve several streams of one field with one kernel launch:
+  /// where this step's values go and with which operator / what follows the kernel (raw: the D2H copy)
+  float* sampleTarget() { return (mReduceOp == ReduceOperator::kNone) ? mDeviceRaw[mSampledSteps & 1] : mDeviceBuffer; }
+  void   sampleDone();
+  const RealMatrix&  source() const { return mSourceMatrix; }
+  const IndexMatrix& mask() const { return mSensorMask; }
+  OutputStreamsHipKernels::ReduceOperator kernelOperator() const { return kernelOp(); }
  private:
   const IndexMatrix& mSensorMask;
 };

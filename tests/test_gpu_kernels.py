@@ -79,6 +79,28 @@ def test_sample_index_bit_exact(dev, orc, op):
     assert np.array_equal(d_buf.download(), ref)
 
 
+def test_sample_index_multi_equals_separate_launches(dev, orc):
+    """raw + rms + max + min of one field over one mask in one launch == four sampleIndex<op> launches, bit for bit"""
+    import ctypes as C
+    rng = np.random.default_rng(11)
+    src = rng.standard_normal(48 * 40 * 32).astype(np.float32)
+    mask = np.sort(rng.choice(src.size, size=7001, replace=False)).astype(np.uint64)
+    inits = [0.0, 0.0, -np.finfo(np.float32).max, np.finfo(np.float32).max]
+    refs = [np.full(mask.size, v, dtype=np.float32) for v in inits]
+    d_src, d_mask = dev.array(src), dev.array(mask)
+    d_bufs = [dev.array(r.copy()) for r in refs]
+    ops = (C.c_int * 4)(0, 1, 2, 3)
+    ptrs = (C.c_void_p * 4)(*[b.ptr for b in d_bufs])
+    for rep in range(3):
+        s = (src * np.float32(1.5 - rep)).astype(np.float32)
+        d_src.upload(s)
+        dev.call("sample_index_multi", 4, ops, ptrs, d_src, d_mask, mask.size)
+        for op in range(4):
+            orc.sample_index(op, refs[op], s, mask)
+    for op in range(4):
+        assert np.array_equal(d_bufs[op].download(), refs[op]), op
+
+
 def test_sample_index_empty_mask_is_noop(dev):
     d = dev.array(np.ones(8, dtype=np.float32))
     dev.call("sample_index", 0, d, d, None, 0)  # n == 0: must not touch pointers
