@@ -94,6 +94,9 @@ template<int R, int DIR> struct Dft
   }
   static __device__ __forceinline__ void run(float2 (&v)[R])
   {
+#ifdef KW_NO_DFT /* timing experiment only: how much of a pass is butterfly arithmetic (results are wrong) */
+    return;
+#endif
     float2 e[R / 2], o[R / 2];
 #pragma unroll
     for (int k = 0; k < R / 2; k++) { e[k] = v[2 * k]; o[k] = v[2 * k + 1]; }
