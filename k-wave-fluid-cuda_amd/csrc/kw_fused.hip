@@ -64,6 +64,32 @@ template<int L> struct Geo
 // flight across the exchange steps.
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
+// State and medium arrays are touched once per step and not again for a whole step (> 5 GB of traffic later): they are
+// streamed past the caches (non-temporal), which leaves the 256 MB Infinity Cache to the spectral scratch that the very
+// next kernel re-reads.  Measured: +5.4 % on the whole step (KW_TEMPORAL_STATE restores plain accesses for A/B); the
+// same for the reduced operators (+2.6 %).  Spectra stay on plain accesses: marking their last-use reads non-temporal
+// costs 0.6-2 % in every pass type.
+#ifndef KW_TEMPORAL_STATE
+typedef float v4f __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 ld4(const float* p)
+{
+  const v4f v = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(p));
+  return make_float4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ void st4(float* p, const float4& v)
+{
+  v4f t = { v.x, v.y, v.z, v.w };
+  __builtin_nontemporal_store(t, reinterpret_cast<v4f*>(p));
+}
+__device__ __forceinline__ float ldop(const float* p) { return __builtin_nontemporal_load(p); }
+#else
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ void   st4(float* p, const float4& v) { *reinterpret_cast<float4*>(p) = v; }
+__device__ __forceinline__ float  ldop(const float* p) { return *p; }
+#endif
+#define LDOP(p) ldop(p) // reduced real operators (kappa, nabla): one or two reads per step each (+2.6 % measured)
+
+
 // ---- register-level steps -------------------------------------------------------------------------------------------
 // Fill the block's twiddle table from the global one (tw[m] = exp(-2*pi*i*m/L)); the caller's next lds_barrier()
 // publishes it.  Every use below is "one VGPR base + compile-time offset", so twiddles cost neither address registers
@@ -285,7 +311,7 @@ template<int L, int MODE> __global__ __launch_bounds__(Geo<L>::THREADS) void k_z
   {
     const float* __restrict__ op = a.op[(MODE == Z_ABSORB) ? arr0 : 0];
 #pragma unroll
-    for (int k2 = 0; k2 < R2; k2++) kap[k2] = op[opbase + static_cast<uint32_t>(j + R1 * k2) * opzstr];
+    for (int k2 = 0; k2 < R2; k2++) kap[k2] = LDOP(op + opbase + static_cast<uint32_t>(j + R1 * k2) * opzstr);
   }
   lds_barrier(); // twiddle table visible (the loads above stay in flight across it)
 
@@ -332,7 +358,7 @@ template<int L, int MODE> __global__ __launch_bounds__(Geo<L>::THREADS) void k_z
         uint32_t lb = opbase + static_cast<uint32_t>(j) * opzstr;
         asm volatile("" : "+v"(lb));
 #pragma unroll
-        for (int k2 = 0; k2 < R2; k2++) kap[k2] = op[lb + static_cast<uint32_t>(R1 * k2) * opzstr];
+        for (int k2 = 0; k2 < R2; k2++) kap[k2] = LDOP(op + lb + static_cast<uint32_t>(R1 * k2) * opzstr);
       }
     }
     lds_barrier(); // forward exchange buffer is free again
@@ -560,8 +586,8 @@ template<int L, int MODE> __global__ __launch_bounds__(Geo<L / 2>::THREADS) void
 #pragma unroll
     for (int k2 = 0; k2 < R2; k2++)
     {
-      float sa = op[lb + static_cast<uint32_t>(2 * R1 * k2) * opzstr];
-      float sb = op[lb + static_cast<uint32_t>(2 * R1 * k2 + 1) * opzstr];
+      float sa = LDOP(op + lb + static_cast<uint32_t>(2 * R1 * k2) * opzstr);
+      float sb = LDOP(op + lb + static_cast<uint32_t>(2 * R1 * k2 + 1) * opzstr);
       if (MODE == Z_VGRAD || MODE == Z_SOURCE) { sa *= a.divider; sb *= a.divider; }
       Xa[k2] = make_float2(Xa[k2].x * sa, Xa[k2].y * sa);
       Xb[k2] = make_float2(Xb[k2].x * sb, Xb[k2].y * sb);
@@ -801,8 +827,7 @@ __device__ __forceinline__ void   f4put(float4& v, int k, float s)
 {
   if (k == 0) v.x = s; else if (k == 1) v.y = s; else if (k == 2) v.z = s; else v.w = s;
 }
-__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
-__device__ __forceinline__ void   st4(float* p, const float4& v) { *reinterpret_cast<float4*>(p) = v; }
+
 
 // The inverse leaves each thread with x = f + R1*k2 of two rows — a 64-B-segment pattern.  The results are restaged
 // through LDS as a plain real tile [32 rows][L] and re-read as float4 in a row-contiguous mapping, so that every
