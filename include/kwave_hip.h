@@ -289,7 +289,9 @@ KW_API kw_status kw_fused_create_with_scratch(kw_ctx* ctx, void* const s[3], voi
 KW_API kw_status kw_fused_supported(kw_ctx* ctx, int* out_supported);
 KW_API kw_status kw_fused_create(kw_ctx* ctx);   /* scratch + twiddles; needs kw_set_constants */
 KW_API kw_status kw_fused_destroy(kw_ctx* ctx);
-KW_API kw_status kw_fused_reduced_elems(kw_ctx* ctx, size_t* out_floats);  /* floats of one padded reduced array */
+KW_API kw_status kw_fused_reduced_elems(kw_ctx* ctx, size_t* out_floats);  /* floats of one imported reduced array */
+/* reduced real operator (kappa, nabla1/2, sourceKappa: [nz][ny][nx/2+1]; slab mode: the transposed [nz_global][ny/P][..])
+ * -> the pipeline's private tile-blocked layout [ky][kx tile][kz][16] ("*_padded" arguments below) */
 KW_API kw_status kw_fused_import_reduced(kw_ctx* ctx, float* dst_padded, const float* src_reduced);
 /* computeVelocity (KSpaceFirstOrderSolver.cpp:2087-2119): R2C(p), computePressureGradient (.cu:1139-1157), 3x C2R,
  * computeVelocityHeterogeneous/HomogeneousUniform (.cu:184-215,278-308); dt_rho0_sg* NULL -> scalars */

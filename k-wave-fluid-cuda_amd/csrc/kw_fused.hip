@@ -290,7 +290,9 @@ template<int L, int MODE> __global__ __launch_bounds__(Geo<L>::THREADS) void k_z
   const uint32_t base   = ky * a.P + kx;
   const uint32_t kxl    = min(kx, a.nxc - 1u); // pad lanes re-read the last column; their results are never stored
   const uint32_t basel  = ky * a.P + kxl;
-  const uint32_t opbase = ky * a.Pop + kxl, opzstr = a.ny * a.Pop;
+  // operators live in a tile-blocked layout [ky][kx tile][kz][16]: the 16 x nz values of this block's tile are one
+  // contiguous run (k_import_reduced), instead of 64-B pieces a whole plane apart
+  const uint32_t opbase = ((ky * (a.Pop / NLMAX) + kxl / NLMAX) * a.nz) * NLMAX + kxl % NLMAX, opzstr = NLMAX;
   constexpr bool MULTI  = (MODE == Z_VGRAD || MODE == Z_ABSORB);
   const uint32_t arr0   = MULTI ? a.arr0 : 0;
   const uint32_t narr   = MULTI ? a.narr : 1;
@@ -549,7 +551,9 @@ template<int L, int MODE> __global__ __launch_bounds__(Geo<L / 2>::THREADS) void
   const uint32_t base   = ky * a.P + kx;
   const uint32_t kxl    = min(kx, a.nxc - 1u);
   const uint32_t basel  = ky * a.P + kxl;
-  const uint32_t opbase = ky * a.Pop + kxl, opzstr = a.ny * a.Pop;
+  // operators live in a tile-blocked layout [ky][kx tile][kz][16]: the 16 x nz values of this block's tile are one
+  // contiguous run (k_import_reduced), instead of 64-B pieces a whole plane apart
+  const uint32_t opbase = ((ky * (a.Pop / NLMAX) + kxl / NLMAX) * a.nz) * NLMAX + kxl % NLMAX, opzstr = NLMAX;
   constexpr bool MULTI  = (MODE == Z_VGRAD || MODE == Z_ABSORB);
   const uint32_t arr    = MULTI ? a.arr0 + blockIdx.z : 0;
   // PGRAD: the x- and y-gradients share one z-inverse — ddx(kx), ddy(ky) do not depend on kz, so they are applied after
@@ -1052,7 +1056,7 @@ __global__ __launch_bounds__(Geo<L>::THREADS, (EPI == EPI_DENSITY && L == 256) ?
             f4put(o1, t, ((eBonA * eRhoSum * eRhoSum) / (2.0f * r0)) + eRhoSum);
             f4put(o2, t, r0 * eDuSum);
           }
-          st4(a.t[1] + i, o1); // the nonlinear term is read again by the pressure sum
+          st4(a.t[1] + i, o1); // the nonlinear term is read again by the pressure sum (a stage later: cached or not, same time)
           if constexpr (CHAIN) { *reinterpret_cast<float4*>(&ldsr[(e / Q4) * RP + x]) = o2; fw[0][q] = o0; }
           else { st4(a.t[0] + i, o0); st4(a.t[2] + i, o2); }
         }
@@ -1138,16 +1142,23 @@ __global__ __launch_bounds__(Geo<L>::THREADS, (EPI == EPI_DENSITY && L == 256) ?
   }
 }
 
-// padded import of a reduced real operator: dst[z][y][P] <- src[z][y][nxc]
+// import of a reduced real operator into the pipeline's tile-blocked layout: dst[ky][kx tile][kz][16] <- src[kz][ky][nxc]
+// (rows = nyl local ky, nzg planes: the transposed operators of slab mode have the same form)
 __global__ void k_import_reduced(float* __restrict__ dst, const float* __restrict__ src, uint32_t nxc, uint32_t P,
-                                 size_t total)
+                                 uint32_t nyl, uint32_t nzg, size_t total)
 {
+  const uint32_t nt = P / NLMAX;
   for (size_t e = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x; e < total;
        e += static_cast<size_t>(gridDim.x) * blockDim.x)
   {
-    const size_t   r = e / P;
-    const uint32_t x = static_cast<uint32_t>(e - r * P);
-    dst[e]           = (x < nxc) ? src[r * nxc + x] : 0.f;
+    const uint32_t c  = static_cast<uint32_t>(e % NLMAX);
+    size_t         r  = e / NLMAX;
+    const uint32_t kz = static_cast<uint32_t>(r % nzg);
+    r /= nzg;
+    const uint32_t t  = static_cast<uint32_t>(r % nt);
+    const uint32_t ky = static_cast<uint32_t>(r / nt);
+    const uint32_t kx = t * NLMAX + c;
+    dst[e] = (kx < nxc) ? src[(static_cast<size_t>(kz) * nyl + ky) * nxc + kx] : 0.f;
   }
 }
 
@@ -1704,7 +1715,8 @@ kw_status kw_fused_import_reduced(kw_ctx* ctx, float* dst_padded, const float* s
   KW_REQUIRE(dst_padded && src);
   const kw_constants& c = ctx->c;
   const size_t total = static_cast<size_t>(c.ny) * c.nz * ctx->fused.P;
-  LAUNCH(k_import_reduced, dim3(ctx->cu_count * 8), dim3(256), dst_padded, src, c.nx_complex, ctx->fused.P, total);
+  LAUNCH(k_import_reduced, dim3(ctx->cu_count * 8), dim3(256), dst_padded, src, c.nx_complex, ctx->fused.P,
+         ctx->fused.nyl, ctx->fused.nz_global, total);
   return KW_OK;
 }
 
