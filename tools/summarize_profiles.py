@@ -87,10 +87,10 @@ def main():
     # measured on this build's own probes (8 B/lane tile loads and 16 B/lane flat loads)
     r8 = calib.get("k_probe_tile<256, 0>", {}).get("fetch_ratio")
     r16 = calib.get("k_probe_copy4", {}).get("fetch_ratio")
-    # true read bytes: 128-B requests are tallied at 64 B (x2), 64-B requests (the 4-B-per-lane operator reads of the
-    # z-fused kernels, 16 lanes per row segment) are tallied exactly
-    op_bytes = 4 * P * n * n  # one padded reduced real operator
-    op_reads = {"k_zfused<256, 0>": 1, "k_zfused<256, 1>": 1, "k_zfused<256, 2>": 2, "k_zfused<256, 3>": 1}
+    # true read bytes: 128-B read requests are tallied at 64 B (x2).  (Until the reduced operators moved to the tile-blocked
+    # layout their reads were 64-B requests, tallied exactly, and were excluded from the doubling.)
+    op_bytes = 4 * P * n * n  # one imported reduced real operator
+    op_reads = {}
     steps = None
     table = []
     for k in f256:
