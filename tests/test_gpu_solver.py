@@ -254,3 +254,41 @@ def test_compression_period_found_from_the_source_signal(syn):
     assert auto.stream("p_c").size > 0 and np.array_equal(auto.stream("p_c"), given.stream("p_c"))
     auto.close()
     given.close()
+
+
+def test_cuboid_sensor_mask_streams(orc, syn):
+    """sensor_mask_type = 1 (corners): two cuboids, concatenated in cuboid order, each x-fastest (CuboidOutputStream.cpp:263-345;
+    dataset layout sensor_mask_corners = (6, nCuboids, 1), 1-based inclusive corners)."""
+    n, nt = 32, 14
+    pr = syn.make_problem(n, heterogeneous=True, nonlinear=True, absorbing=True, source="p0", nt=nt + 4, pml_size=4)
+    pr = {k: v for k, v in pr.items() if k != "sensor_mask_index"}
+    corners = np.array([[3, 4, 5, 10, 9, 7], [12, 2, 20, 12, 2, 20]], dtype=np.uint64)  # a box and a single voxel
+    pr["sensor_mask_type"] = np.array([[[1]]], dtype=np.uint64)
+    pr["sensor_mask_corners"] = corners.reshape(1, 2, 6)
+    g = make_gpu(pr, p_raw=1, p_max=1, u_rms=1)
+    g.run(nt)
+    g.finish()
+
+    def gather(field):
+        out = []
+        for x0, y0, z0, x1, y1, z1 in corners.astype(int):
+            out.append(field[z0 - 1:z1, y0 - 1:y1, x0 - 1:x1].reshape(-1))
+        return np.concatenate(out)
+
+    raw = g.stream("p")
+    npts = 8 * 6 * 3 + 1
+    assert raw.shape == (nt, npts)
+    assert np.array_equal(raw[-1], gather(g.field("p")))          # bit-exact sampling of the device field
+    assert np.array_equal(g.stream("p_max"), raw.max(axis=0))
+    o = orc.OracleSim(pr)
+    acc = np.zeros(npts, dtype=np.float64)
+    for step in range(nt):
+        o.step()
+        # the cuboids sit in the quiet part of the field: judge the error against the field's own scale
+        assert np.abs(raw[step] - gather(o.field("p"))).max() < TOL * np.abs(o.field("p")).max(), step
+        acc += gather(o.field("ux")).astype(np.float64) ** 2
+    # RMS is scaled by 1 / (Nt - sampling start) of the input file, not by the steps actually run (BaseOutputStream.cpp:172-178)
+    want = np.sqrt(acc / int(pr["Nt"].ravel()[0]))
+    assert np.abs(g.stream("ux_rms") - want).max() < 1e-4 * want.max()
+    g.close()
+    o.close()
