@@ -894,7 +894,9 @@ __global__ __launch_bounds__(Geo<L>::THREADS, (EPI == EPI_DENSITY && L == 256) ?
   // The operands of the epilogue are requested for a group of GQ float4 per thread before the first one is used: a
   // load - use - store loop per float4 exposes one memory round trip each time (and vmcnt also waits for the stores
   // issued before the loads).  GQ is bounded by the register budget of each epilogue.
-  constexpr int GQ = (EPI == EPI_DENSITY) ? 1 : (EPI == EPI_PSUM) ? 2 : (NQ >= 4 ? 4 : NQ); // psum: 2 beats 1 (-1.4 %) although 1 gives a fourth wave
+  // measured on one box: density 1 (2 spills registers: -1 %), pressure sum 2 (1 gives a fourth wave but -1.4 %),
+  // velocity 4 (8: -1 %)
+  constexpr int GQ = (EPI == EPI_DENSITY) ? 1 : (EPI == EPI_PSUM) ? 2 : (NQ >= 4 ? 4 : NQ);
   static_assert(G::THREADS % Q4 == 0 && NQ % GQ == 0, "x is the same for every float4 of a thread");
   const uint32_t x = 4u * (threadIdx.x % Q4);
   float4 pmlx4 = make_float4(1.f, 1.f, 1.f, 1.f);
