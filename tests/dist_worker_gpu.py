@@ -22,13 +22,15 @@ def main():
     ap.add_argument("--source", default="p0")
     ap.add_argument("--mode", type=int, default=0)
     ap.add_argument("--backend", default="gloo")
+    ap.add_argument("--medium", default="111", help="heterogeneous, nonlinear, absorbing as three 0/1 digits")
     ap.add_argument("--out", required=True)
     a = ap.parse_args()
     dist.init_process_group(a.backend)
     rank, P = dist.get_rank(), dist.get_world_size()
     dev = int(os.environ.get("LOCAL_RANK", "0")) if a.backend == "nccl" else 0
     nx, ny, nz = a.dims
-    pr = synthetic.make_problem(nx, ny, nz, heterogeneous=True, nonlinear=True, absorbing=True, source=a.source,
+    het, nonlin, absorb = (c == "1" for c in a.medium)
+    pr = synthetic.make_problem(nx, ny, nz, heterogeneous=het, nonlinear=nonlin, absorbing=absorb, source=a.source,
                                 source_mode=a.mode, source_many=1, nt=a.steps, pml_size=4, sensor="random")
     loc, info = partition_problem(pr, rank, P)
     sim = DistSolver(loc, rank, P, nz, device_index=dev, p_raw=1, p_max=1)

@@ -14,12 +14,12 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 TOL = 1e-5
 
 
-def run_ranks(world, dims, steps, source, mode, tmp_path, backend="gloo"):
-    out = str(tmp_path / f"dist_{world}_{source}_{mode}_{backend}.npz")
+def run_ranks(world, dims, steps, source, mode, tmp_path, backend="gloo", medium="111"):
+    out = str(tmp_path / f"dist_{world}_{source}_{mode}_{backend}_{medium}.npz")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
            "--master-addr", "127.0.0.1", "--master-port", str(29700 + world + 10 * mode),
            os.path.join(HERE, "dist_worker_gpu.py"), "--dims", *map(str, dims), "--steps", str(steps), "--source", source,
-           "--mode", str(mode), "--backend", backend, "--out", out]
+           "--mode", str(mode), "--backend", backend, "--medium", medium, "--out", out]
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600,
                        env=dict(os.environ, OMP_NUM_THREADS="4", HSA_ENABLE_IPC_MODE_LEGACY="0"))
     assert r.returncode == 0, r.stdout[-4000:]
@@ -70,4 +70,23 @@ def test_slab_path_over_rccl_single_rank(orc, syn, tmp_path, dims, source, mode)
         assert rel_l2(res[f], o.field(f)) < TOL, f
     assert rel_l2(res["series"], np.array(series)) < TOL
     assert int(res["exchanges"][0]) > 10 * steps
+    o.close()
+
+
+@pytest.mark.parametrize("world,dims,source,mode,medium", [
+    (2, (32, 32, 32), "p0", 0, "100"),        # linear lossless: the equation of state runs inside the density kernel
+    (2, (32, 64, 32), "p_source", 1, "010"),  # homogeneous nonlinear lossless with an additive source
+    (4, (32, 32, 64), "u_source", 2, "001"),  # homogeneous linear absorbing, k-space corrected velocity source
+])
+def test_slab_ranks_other_media(orc, syn, tmp_path, world, dims, source, mode, medium):
+    steps = 16
+    res = run_ranks(world, dims, steps, source, mode, tmp_path, medium=medium)
+    nx, ny, nz = dims
+    het, nonlin, absorb = (c == "1" for c in medium)
+    pr = syn.make_problem(nx, ny, nz, heterogeneous=het, nonlinear=nonlin, absorbing=absorb, source=source,
+                          source_mode=mode, source_many=1, nt=steps, pml_size=4, sensor="random")
+    o = orc.OracleSim(pr)
+    o.step(steps)
+    for f in ("p", "ux", "uz", "rhoy"):
+        assert rel_l2(res[f], o.field(f)) < TOL, f
     o.close()
