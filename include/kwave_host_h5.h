@@ -18,6 +18,9 @@ extern "C" {
 KWH_API int kwh_create_from_file(const char* input_path, const kwh_options* options, kwh_solver** out);
 /* output file: header, scalars, one dataset per stream, p_final / u_final (KSpaceFirstOrderSolver.cpp:950-1053) */
 KWH_API int kwh_write_output_file(kwh_solver* s, const char* path);
+/* the same with the reference's -c <deflate level 0..9> (datasets are chunked as in RealMatrix.cpp:88-121 either way) and
+ * --copy_sensor_mask (KSpaceFirstOrderSolver.cpp:1036-1052: sensor_mask_index / sensor_mask_corners, 1-based) */
+KWH_API int kwh_write_output_file_ex(kwh_solver* s, const char* path, uint32_t compression_level, int32_t copy_sensor_mask);
 /* write an input file from in-memory datasets (what the MATLAB side / a generator produces); is_complex[i] != 0 marks
  * interleaved complex float data (domain_type = "complex", fastest dimension doubled: Hdf5File.cpp:898-915) */
 KWH_API int kwh_write_input_file(const char* path, const kwh_dataset* datasets, size_t n, const int32_t* is_complex);

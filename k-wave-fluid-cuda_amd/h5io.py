@@ -40,6 +40,7 @@ def load_h5() -> C.CDLL:
                                           C.POINTER(C.c_int32)]
         L.kwh_h5_read.argtypes = [C.c_char_p, C.c_char_p, C.c_void_p, C.c_uint64, C.c_int32]
         L.kwh_h5_read_attribute.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_uint64]
+        L.kwh_write_output_file_ex.argtypes = [C.c_void_p, C.c_char_p, C.c_uint32, C.c_int32]
         L.kwh_checkpoint_write.argtypes = [C.c_void_p, C.c_char_p]
         L.kwh_checkpoint_read.argtypes = [C.c_void_p, C.c_char_p]
         _h5 = L
@@ -128,8 +129,8 @@ class FileSolver(HostSolver):
         for fn in ("kwh_destroy", "kwh_finish", "kwh_sync"):
             getattr(L, fn).argtypes = [C.c_void_p]
 
-    def write_output(self, path: str):
-        _h5check(self.L.kwh_write_output_file(self._h, path.encode()))
+    def write_output(self, path: str, compression_level: int = 0, copy_sensor_mask: bool = False):
+        _h5check(self.L.kwh_write_output_file_ex(self._h, path.encode(), compression_level, int(copy_sensor_mask)))
 
     def write_checkpoint(self, path: str):
         """State arrays, time index and stream states -> checkpoint file (KSpaceFirstOrderSolver.cpp:1176-1224)."""

@@ -90,27 +90,54 @@ void Hdf5File::readCompleteDataset(const std::string& name, size_t nElements, si
   if (nElements == 0) return;
   if (H5LTread_dataset(mFile, name.c_str(), H5T_NATIVE_UINT64, data) < 0) fail("Error: cannot read dataset \"" + name + "\"");
 }
+// Chunking of output datasets as the reference lays them out: one z-plane per chunk for 2-D / 3-D data, 256 KiB - 4 MiB
+// pieces for long 1-D data (RealMatrix.cpp:88-110), deflate at the requested level (Hdf5File.cpp:330-350).
+static DimensionSizes chunkSizes(const DimensionSizes& d)
+{
+  DimensionSizes c = d;
+  c.nz = 1;
+  if (d.ny == 1 && d.nz == 1)
+  {
+    constexpr size_t k4MB = 1048576, k1MB = 262144, k256kB = 65536;
+    if (d.nx > 4 * k4MB) c.nx = k4MB;
+    else if (d.nx > 4 * k1MB) c.nx = k1MB;
+    else if (d.nx > 4 * k256kB) c.nx = k256kB;
+  }
+  return c;
+}
+
 static void writeDataset(hid_t file, const std::string& name, const DimensionSizes& d, hid_t fileType, hid_t memType,
-                         const void* data)
+                         const void* data, bool chunked = false, unsigned compressionLevel = 0)
 {
   hsize_t dims[3] = {d.nz, d.ny, d.nx};
   hid_t space = H5Screate_simple(3, dims, nullptr);
-  hid_t set   = H5Dcreate2(file, name.c_str(), fileType, space, H5P_DEFAULT, H5P_DEFAULT, H5P_DEFAULT);
+  hid_t plist = H5P_DEFAULT;
+  if (chunked && d.nElements() > 0)
+  {
+    const DimensionSizes c = chunkSizes(d);
+    hsize_t cdims[3] = {c.nz, c.ny, c.nx};
+    plist = H5Pcreate(H5P_DATASET_CREATE);
+    H5Pset_chunk(plist, 3, cdims);
+    if (compressionLevel > 0) H5Pset_deflate(plist, compressionLevel);
+  }
+  hid_t set   = H5Dcreate2(file, name.c_str(), fileType, space, H5P_DEFAULT, plist, H5P_DEFAULT);
   herr_t st   = -1;
   if (set >= 0) st = (d.nx * d.ny * d.nz == 0) ? 0 : H5Dwrite(set, memType, H5S_ALL, H5S_ALL, H5P_DEFAULT, data);
   if (set >= 0) H5Dclose(set);
+  if (plist != H5P_DEFAULT) H5Pclose(plist);
   H5Sclose(space);
   if (set < 0 || st < 0) throw std::ios_base::failure("Error: cannot write dataset \"" + name + "\"");
 }
 void Hdf5File::writeMatrix(const std::string& name, const DimensionSizes& dims, const float* data, MatrixDomainType domain)
 {
-  writeDataset(mFile, name, dims, H5T_IEEE_F32LE, H5T_NATIVE_FLOAT, data);
+  writeDataset(mFile, name, dims, H5T_IEEE_F32LE, H5T_NATIVE_FLOAT, data, mChunkedOutput, mCompressionLevel);
   writeStringAttribute(name, kMatrixDataTypeName, kDataNames[0]);
   writeStringAttribute(name, kMatrixDomainTypeName, kDomainNames[static_cast<int>(domain)]);
 }
 void Hdf5File::writeMatrix(const std::string& name, const DimensionSizes& dims, const size_t* data)
 {
-  writeDataset(mFile, name, dims, H5T_STD_U64LE, H5T_NATIVE_UINT64, data);
+  writeDataset(mFile, name, dims, H5T_STD_U64LE, H5T_NATIVE_UINT64, data, mChunkedOutput && dims.nElements() > 1,
+               mCompressionLevel);
   writeStringAttribute(name, kMatrixDataTypeName, kDataNames[1]);
   writeStringAttribute(name, kMatrixDomainTypeName, kDomainNames[0]);
 }

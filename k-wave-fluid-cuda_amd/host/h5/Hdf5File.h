@@ -48,10 +48,15 @@ class Hdf5File
   /// root header attributes (Hdf5FileHeader.cpp:126-149 write, :155-200 read/check)
   void writeHeader(const std::string& fileType, const std::string& description);
   std::string readFileType() const { return readStringAttribute("/", "file_type"); }
+  /// datasets written from now on are chunked like the reference's output (RealMatrix.cpp:88-121) and deflated at
+  /// `compressionLevel` (0-9; the reference's -c, default 0)
+  void setOutputLayout(bool chunked, unsigned compressionLevel) { mChunkedOutput = chunked; mCompressionLevel = compressionLevel; }
 
  private:
   hid_t mFile = -1;
   std::string mName;
+  bool     mChunkedOutput    = false;
+  unsigned mCompressionLevel = 0;
 };
 
 /// InputProvider backed by an HDF5 input file (what Parameters::readScalarsFromInputFile and the matrices read)

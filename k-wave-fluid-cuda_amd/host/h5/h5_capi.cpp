@@ -17,11 +17,12 @@
   catch (...) { kwh_set_error("unknown exception"); return 1; }                                                        \
   return 0;
 
-void kwh_write_output(kwh_solver* s, const std::string& path)
+void kwh_write_output(kwh_solver* s, const std::string& path, unsigned compressionLevel, bool copySensorMask)
 {
   const Parameters& params = Parameters::getInstance();
   Hdf5File out;
   out.create(path);
+  out.setOutputLayout(true, compressionLevel); // chunked like the reference's output; -c N deflate level
   out.writeHeader("output", "k-Wave output written by kspaceFirstOrder-HIP");
   const DimensionSizes dims = params.getGlobalDimensionSizes();
   out.writeScalarValue(kNxName, dims.nx);
@@ -63,8 +64,23 @@ void kwh_write_output(kwh_solver* s, const std::string& path)
     writeFinal(MI::kUySgy, kUyFinalName);
     if (params.isSimulation3D()) writeFinal(MI::kUzSgz, kUzFinalName);
   }
+  if (copySensorMask)
+  { // --copy_sensor_mask (KSpaceFirstOrderSolver.cpp:1036-1052): the mask goes to the output file, 1-based again
+    using MI = MatrixContainer::MatrixIdx;
+    MatrixContainer& mc = s->solver->getMatrixContainer();
+    const MI   idx  = (params.getSensorMaskType() == Parameters::SensorMaskType::kIndex) ? MI::kSensorMaskIndex : MI::kSensorMaskCorners;
+    const char* name = (idx == MI::kSensorMaskIndex) ? "sensor_mask_index" : "sensor_mask_corners";
+    if (mc.has(idx))
+    {
+      IndexMatrix& m = mc.getMatrix<IndexMatrix>(idx);
+      std::vector<size_t> oneBased(m.getHostData(), m.getHostData() + m.size());
+      for (size_t& v : oneBased) v += 1;
+      out.writeMatrix(name, m.getDimensionSizes(), oneBased.data());
+    }
+  }
   out.close();
 }
+void kwh_write_output(kwh_solver* s, const std::string& path) { kwh_write_output(s, path, 0, false); }
 
 // ---- checkpoint file (KSpaceFirstOrderSolver.cpp:1176-1224 write, :186-228 + :1124-1169 read / check) --------------
 // Root datasets: the seven state arrays under their matrix names (MatrixContainer.cpp:504-537), t_index, Nx, Ny, Nz;
@@ -214,6 +230,15 @@ KWH_API int kwh_h5_read_attribute(const char* path, const char* dataset, const c
   const std::string v = f.readStringAttribute(dataset, attr);
   std::strncpy(out, v.c_str(), cap);
   if (cap) out[cap - 1] = 0;
+  KWH_CATCH
+}
+
+KWH_API int kwh_write_output_file_ex(kwh_solver* s, const char* path, uint32_t compression_level, int32_t copy_sensor_mask)
+{
+  KWH_TRY
+  if (!s || !path) throw std::invalid_argument("kwh_write_output_file_ex: NULL argument");
+  if (compression_level > 9) throw std::invalid_argument("compression level must be 0..9");
+  kwh_write_output(s, path, compression_level, copy_sensor_mask != 0);
   KWH_CATCH
 }
 

@@ -10,7 +10,7 @@
 #include "../HostSolverHandle.h"
 #include "Hdf5File.h"
 
-void kwh_write_output(kwh_solver* s, const std::string& path);
+void kwh_write_output(kwh_solver* s, const std::string& path, unsigned compressionLevel, bool copySensorMask);
 void kwh_checkpoint_write_impl(kwh_solver* s, const std::string& path);
 void kwh_checkpoint_read_impl(kwh_solver* s, const std::string& path);
 
@@ -20,6 +20,7 @@ static void usage()
               "  [-p|--p_raw] [--p_rms] [--p_max] [--p_min] [--p_max_all] [--p_min_all] [--p_final]\n"
               "  [-u|--u_raw] [--u_rms] [--u_max] [--u_min] [--u_max_all] [--u_min_all] [--u_final] [--u_non_staggered_raw]\n"
               "  [--p_c] [--u_non_staggered_c] [--I_avg_c] [--period P] [--mos M] [--harmonics H] [--no_overlap] [--granular]\n"
+              "  [-c <deflate 0..9>] [--copy_sensor_mask]\n"
               "  [--checkpoint_file <ckpt.h5> --checkpoint_timesteps N]  stop after N steps, leaving a checkpoint; the\n"
               "      same command line resumes from it (CommandLineParameters.cpp:264-292)\n");
 }
@@ -28,6 +29,8 @@ int main(int argc, char** argv)
 {
   std::string in, out, ckpt;
   size_t ckptSteps = 0;
+  unsigned compressionLevel = 0; // -c (CommandLineParameters.h:791: default 0)
+  bool copySensorMask = false;
   kwh_options o{};
   o.device_idx    = -1;
   o.fused_kernels = 1;
@@ -64,6 +67,8 @@ int main(int argc, char** argv)
     else if (a == "--harmonics") o.harmonics = std::strtoull(next(), nullptr, 10);
     else if (a == "--no_overlap") o.no_overlap = 1;
     else if (a == "--granular") o.fused_kernels = 0;
+    else if (a == "-c") compressionLevel = static_cast<unsigned>(std::strtoul(next(), nullptr, 10));
+    else if (a == "--copy_sensor_mask") copySensorMask = true;
     else if (a == "--checkpoint_file") ckpt = next();
     else if (a == "--checkpoint_timesteps") ckptSteps = std::strtoull(next(), nullptr, 10);
     else if (a == "-h" || a == "--help") { usage(); return EXIT_SUCCESS; }
@@ -105,7 +110,7 @@ int main(int argc, char** argv)
       s.solver->compute();
     }
     kwCheck(kw_sync(params.getHipParameters().getContext()));
-    kwh_write_output(&s, out);
+    kwh_write_output(&s, out, compressionLevel, copySensorMask);
     std::printf("time steps: %zu, output: %s\n", params.getTimeIndex(), out.c_str());
     s.solver.reset();
   }

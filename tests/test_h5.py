@@ -103,3 +103,35 @@ def test_command_line_program(h5io, syn, tmp_path):
     r = subprocess.run([exe, "-i", str(tmp_path / "missing.h5"), "-o", path_out], stdout=subprocess.PIPE,
                        stderr=subprocess.STDOUT, text=True, timeout=60)
     assert r.returncode != 0 and "Error" in r.stdout
+
+
+@pytest.mark.gpu
+def test_output_compression_level_and_copied_sensor_mask(h5io, syn, tmp_path):
+    """-c <level> and --copy_sensor_mask (KSpaceFirstOrderSolver.cpp:1036-1052): same data, smaller file, mask 1-based"""
+    import kwave_amd  # noqa: F401
+    from kwave_amd import capi
+    pr = syn.make_problem(32, heterogeneous=True, nonlinear=False, absorbing=False, source="p0", nt=12, pml_size=4,
+                          sensor="random")
+    path_in = str(tmp_path / "in.h5")
+    h5io.write_input_file(pr, path_in)
+    fs = h5io.FileSolver(path_in, p_raw=1, p_final=1, p_max_all=1)
+    fs.run(12)
+    fs.finish()
+    plain, packed = str(tmp_path / "plain.h5"), str(tmp_path / "packed.h5")
+    fs.write_output(plain)
+    fs.write_output(packed, compression_level=6, copy_sensor_mask=True)
+    fs.close()
+    for name in ("p", "p_final", "p_max_all", "t_index"):
+        assert np.array_equal(h5io.read_dataset(plain, name), h5io.read_dataset(packed, name)), name
+    assert os.path.getsize(packed) < os.path.getsize(plain)
+    assert np.array_equal(h5io.read_dataset(packed, "sensor_mask_index").ravel(), pr["sensor_mask_index"].ravel())
+    with pytest.raises(capi.KWaveError):
+        h5io.read_dataset(plain, "sensor_mask_index")
+    # the command line spells them -c / --copy_sensor_mask
+    exe = os.path.join(capi.PKG, "lib", "kspaceFirstOrder-HIP")
+    cli = str(tmp_path / "cli.h5")
+    r = subprocess.run([exe, "-i", path_in, "-o", cli, "--p_raw", "--p_final", "--p_max_all", "-c", "6", "--copy_sensor_mask"],
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout
+    assert np.array_equal(h5io.read_dataset(cli, "p"), h5io.read_dataset(plain, "p"))
+    assert np.array_equal(h5io.read_dataset(cli, "sensor_mask_index").ravel(), pr["sensor_mask_index"].ravel())
