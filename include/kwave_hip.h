@@ -105,6 +105,14 @@ KW_API kw_status   kw_device_info_get(kw_ctx* ctx, kw_device_info* out);
 KW_API kw_status   kw_set_stream(kw_ctx* ctx, void* hip_stream);
 KW_API void*       kw_get_stream(kw_ctx* ctx);
 KW_API kw_status   kw_sync(kw_ctx* ctx);
+/* Launch-bound loops (small grids): record the launches of a fixed sequence of kw_* calls once, replay it per step.
+ * kw_graph_begin puts the context's stream into capture mode (nothing executes until the graph is launched);
+ * every kw_* call in between must be a pure kernel-launch call (no allocation, copy or synchronisation). */
+typedef struct kw_graph kw_graph;
+KW_API kw_status   kw_graph_begin(kw_ctx* ctx);
+KW_API kw_status   kw_graph_end(kw_ctx* ctx, kw_graph** out);
+KW_API kw_status   kw_graph_launch(kw_ctx* ctx, kw_graph* g);
+KW_API kw_status   kw_graph_destroy(kw_ctx* ctx, kw_graph* g);
 /* HIP events on the context's stream (bench.py times kernels with these) */
 KW_API kw_status   kw_event_create(kw_ctx* ctx, void** out_event);
 KW_API kw_status   kw_event_record(kw_ctx* ctx, void* event);
@@ -121,6 +129,7 @@ typedef struct kw_profile_entry
   double   total_ms;
 } kw_profile_entry;
 KW_API kw_status kw_profile_enable(kw_ctx* ctx, int on);
+KW_API int       kw_profile_enabled(kw_ctx* ctx); /* 1 while per-call timing is on (recorded graphs would bypass it) */
 /* synchronises, aggregates by entry-point name, clears the recorded events; *n_out = number of entries written */
 KW_API kw_status kw_profile_collect(kw_ctx* ctx, kw_profile_entry* out, size_t capacity, size_t* n_out);
 

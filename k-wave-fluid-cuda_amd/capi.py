@@ -72,12 +72,17 @@ _SIG: Dict[str, list] = {
     "kw_device_info_get": [_P, C.POINTER(DeviceInfo)],
     "kw_set_stream": [_P, _P],
     "kw_sync": [_P],
+    "kw_graph_begin": [_P],
+    "kw_graph_end": [_P, _P],
+    "kw_graph_launch": [_P, _P],
+    "kw_graph_destroy": [_P, _P],
     "kw_event_create": [_P, C.POINTER(_P)],
     "kw_event_record": [_P, _P],
     "kw_event_synchronize": [_P, _P],
     "kw_event_elapsed_ms": [_P, _P, _P, C.POINTER(C.c_float)],
     "kw_event_destroy": [_P, _P],
     "kw_profile_enable": [_P, C.c_int],
+    "kw_profile_enabled": [_P],
     "kw_profile_collect": [_P, _P, C.c_size_t, C.POINTER(C.c_size_t)],
     "kw_malloc": [_P, C.c_size_t, C.POINTER(_P)],
     "kw_free": [_P, _P],

@@ -131,6 +131,59 @@ kw_status kw_set_stream(kw_ctx* ctx, void* hip_stream)
 
 void* kw_get_stream(kw_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
 
+struct kw_graph
+{
+  hipGraph_t     graph = nullptr;
+  hipGraphExec_t exec  = nullptr;
+};
+
+kw_status kw_graph_begin(kw_ctx* ctx)
+{
+  KW_CHECK_CTX(ctx);
+  if (ctx->profiling) { kw_set_error("kw_graph_begin: not while per-call profiling is enabled"); return KW_ERR_STATE; }
+  KW_HIP(hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
+  return KW_OK;
+}
+
+kw_status kw_graph_end(kw_ctx* ctx, kw_graph** out)
+{
+  KW_CHECK_CTX(ctx);
+  KW_REQUIRE(out != nullptr);
+  *out = nullptr;
+  hipGraph_t g = nullptr;
+  KW_HIP(hipStreamEndCapture(ctx->stream, &g));
+  kw_graph* kg = new kw_graph();
+  kg->graph    = g;
+  const hipError_t e = hipGraphInstantiate(&kg->exec, g, nullptr, nullptr, 0);
+  if (e != hipSuccess)
+  {
+    (void)hipGraphDestroy(g);
+    delete kg;
+    kw_set_error("kw_graph_end: hipGraphInstantiate: %s", hipGetErrorString(e));
+    return KW_ERR_HIP;
+  }
+  *out = kg;
+  return KW_OK;
+}
+
+kw_status kw_graph_launch(kw_ctx* ctx, kw_graph* g)
+{
+  KW_CHECK_CTX(ctx);
+  KW_REQUIRE(g != nullptr && g->exec != nullptr);
+  KW_HIP(hipGraphLaunch(g->exec, ctx->stream));
+  return KW_OK;
+}
+
+kw_status kw_graph_destroy(kw_ctx* ctx, kw_graph* g)
+{
+  KW_CHECK_CTX(ctx);
+  if (g == nullptr) return KW_OK;
+  if (g->exec) (void)hipGraphExecDestroy(g->exec);
+  if (g->graph) (void)hipGraphDestroy(g->graph);
+  delete g;
+  return KW_OK;
+}
+
 kw_status kw_sync(kw_ctx* ctx)
 {
   KW_CHECK_CTX(ctx);
@@ -174,6 +227,8 @@ kw_status kw_event_destroy(kw_ctx* ctx, void* event)
 }
 
 // ---- profiling -----------------------------------------------------------------------------------------------------
+int kw_profile_enabled(kw_ctx* ctx) { return (ctx != nullptr && ctx->profiling) ? 1 : 0; }
+
 kw_status kw_profile_enable(kw_ctx* ctx, int on)
 {
   KW_CHECK_CTX(ctx);

@@ -90,6 +90,10 @@ class KSpaceFirstOrderSolver
   bool                  mVelocityChained = false; // x-spectra of u handed over by the velocity stage this step
   bool mPressureFused = false;     // lossless: p of this step already produced by the density stage
   bool mPressureInScratch = false; // the spectrum of p is still in the pipeline scratch (chained by the pressure sum)
+  // launch-bound grids: the kernel launches of one steady-state step (no source active, p's spectrum chained from the
+  // previous step) are recorded once and replayed (kw_graph_*)
+  kw_graph*             mStepGraph = nullptr;
+  bool                  mUseStepGraph = false, mStepGraphFailed = false;
   float*                mKappaPadded = nullptr;
   float*                mNabla1Padded = nullptr;
   float*                mNabla2Padded = nullptr;
