@@ -68,7 +68,8 @@ KWH_API void*    kwh_context(kwh_solver* s);
  * from the device into dst; n = number of floats expected (checked) */
 KWH_API int      kwh_get_matrix(kwh_solver* s, const char* name, float* dst, uint64_t n);
 KWH_API int      kwh_matrix_size(kwh_solver* s, const char* name, uint64_t* n_floats);
-/* scalar parameters computed by pre-processing: "absorb_tau","absorb_eta","c2","dt_rho0_sgx",... */
+/* scalar parameters computed by pre-processing: "absorb_tau","absorb_eta","c2","dt_rho0_sgx",...;
+ * "fused_pipeline" = 1 when the grid runs on the hand-written FFT pipeline, 0 on the rocFFT path */
 KWH_API int      kwh_get_scalar(kwh_solver* s, const char* name, float* out);
 /* output streams by dataset name ("p","p_max","ux",...): size = points per step, steps = stored steps (1 for aggregates) */
 KWH_API int      kwh_stream_info(kwh_solver* s, const char* name, uint64_t* size, uint64_t* steps);

@@ -29,10 +29,13 @@ using namespace kwfft;
 namespace {
 
 constexpr int NLMAX = 16; // widest tile: 16 complex = 128-B segments (also the row-pitch granule)
-// lines per tile: 16 up to L = 256; 8 for L = 512, whose 32-point register DFT needs the VGPR budget of a 256-thread block
-constexpr int nl_of(int L) { return L >= 512 ? 8 : 16; }
+// lines per tile: 16 up to L = 256; 8 for L = 384 / 512, whose 24- / 32-point register DFTs need the VGPR budget of a
+// small block
+constexpr int nl_of(int L) { return L >= 384 ? 8 : 16; }
 
 constexpr int cmax(int a, int b) { return a > b ? a : b; }
+// largest divisor of n that is <= want
+constexpr int gq_pick(int n, int want) { return (n % want == 0) ? want : gq_pick(n, want - 1); }
 
 template<int L> struct Geo
 {
@@ -699,7 +702,7 @@ __device__ __forceinline__ void xfwd_tail(float2 (&v)[Fac<L>::R1], float2* lds, 
     const int    cc = e / HALF;
     const int    k  = e - cc * HALF;
     const float2 zk = lds[cc * G::ZP + k];
-    const float2 zn = lds[cc * G::ZP + ((L - k) & (L - 1))];
+    const float2 zn = lds[cc * G::ZP + (k == 0 ? 0 : L - k)];
     const float2 xa = make_float2(0.5f * (zk.x + zn.x), 0.5f * (zk.y - zn.y));
     const float2 xb = make_float2(0.5f * (zk.y + zn.y), 0.5f * (zn.x - zk.x));
     const uint32_t r = tile_row0 + 2 * cc;
@@ -896,18 +899,20 @@ __global__ __launch_bounds__(Geo<L>::THREADS, (EPI == EPI_DENSITY && L == 256) ?
   // issued before the loads).  GQ is bounded by the register budget of each epilogue.
   // measured on one box: density 1 (2 spills registers: -1 %), pressure sum 2 (1 gives a fourth wave but -1.4 %),
   // velocity 4 (8: -1 %)
-  constexpr int GQ = (EPI == EPI_DENSITY) ? 1 : (EPI == EPI_PSUM) ? 2 : (NQ >= 4 ? 4 : NQ);
-  static_assert(G::THREADS % Q4 == 0 && NQ % GQ == 0, "x is the same for every float4 of a thread");
-  const uint32_t x = 4u * (threadIdx.x % Q4);
+  constexpr int GQ = gq_pick(NQ, (EPI == EPI_DENSITY) ? 1 : (EPI == EPI_PSUM) ? 2 : 4);
+  // power-of-two rows: x is the same for every float4 of a thread (one PML-x load per thread); the 3 * 2^m rows whose
+  // float4 count does not divide the block take x (and the PML-x operand) per float4
+  constexpr bool XFIX = (G::THREADS % Q4 == 0);
+  const uint32_t xfix = 4u * (threadIdx.x % Q4);
   float4 pmlx4 = make_float4(1.f, 1.f, 1.f, 1.f);
-  if ((EPI == EPI_VELOCITY && comp == 0) || EPI == EPI_DENSITY) pmlx4 = ld4(a.m1[0] + x);
+  if (XFIX && ((EPI == EPI_VELOCITY && comp == 0) || EPI == EPI_DENSITY)) pmlx4 = ld4(a.m1[0] + xfix);
   const bool hetRho0 = (EPI == EPI_DENSITY) && (a.m0[0] != nullptr);
   const bool hetBonA = (EPI == EPI_DENSITY) && (terms == 2 || (terms == 3 && a.nonlinear)) && (a.m0[1] != nullptr);
   const bool hetC2   = (EPI == EPI_DENSITY) && (terms == 3) && (a.m0[2] != nullptr);
 #pragma unroll
   for (int q0 = 0; q0 < NQ; q0 += GQ)
   {
-    float4 op0[GQ], op1[GQ], op2[GQ], op3[GQ], op4[GQ], op5[GQ];
+    float4 op0[GQ], op1[GQ], op2[GQ], op3[GQ], op4[GQ], op5[GQ], opx[GQ];
     float  sy[GQ], sz[GQ];
 #pragma unroll
     for (int g = 0; g < GQ; g++)
@@ -916,7 +921,9 @@ __global__ __launch_bounds__(Geo<L>::THREADS, (EPI == EPI_DENSITY && L == 256) ?
       const uint32_t r   = tile_row0 + e / Q4;
       const uint32_t z   = r / k.ny;
       const uint32_t y   = r - z * k.ny;
+      const uint32_t x   = XFIX ? xfix : 4u * (e % Q4);
       const uint32_t i   = r * L + x;
+      if (!XFIX && ((EPI == EPI_VELOCITY && comp == 0) || EPI == EPI_DENSITY)) opx[g] = ld4(a.m1[0] + x);
       if (EPI == EPI_VELOCITY)
       {
         op0[g] = ld4(a.out[comp] + i);
@@ -953,7 +960,9 @@ __global__ __launch_bounds__(Geo<L>::THREADS, (EPI == EPI_DENSITY && L == 256) ?
       const int      q = q0 + g;
       const int      e = threadIdx.x + q * G::THREADS;
       const uint32_t r = tile_row0 + e / Q4;
+      const uint32_t x = XFIX ? xfix : 4u * (e % Q4);
       const uint32_t i = r * L + x;
+      const float4   pmx = XFIX ? pmlx4 : opx[g];
       if (EPI == EPI_STORE)
       {
         st4(a.out[comp] + i, res[0][q]);
@@ -962,7 +971,7 @@ __global__ __launch_bounds__(Geo<L>::THREADS, (EPI == EPI_DENSITY && L == 256) ?
       { // SolverCudaKernels.cu:199-212 (heterogeneous) / :287-305 (homogeneous)
         float4       vu   = op0[g];
         const float4 gr   = res[0][q];
-        const float4 pml4 = (comp == 0) ? pmlx4 : make_float4(sy[g], sy[g], sy[g], sy[g]);
+        const float4 pml4 = (comp == 0) ? pmx : make_float4(sy[g], sy[g], sy[g], sy[g]);
         if (a.m0[comp] != nullptr)
         {
           const float4 d = op1[g];
@@ -1016,7 +1025,7 @@ __global__ __launch_bounds__(Geo<L>::THREADS, (EPI == EPI_DENSITY && L == 256) ?
 #pragma unroll
         for (int t = 0; t < 4; t++)
         {
-          const float px = f4get(pmlx4, t);
+          const float px = f4get(pmx, t);
           const float r0 = f4get(r04, t);
           const float erx = f4get(rx, t), ery = f4get(ry, t), erz = f4get(rz, t);
           if (a.nonlinear)
@@ -1269,18 +1278,23 @@ template<int L> __global__ __launch_bounds__(Geo<L>::THREADS) void k_probe_xinv(
 }
 
 // ---- host side ------------------------------------------------------------------------------------------------------
-bool supported_len(uint32_t n) { return n == 16 || n == 32 || n == 64 || n == 128 || n == 256 || n == 512; }
+// line lengths with a two-factor register decomposition: 2^m, 3 * 2^m, 9 * 2^m, 5 * 2^m, 15 * 2^m
+#define KW_FUSED_LENGTHS(X) X(16) X(32) X(48) X(64) X(72) X(80) X(96) X(120) X(128) X(144) X(160) X(192) X(240) X(256) \
+  X(288) X(320) X(384) X(480) X(512) X(576) X(640)
+bool supported_len(uint32_t n)
+{
+#define X(LEN) if (n == LEN) return true;
+  KW_FUSED_LENGTHS(X)
+#undef X
+  return false;
+}
 
-// dispatch on a runtime power-of-two length
+// dispatch on a runtime line length; the call sites define the per-length launch macro under the name M
+#define KW_LEN_CASE(LEN) case LEN: M(LEN); break;
 #define KW_LEN_SWITCH(len, MACRO)                                                                                      \
   switch (len)                                                                                                         \
   {                                                                                                                    \
-    case 16: MACRO(16); break;                                                                                         \
-    case 32: MACRO(32); break;                                                                                         \
-    case 64: MACRO(64); break;                                                                                         \
-    case 128: MACRO(128); break;                                                                                       \
-    case 256: MACRO(256); break;                                                                                       \
-    case 512: MACRO(512); break;                                                                                       \
+    KW_FUSED_LENGTHS(KW_LEN_CASE)                                                                                      \
     default: kw_set_error("fused pipeline: unsupported length %u", (unsigned)(len)); return KW_ERR_INVALID;            \
   }
 
@@ -1657,7 +1671,11 @@ kw_status kw_fused_supported(kw_ctx* ctx, int* out)
   const auto& f         = ctx->fused;
   const uint32_t nzg    = (f.slab) ? f.nz_global : c.nz;
   bool ok = supported_len(c.nx) && supported_len(c.ny) && supported_len(nzg) && ((c.ny * c.nz) % (2 * NLMAX) == 0);
-  if (f.slab) ok = ok && (nzg == c.nz * f.nranks) && (c.ny % f.nranks == 0);
+  if (f.slab)
+  { // the packed (exchange-side) row addressing splits ky with a shift and a mask: power-of-two ky chunk per rank
+    const uint32_t nyl = c.ny / f.nranks;
+    ok = ok && (nzg == c.nz * f.nranks) && (c.ny % f.nranks == 0) && ((nyl & (nyl - 1u)) == 0);
+  }
   const uint64_t P64 = (c.nx_complex + NLMAX - 1) / NLMAX * NLMAX;
   ok = ok && (P64 * c.ny * c.nz < (1ull << 32)) && (static_cast<uint64_t>(c.nx) * c.ny * c.nz < (1ull << 32));
   *out = ok ? 1 : 0;

@@ -33,6 +33,8 @@ class KSpaceFirstOrderSolver
 
   MatrixContainer&       getMatrixContainer() { return mMatrixContainer; }
   OutputStreamContainer& getOutputStreamContainer() { return mOutputStreamContainer; }
+  /// true once prepare() has chosen the hand-written FFT pipeline for this grid (false: rocFFT + one kernel per stage)
+  bool usesFusedPipeline() const { return mFused; }
   /// "kspaceFirstOrder-HIP" code name (reference: getCodeName, KSpaceFirstOrderSolver.h)
   std::string getCodeName() const { return "kspaceFirstOrder-HIP v0.1 (gfx950)"; }
 

@@ -162,12 +162,17 @@ int kwh_get_matrix(kwh_solver* s, const char* name, float* dst, uint64_t n)
   KWH_CATCH
 }
 
-int kwh_get_scalar(kwh_solver*, const char* name, float* out)
+int kwh_get_scalar(kwh_solver* s, const char* name, float* out)
 {
   KWH_TRY
   const Parameters& p = Parameters::getInstance();
   const std::string n(name);
-  if (n == "absorb_tau") *out = p.getAbsorbTauScalar();
+  if (n == "fused_pipeline")
+  {
+    if (!s) throw std::invalid_argument("kwh_get_scalar: NULL solver");
+    *out = s->solver->usesFusedPipeline() ? 1.f : 0.f;
+  }
+  else if (n == "absorb_tau") *out = p.getAbsorbTauScalar();
   else if (n == "absorb_eta") *out = p.getAbsorbEtaScalar();
   else if (n == "c2") *out = p.getC2Scalar();
   else if (n == "dt_rho0_sgx") *out = p.getDtRho0SgxScalar();

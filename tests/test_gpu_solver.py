@@ -118,6 +118,30 @@ def test_fused_line_length_512(orc, syn, dims):
     assert max(errs.values()) < TOL, (dims, errs)
 
 
+@pytest.mark.parametrize("dims", [
+    (48, 16, 32), (96, 48, 16), (16, 96, 48), (192, 16, 16), (16, 192, 32), (32, 16, 192), (384, 16, 16), (16, 384, 16),
+    (16, 16, 384), (48, 48, 48),                                                          # 3 * 2^m
+    (72, 144, 16), (144, 16, 72), (16, 72, 144), (288, 16, 16), (16, 288, 16), (16, 16, 288), (576, 16, 16),
+    (16, 576, 16), (16, 16, 576),                                                         # 9 * 2^m
+    (80, 160, 16), (160, 16, 80), (16, 80, 160), (320, 16, 16), (16, 320, 16), (16, 16, 320), (640, 16, 16),
+    (16, 640, 16), (16, 16, 640),                                                         # 5 * 2^m
+    (120, 240, 16), (240, 16, 120), (16, 120, 240), (480, 16, 16), (16, 480, 16), (16, 16, 480),  # 15 * 2^m
+])
+def test_fused_line_lengths_mixed_radix(orc, syn, dims):
+    """Line lengths with one radix-3 or radix-5 stage (or two radix-3) inside the register DFTs: every supported
+    length along every axis."""
+    for kw in (dict(nonlinear=True, absorbing=True), dict(nonlinear=False, absorbing=False)):
+        pr = syn.make_problem(*dims, heterogeneous=True, source="p0", pml_size=4, **kw)
+        g, o = make_gpu(pr, fused_kernels=True), orc.OracleSim(pr)
+        g.run(20)
+        assert g.scalar("fused_pipeline") == 1.0
+        o.step(20)
+        errs = {f: rel_l2(g.field(f), o.field(f)) for f in ("p", "ux", "uy", "uz", "rhox", "rhoz")}
+        g.close()
+        o.close()
+        assert max(errs.values()) < TOL, (dims, kw, errs)
+
+
 def test_transducer_source(orc, syn):
     pr = syn.make_problem(24, heterogeneous=True, nonlinear=True, absorbing=True, source="transducer", nt=40,
                           pml_size=4)
