@@ -386,6 +386,16 @@ KW_API kw_status kw_intensity_avg_c_accumulate(kw_ctx* ctx, float* iavg, const f
                                                uint64_t n_samples, uint32_t harmonics);
 /* buf[i] /= divisor — final division of I_avg_c by the frame count (IndexOutputStream.cpp:482-490) */
 KW_API kw_status kw_divide(kw_ctx* ctx, float* buf, float divisor, uint64_t n);
+/* ---- post-processing of stored series (KSpaceFirstOrderSolver.cpp:1231-1534 computeAverageIntensities, :1783-2080
+ * computeQTerm).  The reference moves every spectrum to the host for the multiply; here the series stay on the device.
+ * kw_time_shift_series: series[step][i] (device, steps x n, in place) is advanced by half a time step through its
+ *   spectrum along the step axis: X[k] *= (1/steps) * shift[k], k = 0..steps/2 (:1437-1449); shift = device array of
+ *   steps/2+1 complex values exp(i*pi*s(k)/steps) computed by the caller (:1253-1260).
+ * kw_intensity_avg: iavg[i] = (sum over steps, in step order, of u[step][i]*p[step][i]) / steps (:1492-1513).
+ * kw_q_term_sum: out[i] = -(a[i] + b[i] + c[i]) over the grid, c may be NULL in 2-D (:2014-2026). */
+KW_API kw_status kw_time_shift_series(kw_ctx* ctx, float* series, const float* shift, uint64_t steps, uint64_t n);
+KW_API kw_status kw_intensity_avg(kw_ctx* ctx, float* iavg, const float* p, const float* u, uint64_t steps, uint64_t n);
+KW_API kw_status kw_q_term_sum(kw_ctx* ctx, float* out, const float* a, const float* b, const float* c, uint64_t n);
 /* postProcessingRms (.cuh:103-105, .cu:359-378) */
 KW_API kw_status kw_post_processing_rms(kw_ctx* ctx, float* sampling_buffer, float scaling_coeff, uint64_t n_samples);
 

@@ -53,6 +53,9 @@ typedef struct kwh_options
   void*    exchange_start_fn; /* optional kw_exchange_start_fn / kw_exchange_wait_fn pair (both or neither) */
   void*    exchange_wait_fn;
   void*    scratch[6]; /* optional caller-owned pipeline scratch (kw_fused_create_with_scratch), else all NULL */
+  /* post-processed quantities (--I_avg, --Q_term, --Q_term_c; KSpaceFirstOrderSolver.cpp:977-1024): time-averaged
+   * intensity from the stored p / u_non_staggered series, and Q = -div(I_avg) from it or from the compressed one */
+  int32_t  i_avg, q_term, q_term_c, reserved_;
 } kwh_options;
 
 KWH_API const char* kwh_last_error(void);

@@ -148,6 +148,9 @@ _SIG: Dict[str, list] = {
     "kw_post_processing_rms": [_P, _P, C.c_float, _U64],
     "kw_sample_index_compress": [_P, _P, _P, _P, _P, _U64, C.c_uint32, _P, _P, C.c_uint32, C.c_uint32, C.c_int],
     "kw_intensity_avg_c_accumulate": [_P, _P, _P, _P, _U64, C.c_uint32],
+    "kw_time_shift_series": [_P, _P, _P, _U64, _U64],
+    "kw_intensity_avg": [_P, _P, _P, _P, _U64, _U64],
+    "kw_q_term_sum": [_P, _P, _P, _P, _P, _U64],
     "kw_divide": [_P, _P, C.c_float, _U64],
 }
 

@@ -107,6 +107,17 @@ static kw_status make_plan(kw_fft_plan& p, rocfft_transform_type type, size_t di
   return KW_OK;
 }
 
+// X[k][i] *= divider * shift[k]   (series spectrum [kc][n], k along the step axis)
+__global__ void k_series_shift(float2* __restrict__ spec, const float2* __restrict__ shift, uint64_t n, float divider)
+{
+  const uint64_t i = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float2 s = shift[blockIdx.y];
+  const float2 m = make_float2(divider * s.x, divider * s.y);
+  float2&      v = spec[static_cast<uint64_t>(blockIdx.y) * n + i];
+  v = make_float2(v.x * m.x - v.y * m.y, v.x * m.y + v.y * m.x);
+}
+
 extern "C" {
 
 kw_status kw_fft_create_plans_3d(kw_ctx* ctx)
@@ -158,6 +169,54 @@ kw_status kw_fft_create_plans_1d(kw_ctx* ctx, int axis)
   }
   if (st != KW_OK) return st;
   return bind_work(ctx);
+}
+
+kw_status kw_time_shift_series(kw_ctx* ctx, float* series, const float* shift, uint64_t steps, uint64_t n)
+{
+  KW_CHECK_CTX(ctx);
+  KW_REQUIRE(series != nullptr && shift != nullptr && steps >= 2 && n >= 1 && steps / 2 + 1 <= 65535u);
+  KW_HIP(hipSetDevice(ctx->device));
+  kw_status st = ensure_setup(ctx);
+  if (st != KW_OK) return st;
+  // transforms along the step axis: n lines of `steps` elements, element stride n, line distance 1
+  const size_t kc = steps / 2 + 1;
+  size_t len[1] = { static_cast<size_t>(steps) }, str[1] = { static_cast<size_t>(n) };
+  kw_fft_plan fwd, inv;
+  void *work = nullptr, *spec = nullptr;
+  auto cleanup = [&]() {
+    (void)hipStreamSynchronize(ctx->stream);
+    plan_free(fwd);
+    plan_free(inv);
+    if (work) (void)hipFree(work);
+    if (spec) (void)hipFree(spec);
+  };
+#define KW_TS(call) do { kw_status s__ = (call); if (s__ != KW_OK) { cleanup(); return s__; } } while (0)
+  KW_TS(make_plan(fwd, rocfft_transform_type_real_forward, 1, len, n, str, 1, str, 1));
+  KW_TS(make_plan(inv, rocfft_transform_type_real_inverse, 1, len, n, str, 1, str, 1));
+  auto run = [&]() -> kw_status {
+    const size_t wbytes = fwd.work > inv.work ? fwd.work : inv.work;
+    if (wbytes) KW_HIP(hipMalloc(&work, wbytes));
+    KW_HIP(hipMalloc(&spec, kc * n * sizeof(float2)));
+    for (kw_fft_plan* p : { &fwd, &inv })
+    {
+      KW_FFT(rocfft_execution_info_create(&p->info));
+      if (p->work > 0) KW_FFT(rocfft_execution_info_set_work_buffer(p->info, work, wbytes));
+      KW_FFT(rocfft_execution_info_set_stream(p->info, ctx->stream));
+    }
+    void* a[1] = { series };
+    void* b[1] = { spec };
+    KW_FFT(rocfft_execute(fwd.plan, a, b, fwd.info));
+    hipLaunchKernelGGL(k_series_shift, dim3(static_cast<unsigned>((n + 255) / 256), static_cast<unsigned>(kc), 1),
+                       dim3(256), 0, ctx->stream, static_cast<float2*>(spec), reinterpret_cast<const float2*>(shift), n,
+                       1.0f / static_cast<float>(steps));
+    KW_LAUNCH_CHECK();
+    KW_FFT(rocfft_execute(inv.plan, b, a, inv.info));
+    return KW_OK;
+  };
+  st = run();
+  cleanup();
+#undef KW_TS
+  return st;
 }
 
 kw_status kw_fft_destroy_plans(kw_ctx* ctx)

@@ -1241,6 +1241,36 @@ template<int L> __global__ __launch_bounds__(256) void k_probe_tile_wide(PassArg
   }
 }
 
+// tile loads + stores of lines of 16*R elements, 256 threads, VEC complex per lane (16 lanes per row: 128-B or 256-B
+// row segments); XCD: blocks that follow each other in the logical tile order run on the same XCD (same L2 / TLB)
+template<int R, int VEC, bool XCD> __global__ __launch_bounds__(256) void k_probe_tile_rt(PassArgs a)
+{
+  typedef float vf __attribute__((ext_vector_type(2 * VEC)));
+  uint32_t bx = blockIdx.x, by = blockIdx.y;
+  if (XCD)
+  {
+    const uint32_t nb = gridDim.x * gridDim.y, b = by * gridDim.x + bx;
+    const uint32_t l = (b % 8u) * (nb / 8u) + b / 8u; // nb % 8 == 0 checked by the host
+    bx = l % gridDim.x;
+    by = l / gridDim.x;
+  }
+  const int      c   = threadIdx.x % 16;
+  const int      j   = threadIdx.x / 16;
+  const uint32_t kx  = bx * (16 * VEC) + VEC * c;
+  const uint32_t kxl = min(kx, a.P - VEC);
+  vf* __restrict__ S = reinterpret_cast<vf*>(a.out[0]);
+  const uint32_t b0   = ((by * a.ain.zmul + j * a.ain.estride) * a.P + kxl) / VEC;
+  const uint32_t step = (16 * a.ain.estride * a.P) / VEC;
+  vf v[R];
+#pragma unroll
+  for (int n1 = 0; n1 < R; n1++) v[n1] = S[b0 + n1 * step];
+  if (kx < a.nxc)
+  {
+#pragma unroll
+    for (int n1 = 0; n1 < R; n1++) { v[n1].x += 1.f; S[b0 + n1 * step] = v[n1]; }
+  }
+}
+
 // memory pattern of k_xinv<velocity, chain> without its arithmetic: per block 32 spectrum rows in, 32 rows of two real
 // arrays in (float4), one real array out, 32 spectrum rows out
 template<int L> __global__ __launch_bounds__(Geo<L>::THREADS) void k_probe_xinv(XinvArgs a)
@@ -2007,6 +2037,32 @@ kw_status kw_fused_probe(kw_ctx* ctx, int which, const float* op)
     a.P   = f.P;
     a.ain = (which == 15) ? RowAddr{31u, 0xffffffffu, 0u, c.ny, 1u} : RowAddr{31u, 0xffffffffu, 0u, 1u, c.ny};
     LAUNCH((k_probe_tile_wide<256>), dim3((f.P + 31) / 32, c.nz, 1), dim3(256), a);
+    return KW_OK;
+  }
+  if (which >= 30 && which <= 37)
+  { // bit 0: z-lines instead of y-lines; bit 1: 256-B segments; bit 2: XCD-grouped tile order.  Lines of 256 or 512.
+    KW_REQUIRE(c.nz == c.ny && (c.ny == 256 || c.ny == 512));
+    const int w = which - 30;
+    PassArgs a{};
+    a.out[0] = f.s[0];
+    a.nxc = c.nx_complex;
+    a.P   = f.P;
+    a.ain = (w & 1) ? RowAddr{31u, 0xffffffffu, 0u, 1u, c.ny} : RowAddr{31u, 0xffffffffu, 0u, c.ny, 1u};
+    const int  vec = (w & 2) ? 2 : 1;
+    const dim3 grid((f.P + 16 * vec - 1) / (16 * vec), c.nz, 1);
+    KW_REQUIRE(!(w & 4) || (grid.x * grid.y) % 8 == 0);
+#define PR(R, V, X) LAUNCH((k_probe_tile_rt<R, V, X>), grid, dim3(256), a)
+    if (c.ny == 256)
+    {
+      if (w == 0 || w == 1) PR(16, 1, false); else if (w == 2 || w == 3) PR(16, 2, false);
+      else if (w == 4 || w == 5) PR(16, 1, true); else PR(16, 2, true);
+    }
+    else
+    {
+      if (w == 0 || w == 1) PR(32, 1, false); else if (w == 2 || w == 3) PR(32, 2, false);
+      else if (w == 4 || w == 5) PR(32, 1, true); else PR(32, 2, true);
+    }
+#undef PR
     return KW_OK;
   }
   if (which >= 20 && which <= 23)

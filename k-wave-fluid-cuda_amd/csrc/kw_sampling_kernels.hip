@@ -148,6 +148,29 @@ __global__ __launch_bounds__(256) void k_divide(float* __restrict__ buf, float d
     buf[i] = buf[i] / divisor;
 }
 
+// time-averaged intensity of one sampled point: the products are added in step order, then divided by the step count
+// (KSpaceFirstOrderSolver.cpp:1492-1513)
+__global__ __launch_bounds__(256) void k_intensity_avg(float* __restrict__ iavg, const float* __restrict__ p,
+                                                       const float* __restrict__ u, uint64_t steps, uint64_t n)
+{
+  for (uint64_t i = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n;
+       i += static_cast<uint64_t>(gridDim.x) * blockDim.x)
+  {
+    float acc = 0.0f;
+    for (uint64_t s = 0; s < steps; s++) acc += u[s * n + i] * p[s * n + i];
+    iavg[i] = acc / static_cast<float>(steps);
+  }
+}
+
+// Q = -(dIx/dx + dIy/dy [+ dIz/dz])   (KSpaceFirstOrderSolver.cpp:2014-2026)
+__global__ __launch_bounds__(256) void k_q_term_sum(float* __restrict__ out, const float* __restrict__ a,
+                                                    const float* __restrict__ b, const float* __restrict__ c, uint64_t n)
+{
+  for (uint64_t i = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n;
+       i += static_cast<uint64_t>(gridDim.x) * blockDim.x)
+    out[i] = (c != nullptr) ? -(a[i] + b[i] + c[i]) : -(a[i] + b[i]);
+}
+
 inline unsigned sampler_grid(const kw_ctx* ctx, uint64_t n)
 {
   // CU count x 8 blocks, shrunk to the work size (reference: SM count x 8, CudaParameters.cpp:218-231)
@@ -260,6 +283,26 @@ kw_status kw_intensity_avg_c_accumulate(kw_ctx* ctx, float* iavg, const float* f
   KW_REQUIRE(iavg && frame_p && frame_u && harmonics >= 1);
   LAUNCH(k_intensity_avg_c, dim3(sampler_grid(ctx, n)), dim3(256), iavg, (const float2*)frame_p, (const float2*)frame_u,
          n, harmonics);
+  return KW_OK;
+}
+
+kw_status kw_intensity_avg(kw_ctx* ctx, float* iavg, const float* p, const float* u, uint64_t steps, uint64_t n)
+{
+  KW_CHECK_CTX(ctx);
+  KW_PROF(ctx, "intensity_avg");
+  if (n == 0) return KW_OK;
+  KW_REQUIRE(iavg && p && u && steps >= 1);
+  LAUNCH(k_intensity_avg, dim3(sampler_grid(ctx, n)), dim3(256), iavg, p, u, steps, n);
+  return KW_OK;
+}
+
+kw_status kw_q_term_sum(kw_ctx* ctx, float* out, const float* a, const float* b, const float* c, uint64_t n)
+{
+  KW_CHECK_CTX(ctx);
+  KW_PROF(ctx, "q_term_sum");
+  if (n == 0) return KW_OK;
+  KW_REQUIRE(out && a && b);
+  LAUNCH(k_q_term_sum, dim3(sampler_grid(ctx, n)), dim3(256), out, a, b, c, n);
   return KW_OK;
 }
 

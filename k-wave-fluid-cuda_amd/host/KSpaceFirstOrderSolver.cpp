@@ -3,7 +3,9 @@
 #include "KSpaceFirstOrderSolver.h"
 #include <cstdlib>
 
+#include <algorithm>
 #include <cmath>
+#include <complex>
 #include <limits>
 
 #include "HipError.h"
@@ -202,8 +204,153 @@ void KSpaceFirstOrderSolver::runTimeSteps(size_t nSteps)
 
 template<SD sd> void KSpaceFirstOrderSolver::postProcessing()
 { // KSpaceFirstOrderSolver.cpp:950-1053 (streams part); p_final/u_final stay on the device until asked for
+  using OI = OutputStreamContainer::OutputStreamIdx;
+  // average intensity from the stored p and u_non_staggered series (:982-987)
+  if (mParameters.getStoreQTermFlag() || mParameters.getStoreIntensityAvgFlag()) computeAverageIntensities();
   mOutputStreamContainer.postProcessStreams();
+  // volume rate of heat deposition from the average intensity (:1001-1021)
+  if (mParameters.getStoreQTermFlag())
+    computeQTerm(OI::kIntensityXAvg, OI::kIntensityYAvg, OI::kIntensityZAvg, OI::kQTerm);
+  if (mParameters.getStoreQTermCFlag())
+    computeQTerm(OI::kIntensityXAvgC, OI::kIntensityYAvgC, OI::kIntensityZAvgC, OI::kQTermC);
   mOutputStreamContainer.closeStreams();
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Post-processing.  Same arithmetic as the reference; the spectra stay on the device (the reference copies every
+// spectrum to the host for the multiply and back, :1437-1487, :1941-2004).
+// ---------------------------------------------------------------------------------------------------------------------
+namespace
+{
+struct DeviceBuffer
+{ // scoped device allocation
+  DeviceBuffer(kw_ctx* c, size_t bytes) : ctx(c) { kwCheck(kw_malloc(ctx, bytes, &ptr)); }
+  ~DeviceBuffer() { if (ptr) kw_free(ctx, ptr); }
+  DeviceBuffer(const DeviceBuffer&) = delete;
+  DeviceBuffer& operator=(const DeviceBuffer&) = delete;
+  float* f() const { return static_cast<float*>(ptr); }
+  kw_ctx* ctx;
+  void*   ptr = nullptr;
+};
+} // namespace
+
+std::vector<size_t> KSpaceFirstOrderSolver::sensorGridIndices()
+{
+  std::vector<size_t> idx;
+  if (mMatrixContainer.has(MI::kSensorMaskIndex))
+  {
+    const IndexMatrix& m = index(MI::kSensorMaskIndex);
+    idx.assign(m.getHostData(), m.getHostData() + m.size());
+    return idx;
+  }
+  const IndexMatrix&   m    = index(MI::kSensorMaskCorners);
+  const DimensionSizes dims = mParameters.getFullDimensionSizes();
+  for (size_t c = 0; c < m.getDimensionSizes().ny; c++)
+  { // buffer order of a cuboid: x fastest, then y, then z (:1822-1840)
+    const DimensionSizes a = m.getTopLeftCorner(c), b = m.getBottomRightCorner(c);
+    for (size_t z = a.nz; z <= b.nz; z++)
+      for (size_t y = a.ny; y <= b.ny; y++)
+        for (size_t x = a.nx; x <= b.nx; x++) idx.push_back((z * dims.ny + y) * dims.nx + x);
+  }
+  return idx;
+}
+
+void KSpaceFirstOrderSolver::computeAverageIntensities()
+{ // :1231-1534: u is sampled half a step after p; its series is advanced by half a step through its spectrum along
+  // time, then I = mean over the stored steps of p * u
+  using OI = OutputStreamContainer::OutputStreamIdx;
+  kw_ctx* ctx = mParameters.getHipParameters().getContext();
+  BaseOutputStream* ps = mOutputStreamContainer.get(OI::kPressureRaw);
+  const OI ui[3] = {OI::kVelocityXNonStaggeredRaw, OI::kVelocityYNonStaggeredRaw, OI::kVelocityZNonStaggeredRaw};
+  const OI ii[3] = {OI::kIntensityXAvg, OI::kIntensityYAvg, OI::kIntensityZAvg};
+  if (ps == nullptr) throw std::runtime_error("computeAverageIntensities: the raw pressure stream is missing");
+  const size_t steps = ps->sampledSteps(), points = ps->size();
+  if (steps < 2 || points == 0) return; // nothing stored (sampling never started): the intensities stay zero
+
+  // phase factors of the half-step shift (:1253-1260)
+  using FloatComplex = std::complex<float>;
+  const float  pi2 = static_cast<float>(M_PI) * 2.0f;
+  const size_t stepsComplex = steps / 2 + 1;
+  std::vector<FloatComplex> kx(stepsComplex);
+  for (size_t i = 0; i < stepsComplex; i++)
+  {
+    const ssize_t shift = ssize_t((i + (steps / 2)) % steps - (steps / 2));
+    kx[i] = std::exp(FloatComplex(0.0f, 1.0f) * (pi2 * 0.5f) * (float(shift) / float(steps)));
+  }
+  DeviceBuffer dShift(ctx, stepsComplex * sizeof(FloatComplex));
+  kwCheck(kw_memcpy_h2d(ctx, dShift.ptr, kx.data(), stepsComplex * sizeof(FloatComplex)));
+
+  // blocks of sensor points: p, u and the spectrum of u (~ 3.1 arrays of block x steps floats) stay below ~1 GB
+  const size_t budget = size_t(80) << 20; // floats per array
+  size_t block = std::max<size_t>(1, std::min(points, budget / steps));
+  DeviceBuffer dP(ctx, block * steps * sizeof(float)), dU(ctx, block * steps * sizeof(float)), dI(ctx, block * sizeof(float));
+  std::vector<float> pack(block * steps);
+  auto upload = [&](const std::vector<float>& series, size_t first, size_t n, float* dst) {
+    for (size_t s = 0; s < steps; s++) std::copy_n(series.data() + s * points + first, n, pack.data() + s * n);
+    kwCheck(kw_memcpy_h2d(ctx, dst, pack.data(), n * steps * sizeof(float)));
+  };
+  for (size_t first = 0; first < points; first += block)
+  {
+    const size_t n = std::min(block, points - first);
+    upload(ps->dataset(), first, n, dP.f());
+    for (int a = 0; a < 3; a++)
+    {
+      BaseOutputStream* us = mOutputStreamContainer.get(ui[a]);
+      auto* is = dynamic_cast<PostProcessedOutputStream*>(mOutputStreamContainer.get(ii[a]));
+      if (us == nullptr || is == nullptr) throw std::runtime_error("computeAverageIntensities: stream missing");
+      upload(us->dataset(), first, n, dU.f());
+      kwCheck(kw_time_shift_series(ctx, dU.f(), dShift.f(), steps, n));
+      kwCheck(kw_intensity_avg(ctx, dI.f(), dP.f(), dU.f(), steps, n));
+      kwCheck(kw_memcpy_d2h(ctx, is->data().data() + first, dI.f(), n * sizeof(float)));
+    }
+  }
+}
+
+void KSpaceFirstOrderSolver::computeQTerm(OutputStreamContainer::OutputStreamIdx intensityX,
+                                          OutputStreamContainer::OutputStreamIdx intensityY,
+                                          OutputStreamContainer::OutputStreamIdx intensityZ,
+                                          OutputStreamContainer::OutputStreamIdx qTerm)
+{ // :1783-2080: Q = -div(I_avg), each derivative taken spectrally along its own axis of the full grid (zero outside
+  // the sensor mask)
+  using FloatComplex = std::complex<float>;
+  kw_ctx* ctx = mParameters.getHipParameters().getContext();
+  const DimensionSizes dims = mParameters.getFullDimensionSizes();
+  const std::vector<size_t> where = sensorGridIndices();
+  auto* q = dynamic_cast<PostProcessedOutputStream*>(mOutputStreamContainer.get(qTerm));
+  if (q == nullptr) throw std::runtime_error("computeQTerm: the Q-term stream is missing");
+  const OutputStreamContainer::OutputStreamIdx ii[3] = {intensityX, intensityY, intensityZ};
+  RealMatrix* grid[3] = {&getTemp1RealND(), &getTemp2RealND(), &getTemp3RealND()};
+  HipFftComplexMatrix& tempShift = fft(MI::kTempHipFftShift);
+  const float  pi2 = static_cast<float>(M_PI) * 2.0f;
+  const size_t n[3] = {dims.nx, dims.ny, dims.nz};
+  const float  d[3] = {mParameters.getDx(), mParameters.getDy(), mParameters.getDz()};
+  for (int a = 0; a < 3; a++)
+  {
+    BaseOutputStream* is = mOutputStreamContainer.get(ii[a]);
+    if (is == nullptr || is->dataset().size() != where.size()) throw std::runtime_error("computeQTerm: intensity stream missing");
+    float* host = grid[a]->getHostData();
+    std::fill_n(host, dims.nElements(), 0.0f);
+    for (size_t i = 0; i < where.size(); i++) host[where[i]] = is->dataset()[i];
+    grid[a]->copyToDevice();
+    // i*k of this axis (:1905-1921); the 1/N of the transform pair is applied with it (:1945-1958)
+    const size_t nc = n[a] / 2 + 1;
+    std::vector<FloatComplex> k(nc);
+    for (size_t i = 0; i < nc; i++)
+    {
+      const ssize_t shift = ssize_t((i + (n[a] / 2)) % n[a] - (n[a] / 2));
+      k[i] = FloatComplex(0.0f, 1.0f) * (pi2 / d[a]) * (float(shift) / float(n[a]));
+    }
+    DeviceBuffer dk(ctx, nc * sizeof(FloatComplex));
+    kwCheck(kw_memcpy_h2d(ctx, dk.ptr, k.data(), nc * sizeof(FloatComplex)));
+    kwCheck(kw_fft_r2c_1d(ctx, a, grid[a]->getDeviceData(), tempShift.getDeviceData()));
+    kwCheck(kw_compute_velocity_shift(ctx, a, tempShift.getDeviceData(), dk.f()));
+    kwCheck(kw_fft_c2r_1d(ctx, a, tempShift.getDeviceData(), grid[a]->getDeviceData()));
+  }
+  kwCheck(kw_q_term_sum(ctx, grid[0]->getDeviceData(), grid[0]->getDeviceData(), grid[1]->getDeviceData(),
+                        grid[2]->getDeviceData(), dims.nElements()));
+  grid[0]->copyFromDevice();
+  const float* host = grid[0]->getHostData();
+  for (size_t i = 0; i < where.size(); i++) q->data()[i] = host[where[i]];
 }
 
 void KSpaceFirstOrderSolver::storeSensorData()

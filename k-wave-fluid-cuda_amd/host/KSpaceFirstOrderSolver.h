@@ -57,6 +57,11 @@ class KSpaceFirstOrderSolver
   void scaleSource(RealMatrix& scaledSource, const RealMatrix& sourceInput, const IndexMatrix& sourceIndex, const size_t manyFlag);
   template<SD simulationDimension> void addInitialPressureSource();
   template<SD simulationDimension> void computeShiftedVelocity();
+  // post-processing of the stored series (KSpaceFirstOrderSolver.cpp:1231-1534, :1783-2080)
+  void computeAverageIntensities();
+  void computeQTerm(OutputStreamContainer::OutputStreamIdx intensityX, OutputStreamContainer::OutputStreamIdx intensityY,
+                    OutputStreamContainer::OutputStreamIdx intensityZ, OutputStreamContainer::OutputStreamIdx qTerm);
+  std::vector<size_t> sensorGridIndices(); // grid index of every sensor point, in stream-buffer order
 
   void generateKappa();
   void generateSourceKappa();

@@ -362,8 +362,28 @@ void OutputStreamContainer::init(MatrixContainer& mc)
         if (is3D) mContainer[a.z] = createOutputStream(mc, MI::kUzSgz, kUzName + a.suffix, a.op);
       }
   }
-  // ---- compression streams (OutputStreamContainer.cpp:92-96,157-168,272-316); index masks only ----
-  const bool wantIAvgC = params.getStoreIntensityAvgCFlag();
+  // ---- average intensity / Q term from the stored raw series (OutputStreamContainer.cpp:227-271): the series they are
+  // computed from are stored too, the intensities are kept out of the output unless asked for ----
+  if (haveMask && (params.getStoreQTermFlag() || params.getStoreIntensityAvgFlag()))
+  {
+    if (mContainer.count(OI::kPressureRaw) == 0) mContainer[OI::kPressureRaw] = createOutputStream(mc, MI::kP, kPName, RO::kNone);
+    if (mContainer.count(OI::kVelocityXNonStaggeredRaw) == 0)
+    {
+      mContainer[OI::kVelocityXNonStaggeredRaw] = createOutputStream(mc, MI::kUxShifted, kUxNonStaggeredName, RO::kNone);
+      mContainer[OI::kVelocityYNonStaggeredRaw] = createOutputStream(mc, MI::kUyShifted, kUyNonStaggeredName, RO::kNone);
+      mContainer[OI::kVelocityZNonStaggeredRaw] = createOutputStream(mc, MI::kUzShifted, kUzNonStaggeredName, RO::kNone);
+    }
+    const bool cuboid = !mc.has(MI::kSensorMaskIndex);
+    const IndexMatrix& points = mc.getMatrix<IndexMatrix>(cuboid ? MI::kSensorMaskCorners : MI::kSensorMaskIndex);
+    const bool hide = !params.getStoreIntensityAvgFlag();
+    const RealMatrix& pm = mc.getMatrix<RealMatrix>(MI::kP);
+    mContainer[OI::kIntensityXAvg] = new PostProcessedOutputStream("Ix_avg", pm, RO::kIAvg, points, cuboid, hide);
+    mContainer[OI::kIntensityYAvg] = new PostProcessedOutputStream("Iy_avg", pm, RO::kIAvg, points, cuboid, hide);
+    mContainer[OI::kIntensityZAvg] = new PostProcessedOutputStream("Iz_avg", pm, RO::kIAvg, points, cuboid, hide);
+    if (params.getStoreQTermFlag()) mContainer[OI::kQTerm] = new PostProcessedOutputStream("Q_term", pm, RO::kQTerm, points, cuboid);
+  }
+  // ---- compression streams (OutputStreamContainer.cpp:92-96,157-168,272-321); index masks only ----
+  const bool wantIAvgC = params.getStoreIntensityAvgCFlag() || params.getStoreQTermCFlag();
   if (mc.has(MI::kSensorMaskIndex) && (params.getStorePressureCFlag() || params.getStoreVelocityNonStaggeredCFlag() || wantIAvgC))
   {
     IndexMatrix& mask = mc.getMatrix<IndexMatrix>(MI::kSensorMaskIndex);
@@ -382,8 +402,17 @@ void OutputStreamContainer::init(MatrixContainer& mc)
       const OI is[3] = {OI::kIntensityXAvgC, OI::kIntensityYAvgC, OI::kIntensityZAvgC};
       const char* names[3] = {"Ix_avg_c", "Iy_avg_c", "Iz_avg_c"};
       for (int a = 0; a < 3; a++)
+      {
         mContainer[is[a]] = new IntensityAvgCOutputStream(names[a], mc.getMatrix<RealMatrix>(MI::kP), pc,
                                                           *static_cast<CompressedIndexOutputStream*>(mContainer[us[a]]));
+        mContainer[is[a]]->setDoNotSave(!params.getStoreIntensityAvgCFlag());
+      }
+      // coefficient series that only feed the intensities are not part of the output (:274-292: doNotSaveFlag)
+      if (!params.getStorePressureCFlag()) mContainer[OI::kPressureC]->setDoNotSave(true);
+      if (!params.getStoreVelocityNonStaggeredCFlag())
+        for (int a = 0; a < 3; a++) mContainer[us[a]]->setDoNotSave(true);
+      if (params.getStoreQTermCFlag())
+        mContainer[OI::kQTermC] = new PostProcessedOutputStream("Q_term_c", mc.getMatrix<RealMatrix>(MI::kP), RO::kQTermC, mask, false);
     }
   }
   if (params.getStoreVelocityMaxAllFlag())
@@ -463,9 +492,10 @@ BaseOutputStream* OutputStreamContainer::find(const std::string& name) const
     if (it.second->name() == name) return it.second;
   return nullptr;
 }
-std::vector<std::string> OutputStreamContainer::names() const
+std::vector<std::string> OutputStreamContainer::names(bool includeHidden) const
 {
   std::vector<std::string> v;
-  for (auto& it : mContainer) v.push_back(it.second->name());
+  for (auto& it : mContainer)
+    if (includeHidden || !it.second->doNotSave()) v.push_back(it.second->name());
   return v;
 }

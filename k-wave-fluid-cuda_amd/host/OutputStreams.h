@@ -31,9 +31,9 @@ void postProcessingRms(float* samplingBuffer, float scalingCoeff, size_t nSample
 class BaseOutputStream
 {
  public:
-  enum class ReduceOperator { kNone, kRms, kMax, kMin, kC, kIAvgC };
-  BaseOutputStream(const std::string& name, const RealMatrix& source, ReduceOperator op)
-    : mName(name), mSourceMatrix(source), mReduceOp(op) {}
+  enum class ReduceOperator { kNone, kRms, kMax, kMin, kC, kIAvgC, kIAvg, kQTerm, kQTermC };
+  BaseOutputStream(const std::string& name, const RealMatrix& source, ReduceOperator op, bool doNotSave = false)
+    : mName(name), mSourceMatrix(source), mReduceOp(op), mDoNotSave(doNotSave) {}
   virtual ~BaseOutputStream();
   virtual void create() = 0;
   virtual void sample() = 0;
@@ -46,6 +46,9 @@ class BaseOutputStream
   const std::vector<float>& dataset() const { return mDataset; }
   size_t size() const { return mSize; }
   size_t sampledSteps() const { return mFlushedSteps; }
+  /// stream that only feeds another one (the reference's doNotSaveFlag, e.g. I_avg behind --Q_term): not listed, not written
+  bool   doNotSave() const { return mDoNotSave; }
+  void   setDoNotSave(bool v) { mDoNotSave = v; }
   /// Checkpoint / restart (BaseOutputStream::checkpoint / reopen, e.g. IndexOutputStream.cpp:497-533): what a restart
   /// needs to continue this stream — the series stored so far (raw; the reference keeps it in the output file) or the
   /// device accumulator (rms / max / min) — and the number of sampled steps.
@@ -61,6 +64,7 @@ class BaseOutputStream
   std::string       mName;
   const RealMatrix& mSourceMatrix;
   ReduceOperator    mReduceOp;
+  bool              mDoNotSave = false;
   size_t            mSize = 0;
   float*            mDeviceBuffer = nullptr;       // aggregate, or raw staging buffer 0 (device)
   float*            mDeviceRaw[2] = {nullptr, nullptr}; // raw: double-buffered device staging (copy overlaps compute)
@@ -136,6 +140,30 @@ class IntensityAvgCOutputStream : public BaseOutputStream
   size_t mCompressedTimeStep = 0;
 };
 
+/// kIAvg / kQTerm / kQTermC streams: one value per sensor point, produced after the last step by the solver's
+/// post-processing (computeAverageIntensities / computeQTerm) instead of by sampling
+class PostProcessedOutputStream : public BaseOutputStream
+{
+ public:
+  PostProcessedOutputStream(const std::string& name, const RealMatrix& source, ReduceOperator op,
+                            const IndexMatrix& sensorMask, bool cuboidMask, bool doNotSave = false)
+    : BaseOutputStream(name, source, op, doNotSave), mSensorMask(sensorMask), mCuboidMask(cuboidMask) {}
+  void create() override
+  { // the mask is loaded by now (the container is set up before the input file is read)
+    mSize = mCuboidMask ? mSensorMask.getSizeOfAllCuboids() : mSensorMask.size();
+    mDataset.assign(mSize, 0.0f);
+  }
+  void sample() override {}
+  void postProcess() override {}
+  std::vector<float>& data() { return mDataset; }
+  void checkpointState(std::vector<float>& state, size_t& sampledSteps) override { state.clear(); sampledSteps = 0; }
+  void restoreState(const float*, size_t, size_t) override {}
+
+ private:
+  const IndexMatrix& mSensorMask;
+  bool               mCuboidMask;
+};
+
 class CuboidOutputStream : public BaseOutputStream
 {
  public:
@@ -169,7 +197,8 @@ class OutputStreamContainer
     kVelocityZMax, kVelocityXMin, kVelocityYMin, kVelocityZMin, kVelocityXMaxAll, kVelocityYMaxAll, kVelocityZMaxAll,
     kVelocityXMinAll, kVelocityYMinAll, kVelocityZMinAll,
     kPressureC, kVelocityXNonStaggeredC, kVelocityYNonStaggeredC, kVelocityZNonStaggeredC,
-    kIntensityXAvgC, kIntensityYAvgC, kIntensityZAvgC
+    kIntensityXAvgC, kIntensityYAvgC, kIntensityZAvgC,
+    kIntensityXAvg, kIntensityYAvg, kIntensityZAvg, kQTerm, kQTermC
   };
   ~OutputStreamContainer() { freeStreams(); }
   void init(MatrixContainer& matrixContainer); // OutputStreamContainer.cpp:70-325
@@ -181,7 +210,9 @@ class OutputStreamContainer
   void freeStreams();
   bool empty() const { return mContainer.empty(); }
   BaseOutputStream* find(const std::string& name) const;
-  std::vector<std::string> names() const;
+  BaseOutputStream* get(OutputStreamIdx idx) const { auto it = mContainer.find(idx); return it == mContainer.end() ? nullptr : it->second; }
+  /// streams that are part of the output; includeHidden adds the ones that only feed others (checkpointing needs all)
+  std::vector<std::string> names(bool includeHidden = false) const;
 
  private:
   BaseOutputStream* createOutputStream(MatrixContainer& mc, MatrixContainer::MatrixIdx sampled, const std::string& name,

@@ -140,7 +140,7 @@ void Parameters::init(const InputProvider& in, const Options& options)
     mBOnAScalarFlag = in.getDatasetDimensionSizes(kBonAName) == scalarSizes;
     if (mBOnAScalarFlag) in.readScalarValue(kBonAName, mBOnAScalar);
   }
-  if (mOptions.storePressureC || mOptions.storeVelocityNonStaggeredC || mOptions.storeIntensityAvgC)
+  if (mOptions.storePressureC || mOptions.storeVelocityNonStaggeredC || mOptions.storeIntensityAvgC || mOptions.storeQTermC)
   { // Parameters.cpp:462-551: the period (in time steps) is given (--period) or found from the pressure source signal:
     // the last <= 500 samples of the middle source point (:488-512)
     if (!(mOptions.period > 0.0f))

@@ -52,6 +52,7 @@ class Parameters
     bool   storeVelocityMaxAll = false, storeVelocityMinAll = false, storeVelocityFinalAll = false;
     bool   storeVelocityNonStaggeredRaw = false;
     bool   storePressureC = false, storeVelocityNonStaggeredC = false, storeIntensityAvgC = false;
+    bool   storeIntensityAvg = false, storeQTerm = false, storeQTermC = false; // --I_avg, --Q_term, --Q_term_c
     float  period = 0.0f; // --period (time steps per period)
     size_t mos = 1, harmonics = 1;
     bool   noCompressionOverlap = false;
@@ -162,6 +163,9 @@ class Parameters
   bool getStorePressureCFlag() const { return mOptions.storePressureC; }
   bool getStoreVelocityNonStaggeredCFlag() const { return mOptions.storeVelocityNonStaggeredC; }
   bool getStoreIntensityAvgCFlag() const { return mOptions.storeIntensityAvgC; }
+  bool getStoreIntensityAvgFlag() const { return mOptions.storeIntensityAvg; }
+  bool getStoreQTermFlag() const { return mOptions.storeQTerm; }
+  bool getStoreQTermCFlag() const { return mOptions.storeQTermC; }
   bool getNoCompressionOverlapFlag() const { return mOptions.noCompressionOverlap; }
   float  getPeriod() const { return mOptions.period; }
   size_t getMOS() const { return mOptions.mos; }
@@ -169,7 +173,8 @@ class Parameters
   /// true when any stream needs u on the non-staggered grid (KSpaceFirstOrderSolver.cpp:1075-1078)
   bool needsShiftedVelocity() const
   {
-    return mOptions.storeVelocityNonStaggeredRaw || mOptions.storeVelocityNonStaggeredC || mOptions.storeIntensityAvgC;
+    return mOptions.storeVelocityNonStaggeredRaw || mOptions.storeVelocityNonStaggeredC || mOptions.storeIntensityAvgC ||
+           mOptions.storeIntensityAvg || mOptions.storeQTerm || mOptions.storeQTermC;
   }
 
  private:

@@ -107,7 +107,7 @@ void kwh_checkpoint_write_impl(kwh_solver* s, const std::string& path)
     f.writeMatrix(name, dims, buf.data(), Hdf5File::MatrixDomainType::kReal);
   }
   OutputStreamContainer& streams = s->solver->getOutputStreamContainer();
-  for (const std::string& name : streams.names())
+  for (const std::string& name : streams.names(true))
   {
     std::vector<float> state;
     size_t steps = 0;
@@ -141,7 +141,7 @@ void kwh_checkpoint_read_impl(kwh_solver* s, const std::string& path)
     if (kwh_set_matrix(s, name, buf.data(), buf.size()) != 0) throw std::runtime_error(kwh_last_error());
   }
   OutputStreamContainer& streams = s->solver->getOutputStreamContainer();
-  for (const std::string& name : streams.names())
+  for (const std::string& name : streams.names(true))
   {
     size_t steps = 0;
     f.readCompleteDataset("stream_" + name + "_steps", 1, &steps);

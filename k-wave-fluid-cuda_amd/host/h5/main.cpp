@@ -19,7 +19,7 @@ static void usage()
   std::printf("kspaceFirstOrder-HIP -i <input.h5> -o <output.h5> [-g dev] [-s start (1-based)] [--benchmark N]\n"
               "  [-p|--p_raw] [--p_rms] [--p_max] [--p_min] [--p_max_all] [--p_min_all] [--p_final]\n"
               "  [-u|--u_raw] [--u_rms] [--u_max] [--u_min] [--u_max_all] [--u_min_all] [--u_final] [--u_non_staggered_raw]\n"
-              "  [--p_c] [--u_non_staggered_c] [--I_avg_c] [--period P] [--mos M] [--harmonics H] [--no_overlap] [--granular]\n"
+              "  [--p_c] [--u_non_staggered_c] [--I_avg_c] [--I_avg] [--Q_term] [--Q_term_c] [--period P] [--mos M] [--harmonics H] [--no_overlap] [--granular]\n"
               "  [-c <deflate 0..9>] [--copy_sensor_mask]\n"
               "  [--checkpoint_file <ckpt.h5> --checkpoint_timesteps N]  stop after N steps, leaving a checkpoint; the\n"
               "      same command line resumes from it (CommandLineParameters.cpp:264-292)\n");
@@ -62,6 +62,9 @@ int main(int argc, char** argv)
     else if (a == "--p_c") o.p_c = 1;
     else if (a == "--u_non_staggered_c") o.u_non_staggered_c = 1;
     else if (a == "--I_avg_c") o.i_avg_c = 1;
+    else if (a == "--I_avg") o.i_avg = 1;
+    else if (a == "--Q_term") o.q_term = 1;
+    else if (a == "--Q_term_c") o.q_term_c = 1;
     else if (a == "--period") o.period = std::strtof(next(), nullptr);
     else if (a == "--mos") o.mos = std::strtoull(next(), nullptr, 10);
     else if (a == "--harmonics") o.harmonics = std::strtoull(next(), nullptr, 10);

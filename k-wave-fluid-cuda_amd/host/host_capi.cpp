@@ -30,6 +30,7 @@ Parameters::Options kwh_convert_options(const kwh_options* o)
   opt.storeVelocityFinalAll = o->u_final; opt.storeVelocityNonStaggeredRaw = o->u_non_staggered_raw;
   opt.storePressureC = o->p_c; opt.storeVelocityNonStaggeredC = o->u_non_staggered_c;
   opt.storeIntensityAvgC = o->i_avg_c; opt.noCompressionOverlap = o->no_overlap;
+  opt.storeIntensityAvg = o->i_avg; opt.storeQTerm = o->q_term; opt.storeQTermC = o->q_term_c;
   opt.period = o->period; opt.mos = o->mos ? o->mos : 1; opt.harmonics = o->harmonics ? o->harmonics : 1;
   opt.slabRanks = o->slab_ranks ? o->slab_ranks : 1;
   opt.slabRank  = o->slab_rank;
@@ -249,6 +250,14 @@ int kwh_stream_checkpoint(kwh_solver* s, const char* name, float* dst, uint64_t 
   KWH_TRY
   BaseOutputStream* st = s->solver->getOutputStreamContainer().find(name);
   if (!st) throw std::invalid_argument(std::string("no output stream named ") + name);
+  // streams kept out of the output (compression coefficients behind --Q_term_c) are state too: refuse rather than
+  // hand out a checkpoint that silently lacks them
+  for (const std::string& other : s->solver->getOutputStreamContainer().names(true))
+  {
+    BaseOutputStream* o = s->solver->getOutputStreamContainer().find(other);
+    if (o->doNotSave() && (o->reduceOp() == BaseOutputStream::ReduceOperator::kC || o->reduceOp() == BaseOutputStream::ReduceOperator::kIAvgC))
+      throw std::runtime_error("checkpointing of compression streams (" + other + ") is not implemented");
+  }
   std::vector<float> state;
   size_t sampled = 0;
   st->checkpointState(state, sampled);

@@ -39,7 +39,8 @@ class Options(C.Structure):
                [("period", C.c_float), ("mos", C.c_uint64), ("harmonics", C.c_uint64),
                 ("slab_ranks", C.c_uint64), ("slab_rank", C.c_uint64), ("nz_global", C.c_uint64),
                 ("exchange_fn", C.c_void_p), ("exchange_user", C.c_void_p),
-                ("exchange_start_fn", C.c_void_p), ("exchange_wait_fn", C.c_void_p), ("scratch", C.c_void_p * 6)]
+                ("exchange_start_fn", C.c_void_p), ("exchange_wait_fn", C.c_void_p), ("scratch", C.c_void_p * 6),
+                ("i_avg", C.c_int32), ("q_term", C.c_int32), ("q_term_c", C.c_int32), ("reserved_", C.c_int32)]
 
 
 _hlib: Optional[C.CDLL] = None

@@ -346,3 +346,44 @@ class Compressor:
             self.frames.append(frame)
             return frame
         return None
+
+
+# ---- post-processing of stored series (test oracle only; numpy, fp64 inside) ---------------------------------------
+def _signed_bins(n: int) -> np.ndarray:
+    """shift(i) = (i + n/2) % n - n/2 for the half spectrum i = 0..n/2 (KSpaceFirstOrderSolver.cpp:1257, :1907):
+    the Nyquist bin of an even length gets the negative frequency."""
+    i = np.arange(n // 2 + 1)
+    return ((i + n // 2) % n) - n // 2
+
+
+def time_shift_half_step(series: np.ndarray) -> np.ndarray:
+    """Sampled series [steps][points] advanced by half a time step through its spectrum along time
+    (computeAverageIntensities, KSpaceFirstOrderSolver.cpp:1253-1260, :1434-1449): X[k] *= exp(i*pi*shift(k)/steps),
+    unnormalised R2C / C2R pair with the 1/steps folded into the multiply."""
+    s = np.asarray(series, dtype=np.float64)
+    steps = s.shape[0]
+    kx = np.exp(1j * np.pi * _signed_bins(steps) / steps)
+    return np.fft.irfft(np.fft.rfft(s, axis=0) * kx[:, None], n=steps, axis=0)
+
+
+def average_intensity(p_series: np.ndarray, u_series: np.ndarray) -> np.ndarray:
+    """I_avg per sensor point: mean over the stored steps of p * (u shifted by half a step) (:1492-1513)."""
+    return (time_shift_half_step(u_series) * np.asarray(p_series, dtype=np.float64)).mean(axis=0)
+
+
+def q_term(ix, iy, iz, grid_index, dims, spacing) -> np.ndarray:
+    """Q = -(dIx/dx + dIy/dy + dIz/dz) at the sensor points (computeQTerm, :1783-2080): the intensities are scattered
+    into a zero grid (dims = (nx, ny, nz), grid_index = 0-based linear indices, x fastest), each is differentiated
+    spectrally along its own axis (multiply by i*2*pi/d*shift(k)/n, :1905-1921) and the sum is gathered back."""
+    nx, ny, nz = dims
+    idx = np.asarray(grid_index, dtype=np.int64).reshape(-1)
+    total = np.zeros(nx * ny * nz, dtype=np.float64)
+    for comp, (n, d, ax) in zip((ix, iy, iz), ((nx, spacing[0], 2), (ny, spacing[1], 1), (nz, spacing[2], 0))):
+        g = np.zeros(nx * ny * nz, dtype=np.float64)
+        g[idx] = np.asarray(comp, dtype=np.float64).reshape(-1)
+        g = g.reshape(nz, ny, nx)
+        k = 1j * (2.0 * np.pi / d) * _signed_bins(n) / n
+        shape = [1, 1, 1]
+        shape[ax] = n // 2 + 1
+        total += np.fft.irfft(np.fft.rfft(g, axis=ax) * k.reshape(shape), n=n, axis=ax).reshape(-1)
+    return -total[idx]

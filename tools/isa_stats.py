@@ -15,7 +15,7 @@ SRC = os.path.join(ROOT, "k-wave-fluid-cuda_amd", "csrc", "kw_fused.hip")
 
 def main():
     extra = sys.argv[1:]
-    out = "/tmp/kw_fused_isa.s"
+    out = os.environ.get("KW_ISA_OUT", "/tmp/kw_fused_isa.s")
     cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize", "--cuda-device-only",
            "-S", "-I" + os.path.join(ROOT, "include"), "-I" + os.path.dirname(SRC), SRC, "-o", out] + extra
     subprocess.check_call(cmd)

@@ -34,7 +34,11 @@ def main(n=256, reps=30):
     names[20] = "x-inverse + velocity epilogue pattern (15 units)"
     names[21], names[22], names[23] = "  same, arrays staggered by 4 KiB", "  same, staggered by 68 KiB", "  same, staggered by 1 MiB + 4 KiB"
     names[15], names[16] = "y tiles, 256-B segments: load + store", "z tiles, 256-B segments: load + store"
-    for which in (10, 11, 15, 12, 0, 13, 16, 14, 1, 2, 3, 20):
+    for w, nm in enumerate(("y tiles 128 B", "z tiles 128 B", "y tiles 256 B", "z tiles 256 B", "y tiles 128 B, XCD-grouped",
+                            "z tiles 128 B, XCD-grouped", "y tiles 256 B, XCD-grouped", "z tiles 256 B, XCD-grouped")):
+        names[30 + w] = "rt: " + nm
+    order = (10, 11, 15, 12, 0, 13, 16, 14, 1, 2, 3, 20) if n == 256 else (10, 0, 1, 2, 3)
+    for which in order + tuple(range(30, 38)):
         for _ in range(3):
             dev.call("fused_probe", which, big if which >= 20 else op)
         e0, e1 = dev.event(), dev.event()
