@@ -123,6 +123,8 @@ def run_distributed(args):
     dist.init_process_group(args.backend)
     rank, world = dist.get_rank(), dist.get_world_size()
     local_rank = int(os.environ.get("LOCAL_RANK", "0")) if args.backend == "nccl" else 0
+    if local_rank >= torch.cuda.device_count():
+        local_rank = 0  # the launcher narrowed the visible devices to this rank's GPU
     torch.cuda.set_device(local_rank)
     if args.strong:
         n = args.size or 512
