@@ -91,6 +91,10 @@ KWH_API int      kwh_set_matrix(kwh_solver* s, const char* name, const float* sr
 KWH_API int      kwh_set_time_index(kwh_solver* s, uint64_t t_index);
 KWH_API int      kwh_stream_count(kwh_solver* s, uint64_t* n);
 KWH_API int      kwh_stream_name(kwh_solver* s, uint64_t i, char* out, uint64_t cap);
+/* the same including the streams that only feed others and are not part of the output (the coefficient series behind
+ * --I_avg_c / --Q_term_c alone, the intensities behind --Q_term alone): a checkpoint has to carry those too */
+KWH_API int      kwh_stream_count_all(kwh_solver* s, uint64_t* n);
+KWH_API int      kwh_stream_name_all(kwh_solver* s, uint64_t i, char* out, uint64_t cap);
 /* dst == NULL: only the sizes are returned */
 KWH_API int      kwh_stream_checkpoint(kwh_solver* s, const char* name, float* dst, uint64_t cap, uint64_t* n_floats,
                                        uint64_t* sampled_steps);

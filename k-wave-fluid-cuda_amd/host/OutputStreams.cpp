@@ -237,7 +237,43 @@ void CompressedIndexOutputStream::postSample2()
   mCurrent = nullptr;
 }
 
+void CompressedIndexOutputStream::checkpointState(std::vector<float>& state, size_t& sampledSteps)
+{ // taken between steps: the frame finished by the last sampled step has already been emitted (postSample2)
+  state = mDataset;
+  const size_t frames = state.size();
+  const int    nacc   = (mC2 == mC1) ? 1 : 2;
+  state.resize(frames + nacc * mSize);
+  kwCheck(kw_memcpy_d2h(ctx(), state.data() + frames, mC1, mSize * sizeof(float)));
+  if (nacc == 2) kwCheck(kw_memcpy_d2h(ctx(), state.data() + frames + mSize, mC2, mSize * sizeof(float)));
+  sampledSteps = mSampledSteps;
+}
+void CompressedIndexOutputStream::restoreState(const float* state, size_t n, size_t sampledSteps)
+{
+  const size_t nacc = (mC2 == mC1) ? 1 : 2;
+  if (n < nacc * mSize || (n - nacc * mSize) % mSize != 0)
+    throw std::invalid_argument("checkpoint of stream " + mName + " has the wrong size");
+  const size_t frames = n - nacc * mSize;
+  mDataset.assign(state, state + frames);
+  mCompressedTimeStep = mFlushedSteps = frames / mSize;
+  kwCheck(kw_memcpy_h2d(ctx(), mC1, state + frames, mSize * sizeof(float)));
+  if (nacc == 2) kwCheck(kw_memcpy_h2d(ctx(), mC2, state + frames + mSize, mSize * sizeof(float)));
+  mSampledSteps = sampledSteps;
+  mCurrent      = nullptr;
+}
+
 // ---- IntensityAvgCOutputStream --------------------------------------------------------------------------------------
+void IntensityAvgCOutputStream::checkpointState(std::vector<float>& state, size_t& sampledSteps)
+{
+  state.resize(mSize);
+  kwCheck(kw_memcpy_d2h(ctx(), state.data(), mDeviceBuffer, mSize * sizeof(float)));
+  sampledSteps = mCompressedTimeStep;
+}
+void IntensityAvgCOutputStream::restoreState(const float* state, size_t n, size_t sampledSteps)
+{
+  if (n != mSize) throw std::invalid_argument("checkpoint of stream " + mName + " has the wrong size");
+  kwCheck(kw_memcpy_h2d(ctx(), mDeviceBuffer, state, mSize * sizeof(float)));
+  mCompressedTimeStep = sampledSteps;
+}
 void IntensityAvgCOutputStream::create()
 {
   mSize = mP.points();

@@ -106,6 +106,9 @@ class CompressedIndexOutputStream : public BaseOutputStream
   void postSample2();           // emit the finished frame, zero its accumulator (BaseOutputStream.cpp:117-132)
   /// device buffer holding the frame finished at this sampled step, or nullptr (getCurrentStoreBuffer)
   const float* getCurrentStoreBuffer() const { return mCurrent; }
+  /// state = frames stored so far, then the accumulators c1 (and c2 unless --no_overlap); steps = sampled steps
+  void checkpointState(std::vector<float>& state, size_t& sampledSteps) override;
+  void restoreState(const float* state, size_t n, size_t sampledSteps) override;
   size_t frames() const { return mCompressedTimeStep; }
   size_t points() const { return mSensorMask.size(); }
 
@@ -133,6 +136,9 @@ class IntensityAvgCOutputStream : public BaseOutputStream
   void sample() override {}
   void postSample();
   void postProcess() override;
+  /// state = the running sum; steps = number of frames added so far
+  void checkpointState(std::vector<float>& state, size_t& sampledSteps) override;
+  void restoreState(const float* state, size_t n, size_t sampledSteps) override;
 
  private:
   const CompressedIndexOutputStream& mP;

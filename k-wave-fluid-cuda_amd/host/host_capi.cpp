@@ -245,19 +245,27 @@ int kwh_stream_name(kwh_solver* s, uint64_t i, char* out, uint64_t cap)
   KWH_CATCH
 }
 
+int kwh_stream_count_all(kwh_solver* s, uint64_t* n)
+{
+  KWH_TRY
+  *n = s->solver->getOutputStreamContainer().names(true).size();
+  KWH_CATCH
+}
+
+int kwh_stream_name_all(kwh_solver* s, uint64_t i, char* out, uint64_t cap)
+{
+  KWH_TRY
+  const std::vector<std::string> names = s->solver->getOutputStreamContainer().names(true);
+  if (i >= names.size() || names[i].size() + 1 > cap) throw std::invalid_argument("kwh_stream_name_all: bad index or buffer");
+  std::memcpy(out, names[i].c_str(), names[i].size() + 1);
+  KWH_CATCH
+}
+
 int kwh_stream_checkpoint(kwh_solver* s, const char* name, float* dst, uint64_t cap, uint64_t* n_floats, uint64_t* steps)
 {
   KWH_TRY
   BaseOutputStream* st = s->solver->getOutputStreamContainer().find(name);
   if (!st) throw std::invalid_argument(std::string("no output stream named ") + name);
-  // streams kept out of the output (compression coefficients behind --Q_term_c) are state too: refuse rather than
-  // hand out a checkpoint that silently lacks them
-  for (const std::string& other : s->solver->getOutputStreamContainer().names(true))
-  {
-    BaseOutputStream* o = s->solver->getOutputStreamContainer().find(other);
-    if (o->doNotSave() && (o->reduceOp() == BaseOutputStream::ReduceOperator::kC || o->reduceOp() == BaseOutputStream::ReduceOperator::kIAvgC))
-      throw std::runtime_error("checkpointing of compression streams (" + other + ") is not implemented");
-  }
   std::vector<float> state;
   size_t sampled = 0;
   st->checkpointState(state, sampled);

@@ -72,6 +72,8 @@ def load_host() -> C.CDLL:
         L.kwh_set_time_index.argtypes = [C.c_void_p, C.c_uint64]
         L.kwh_stream_count.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
         L.kwh_stream_name.argtypes = [C.c_void_p, C.c_uint64, C.c_char_p, C.c_uint64]
+        L.kwh_stream_count_all.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
+        L.kwh_stream_name_all.argtypes = [C.c_void_p, C.c_uint64, C.c_char_p, C.c_uint64]
         L.kwh_stream_checkpoint.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64),
                                             C.POINTER(C.c_uint64)]
         L.kwh_stream_restore.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_uint64, C.c_uint64]
@@ -198,13 +200,16 @@ class HostSolver:
     # ---- checkpoint / restart through the plain host API (the HDF5 checkpoint file is h5io.FileSolver's) ----
     CHECKPOINT_MATRICES = ("p", "rhox", "rhoy", "rhoz", "ux_sgx", "uy_sgy", "uz_sgz")
 
-    def stream_names(self):
+    def stream_names(self, include_hidden: bool = False):
+        """Streams of the output; include_hidden adds those that only feed others (e.g. p_c behind --Q_term_c alone)."""
+        count, name = (self.L.kwh_stream_count_all, self.L.kwh_stream_name_all) if include_hidden else \
+                      (self.L.kwh_stream_count, self.L.kwh_stream_name)
         n = C.c_uint64()
-        _check(self.L.kwh_stream_count(self._h, C.byref(n)))
+        _check(count(self._h, C.byref(n)))
         out = []
         for i in range(n.value):
             buf = C.create_string_buffer(128)
-            _check(self.L.kwh_stream_name(self._h, i, buf, 128))
+            _check(name(self._h, i, buf, 128))
             out.append(buf.value.decode())
         return out
 
@@ -213,7 +218,7 @@ class HostSolver:
         st = {"t_index": self.t, "matrices": {}, "streams": {}}
         for name in self.CHECKPOINT_MATRICES:
             st["matrices"][name] = self.field(name).copy()
-        for name in self.stream_names():
+        for name in self.stream_names(include_hidden=True):
             n, steps = C.c_uint64(), C.c_uint64()
             _check(self.L.kwh_stream_checkpoint(self._h, name.encode(), None, 0, C.byref(n), C.byref(steps)))
             a = np.empty(n.value, dtype=np.float32)

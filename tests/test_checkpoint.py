@@ -114,3 +114,36 @@ def test_command_line_checkpoint_legs(h5io, syn, tmp_path):
         assert os.path.exists(out2) == (leg == 2)
     for name in ("p", "p_max", "ux_rms", "uz_rms", "p_final"):
         assert np.array_equal(h5io.read_dataset(out2, name), h5io.read_dataset(out1, name)), name
+
+
+@pytest.mark.parametrize("opts,names", [
+    (dict(p_c=1, u_non_staggered_c=1, i_avg_c=1), ("p_c", "ux_non_staggered_c", "Ix_avg_c", "Iz_avg_c")),
+    (dict(q_term_c=1, no_overlap=1), ("Q_term_c",)),          # every compression stream hidden behind the Q term
+    (dict(i_avg=1, q_term=1), ("p", "uy_non_staggered", "Iy_avg", "Q_term")),
+])
+@pytest.mark.parametrize("split", [37, 64])
+def test_restart_with_compression_and_post_processed_streams(syn, opts, names, split):
+    """The accumulators of the compression streams (c1 / c2, frames so far, the running I_avg_c sum) and the series
+    behind --I_avg / --Q_term are part of the checkpoint, including the streams that are not part of the output."""
+    from kwave_amd.solver import HostSolver
+    nt = 130
+    pr = syn.make_problem(32, heterogeneous=True, nonlinear=False, absorbing=False, source="p_source", source_mode=1,
+                          nt=nt, pml_size=4, sensor="random")
+    dt = float(pr["dt"].ravel()[0])
+    kw = dict(opts, period=1.0 / (1.0e6 * dt), mos=1, harmonics=2) if any(k.endswith("_c") for k in opts) else dict(opts)
+    ref = HostSolver(pr, **kw)
+    ref.run(nt)
+    ref.finish()
+    a = HostSolver(pr, **kw)
+    a.run(split)
+    state = a.checkpoint_state()
+    assert set(a.stream_names()) <= set(state["streams"]) == set(a.stream_names(include_hidden=True))
+    a.close()
+    b = HostSolver(pr, **kw)
+    b.restore_state(state)
+    b.run(nt - split)
+    b.finish()
+    for s in names:
+        assert ref.stream(s).size > 0 and np.array_equal(b.stream(s), ref.stream(s)), s
+    b.close()
+    ref.close()
