@@ -70,7 +70,7 @@ void KSpaceFirstOrderSolver::initializeFftPlans()
   {
     HipFftComplexMatrix::createR2CFftPlan1DX(dims);
     HipFftComplexMatrix::createR2CFftPlan1DY(dims);
-    HipFftComplexMatrix::createR2CFftPlan1DZ(dims);
+    if (mParameters.isSimulation3D()) HipFftComplexMatrix::createR2CFftPlan1DZ(dims);
   }
 }
 
@@ -293,7 +293,7 @@ void KSpaceFirstOrderSolver::computeAverageIntensities()
   {
     const size_t n = std::min(block, points - first);
     upload(ps->dataset(), first, n, dP.f());
-    for (int a = 0; a < 3; a++)
+    for (int a = 0; a < (mParameters.isSimulation3D() ? 3 : 2); a++)
     {
       BaseOutputStream* us = mOutputStreamContainer.get(ui[a]);
       auto* is = dynamic_cast<PostProcessedOutputStream*>(mOutputStreamContainer.get(ii[a]));
@@ -324,7 +324,8 @@ void KSpaceFirstOrderSolver::computeQTerm(OutputStreamContainer::OutputStreamIdx
   const float  pi2 = static_cast<float>(M_PI) * 2.0f;
   const size_t n[3] = {dims.nx, dims.ny, dims.nz};
   const float  d[3] = {mParameters.getDx(), mParameters.getDy(), mParameters.getDz()};
-  for (int a = 0; a < 3; a++)
+  const int    axes = mParameters.isSimulation3D() ? 3 : 2;
+  for (int a = 0; a < axes; a++)
   {
     BaseOutputStream* is = mOutputStreamContainer.get(ii[a]);
     if (is == nullptr || is->dataset().size() != where.size()) throw std::runtime_error("computeQTerm: intensity stream missing");
@@ -347,7 +348,7 @@ void KSpaceFirstOrderSolver::computeQTerm(OutputStreamContainer::OutputStreamIdx
     kwCheck(kw_fft_c2r_1d(ctx, a, tempShift.getDeviceData(), grid[a]->getDeviceData()));
   }
   kwCheck(kw_q_term_sum(ctx, grid[0]->getDeviceData(), grid[0]->getDeviceData(), grid[1]->getDeviceData(),
-                        grid[2]->getDeviceData(), dims.nElements()));
+                        (axes == 3) ? grid[2]->getDeviceData() : nullptr, dims.nElements()));
   grid[0]->copyFromDevice();
   const float* host = grid[0]->getHostData();
   for (size_t i = 0; i < where.size(); i++) q->data()[i] = host[where[i]];
@@ -624,6 +625,7 @@ template<SD sd> void KSpaceFirstOrderSolver::computeShiftedVelocity()
   tempShift.computeR2CFft1DY(real(MI::kUySgy));
   SolverHipKernels::computeVelocityShiftInY(tempShift, mMatrixContainer.getMatrix<ComplexMatrix>(MI::kYShiftNegR));
   tempShift.computeC2RFft1DY(real(MI::kUyShifted));
+  if (!mParameters.isSimulation3D()) return; // SD::k2D instantiation: x and y only (:2714-2735)
   tempShift.computeR2CFft1DZ(real(MI::kUzSgz));
   SolverHipKernels::computeVelocityShiftInZ(tempShift, mMatrixContainer.getMatrix<ComplexMatrix>(MI::kZShiftNegR));
   tempShift.computeC2RFft1DZ(real(MI::kUzShifted));

@@ -123,10 +123,11 @@ void MatrixContainer::init()
     mContainer[MI::kTempHipFftShift].set(MT::kFft, shiftDims, kNoLoad, kNoCheckpoint, "hipfft_shift_temp");
     mContainer[MI::kUxShifted].set(MT::kReal, fullDims, kNoLoad, kNoCheckpoint, "ux_shifted");
     mContainer[MI::kUyShifted].set(MT::kReal, fullDims, kNoLoad, kNoCheckpoint, "uy_shifted");
-    mContainer[MI::kUzShifted].set(MT::kReal, fullDims, kNoLoad, kNoCheckpoint, "uz_shifted");
+    if (params.isSimulation3D()) mContainer[MI::kUzShifted].set(MT::kReal, fullDims, kNoLoad, kNoCheckpoint, "uz_shifted");
     mContainer[MI::kXShiftNegR].set(MT::kComplex, DimensionSizes(nxR, 1, 1), kLoad, kNoCheckpoint, kXShiftNegRName);
     mContainer[MI::kYShiftNegR].set(MT::kComplex, DimensionSizes(1, nyR, 1), kLoad, kNoCheckpoint, kYShiftNegRName);
-    mContainer[MI::kZShiftNegR].set(MT::kComplex, DimensionSizes(1, 1, nzR), kLoad, kNoCheckpoint, kZShiftNegRName);
+    if (params.isSimulation3D())
+      mContainer[MI::kZShiftNegR].set(MT::kComplex, DimensionSizes(1, 1, nzR), kLoad, kNoCheckpoint, kZShiftNegRName);
   }
 
   // ---- temporaries (MatrixContainer.cpp:387-410): alpha_coeff is loaded *into* Temp1 ----

@@ -383,7 +383,7 @@ void OutputStreamContainer::init(MatrixContainer& mc)
     {
       mContainer[OI::kVelocityXNonStaggeredRaw] = createOutputStream(mc, MI::kUxShifted, kUxNonStaggeredName, RO::kNone);
       mContainer[OI::kVelocityYNonStaggeredRaw] = createOutputStream(mc, MI::kUyShifted, kUyNonStaggeredName, RO::kNone);
-      mContainer[OI::kVelocityZNonStaggeredRaw] = createOutputStream(mc, MI::kUzShifted, kUzNonStaggeredName, RO::kNone);
+      if (is3D) mContainer[OI::kVelocityZNonStaggeredRaw] = createOutputStream(mc, MI::kUzShifted, kUzNonStaggeredName, RO::kNone);
     }
     struct Agg { bool on; RO op; const char* suffix; OI x, y, z; };
     const Agg aggs[] = {
@@ -407,7 +407,7 @@ void OutputStreamContainer::init(MatrixContainer& mc)
     {
       mContainer[OI::kVelocityXNonStaggeredRaw] = createOutputStream(mc, MI::kUxShifted, kUxNonStaggeredName, RO::kNone);
       mContainer[OI::kVelocityYNonStaggeredRaw] = createOutputStream(mc, MI::kUyShifted, kUyNonStaggeredName, RO::kNone);
-      mContainer[OI::kVelocityZNonStaggeredRaw] = createOutputStream(mc, MI::kUzShifted, kUzNonStaggeredName, RO::kNone);
+      if (is3D) mContainer[OI::kVelocityZNonStaggeredRaw] = createOutputStream(mc, MI::kUzShifted, kUzNonStaggeredName, RO::kNone);
     }
     const bool cuboid = !mc.has(MI::kSensorMaskIndex);
     const IndexMatrix& points = mc.getMatrix<IndexMatrix>(cuboid ? MI::kSensorMaskCorners : MI::kSensorMaskIndex);
@@ -415,7 +415,7 @@ void OutputStreamContainer::init(MatrixContainer& mc)
     const RealMatrix& pm = mc.getMatrix<RealMatrix>(MI::kP);
     mContainer[OI::kIntensityXAvg] = new PostProcessedOutputStream("Ix_avg", pm, RO::kIAvg, points, cuboid, hide);
     mContainer[OI::kIntensityYAvg] = new PostProcessedOutputStream("Iy_avg", pm, RO::kIAvg, points, cuboid, hide);
-    mContainer[OI::kIntensityZAvg] = new PostProcessedOutputStream("Iz_avg", pm, RO::kIAvg, points, cuboid, hide);
+    if (is3D) mContainer[OI::kIntensityZAvg] = new PostProcessedOutputStream("Iz_avg", pm, RO::kIAvg, points, cuboid, hide);
     if (params.getStoreQTermFlag()) mContainer[OI::kQTerm] = new PostProcessedOutputStream("Q_term", pm, RO::kQTerm, points, cuboid);
   }
   // ---- compression streams (OutputStreamContainer.cpp:92-96,157-168,272-321); index masks only ----
@@ -429,7 +429,7 @@ void OutputStreamContainer::init(MatrixContainer& mc)
     {
       mContainer[OI::kVelocityXNonStaggeredC] = new CompressedIndexOutputStream(kUxNonStaggeredName + "_c", mc.getMatrix<RealMatrix>(MI::kUxShifted), mask, true);
       mContainer[OI::kVelocityYNonStaggeredC] = new CompressedIndexOutputStream(kUyNonStaggeredName + "_c", mc.getMatrix<RealMatrix>(MI::kUyShifted), mask, true);
-      mContainer[OI::kVelocityZNonStaggeredC] = new CompressedIndexOutputStream(kUzNonStaggeredName + "_c", mc.getMatrix<RealMatrix>(MI::kUzShifted), mask, true);
+      if (is3D) mContainer[OI::kVelocityZNonStaggeredC] = new CompressedIndexOutputStream(kUzNonStaggeredName + "_c", mc.getMatrix<RealMatrix>(MI::kUzShifted), mask, true);
     }
     if (wantIAvgC)
     {
@@ -437,7 +437,8 @@ void OutputStreamContainer::init(MatrixContainer& mc)
       const OI us[3] = {OI::kVelocityXNonStaggeredC, OI::kVelocityYNonStaggeredC, OI::kVelocityZNonStaggeredC};
       const OI is[3] = {OI::kIntensityXAvgC, OI::kIntensityYAvgC, OI::kIntensityZAvgC};
       const char* names[3] = {"Ix_avg_c", "Iy_avg_c", "Iz_avg_c"};
-      for (int a = 0; a < 3; a++)
+      const int axes = is3D ? 3 : 2;
+      for (int a = 0; a < axes; a++)
       {
         mContainer[is[a]] = new IntensityAvgCOutputStream(names[a], mc.getMatrix<RealMatrix>(MI::kP), pc,
                                                           *static_cast<CompressedIndexOutputStream*>(mContainer[us[a]]));
@@ -446,7 +447,7 @@ void OutputStreamContainer::init(MatrixContainer& mc)
       // coefficient series that only feed the intensities are not part of the output (:274-292: doNotSaveFlag)
       if (!params.getStorePressureCFlag()) mContainer[OI::kPressureC]->setDoNotSave(true);
       if (!params.getStoreVelocityNonStaggeredCFlag())
-        for (int a = 0; a < 3; a++) mContainer[us[a]]->setDoNotSave(true);
+        for (int a = 0; a < axes; a++) mContainer[us[a]]->setDoNotSave(true);
       if (params.getStoreQTermCFlag())
         mContainer[OI::kQTermC] = new PostProcessedOutputStream("Q_term_c", mc.getMatrix<RealMatrix>(MI::kP), RO::kQTermC, mask, false);
     }

@@ -42,8 +42,6 @@ void Parameters::init(const InputProvider& in, const Options& options)
   { // 2-D (Nz == 1): what this build carries over from the 3-D path; the rest says so instead of computing nonsense
     if (z != 1 || isSlabDecomposed())
       throw std::invalid_argument("2-D simulations need Nz == 1 and a single GPU");
-    if (needsShiftedVelocity())
-      throw std::invalid_argument("2-D simulations: non-staggered velocity / compression / intensity streams are not implemented");
   }
 
   in.readScalarValue(kNtName, mNt);

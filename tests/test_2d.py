@@ -98,9 +98,42 @@ def test_gpu_2d_closed_form_and_rejections(syn):
     g.run(101)
     assert rel_l2(g.field("p"), closed_form_pressure(complete_2d(pr), 100)) < TOL
     g.close()
-    # what the 2-D path does not carry says so
-    with pytest.raises(capi.KWaveError):
-        HostSolver(pr, u_non_staggered_raw=1)
+
+
+@pytest.mark.gpu
+def test_gpu_2d_non_staggered_compression_and_intensity_streams(orc, syn):
+    """2-D runs carry the x / y members of the non-staggered, compression and intensity streams (no z member), and the
+    Q term is the 2-D divergence (KSpaceFirstOrderSolver.cpp:2714-2735 k2D, :2014-2026)."""
+    from kwave_amd.solver import HostSolver
+    nt = 130
+    pr = problem2d(syn, 48, 32, heterogeneous=True, nonlinear=False, absorbing=False, source="p_source", source_mode=1, nt=nt)
+    dt = float(pr["dt"].ravel()[0])
+    g = HostSolver(pr, u_non_staggered_raw=1, i_avg=1, q_term=1, i_avg_c=1, q_term_c=1, period=1.0 / (1.0e6 * dt),
+                   mos=1, harmonics=2)
+    g.run(nt)
+    g.finish()
+    names = g.stream_names()
+    for nm in ("p", "ux_non_staggered", "uy_non_staggered", "Ix_avg", "Iy_avg", "Q_term", "Ix_avg_c", "Iy_avg_c", "Q_term_c"):
+        assert nm in names, (nm, names)
+    assert not [nm for nm in g.stream_names(include_hidden=True) if "z" in nm]
+    mask = pr["sensor_mask_index"].reshape(-1).astype(np.int64) - 1
+    for axis, nm in enumerate(("ux", "uy")):
+        shifted = orc.shifted_velocity(g.field(nm), pr["xy"[axis] + "_shift_neg_r"], axis)
+        assert rel_l2(g.field(nm + "_shifted"), shifted) < TOL
+        assert np.array_equal(g.stream(nm + "_non_staggered")[-1], g.field(nm + "_shifted").reshape(-1)[mask])
+    p = g.stream("p").reshape(nt, -1)
+    dims = (48, 32, 1)
+    spacing = tuple(float(pr[k].ravel()[0]) for k in ("dx", "dy", "dz"))
+    for suffix in ("", "_c"):
+        inten = [g.stream(f"I{a}_avg{suffix}").reshape(-1) for a in "xy"]
+        if suffix == "":
+            for a, got in zip("xy", inten):
+                ref = orc.average_intensity(p, g.stream(f"u{a}_non_staggered").reshape(nt, -1))
+                assert np.abs(got - ref).max() < 1e-5 * np.abs(ref).max()
+        ref = orc.q_term(inten[0], inten[1], 0 * inten[0], mask, dims, spacing)
+        assert np.abs(ref).max() > 0
+        assert np.abs(g.stream("Q_term" + suffix).reshape(-1) - ref).max() < 1e-5 * np.abs(ref).max()
+    g.close()
 
 
 @pytest.mark.gpu
