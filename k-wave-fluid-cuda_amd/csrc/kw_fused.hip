@@ -760,6 +760,7 @@ struct XinvArgs
   float2*       fout[3]; // CHAIN: where the forward x-transform of the epilogue's result goes (scratch rows)
   uint32_t      tile0;   // first 2*NL-row tile of this launch (chunked plane-local passes)
   const float2* mulx[3]; // per component: optional factor mulx[kx] applied to the rows before the inverse (ddx of the gradient)
+  uint32_t      descending; // tiles (and components) are taken from the last to the first (experiment: KW_FUSED_XINV_DESC)
 };
 
 // standalone inverse of one array for this block's 32 rows; thread (c, f<R1) ends with x[f + R1*k2] of rows (2c, 2c+1)
@@ -858,8 +859,9 @@ __global__ __launch_bounds__(Geo<L>::THREADS, (EPI == EPI_DENSITY && L == 256) ?
   float* ldsr = reinterpret_cast<float*>(lds);
   const int f = threadIdx.x % G::TPL;
   const int c = threadIdx.x / G::TPL;
-  const uint32_t comp = (NA == 1) ? blockIdx.y + a.comp0 : 0; // component / array index for single-array epilogues
-  const uint32_t tile = blockIdx.x + a.tile0;
+  const uint32_t by   = a.descending ? gridDim.y - 1u - blockIdx.y : blockIdx.y;
+  const uint32_t comp = (NA == 1) ? by + a.comp0 : 0; // component / array index for single-array epilogues
+  const uint32_t tile = (a.descending ? gridDim.x - 1u - blockIdx.x : blockIdx.x) + a.tile0;
   float4 res[NA][NQ];
   constexpr int NF = CHAIN ? ((EPI == EPI_DENSITY) ? 2 : 1) : 1; // chained forward transforms
   // rows to chain: kept in registers, except the first of the density epilogue's two, which goes straight into the
@@ -1460,6 +1462,7 @@ kw_status launch_xinv(kw_ctx* ctx, int ncomp, XinvArgs a, uint32_t z0 = 0, uint3
   a.c  = c;
   a.P  = ctx->fused.P;
   a.tile0 = z0 * c.ny / (2 * nl_of(c.nx));
+  a.descending = ctx->fused.xinv_desc ? 1u : 0u;
   const dim3 grid(c.ny * (nzc ? nzc : c.nz) / (2 * nl_of(c.nx)), ncomp, 1);
 #define M(LEN) LAUNCH((k_xinv<LEN, EPI, CHAIN, TERMS>), grid, dim3(Geo<LEN>::THREADS), a)
   KW_LEN_SWITCH(c.nx, M)
@@ -1655,6 +1658,8 @@ kw_status create_impl(kw_ctx* ctx, void* const s[3], void* const t[3])
     f.per_array   = (e != nullptr) && (e[0] != '0');
     e             = getenv("KW_FUSED_ZCHUNKS");
     f.zchunks     = (e != nullptr && atoi(e) > 0) ? static_cast<uint32_t>(atoi(e)) : 1u;
+    e             = getenv("KW_FUSED_XINV_DESC");
+    f.xinv_desc   = (e != nullptr && atoi(e) != 0);
     e             = getenv("KW_FUSED_SPLIT512");
     f.split512    = (e == nullptr) || (e[0] != '0');
     e             = getenv("KW_FUSED_YPASS_LOOP");
