@@ -119,16 +119,19 @@ template<int L, int DIR> __device__ __forceinline__ void step_a(float2 (&v)[Fac<
 // =====================================================================================================================
 // Row addressing of a y-line element.  Natural layout: row(z, ky) = z*ny + ky.  Packed layout (slab mode, the send /
 // receive side of the all-to-all): row(z, ky) = ((ky / nyl) * nzl + z) * nyl + ky % nyl, i.e. one contiguous chunk
-// [nzl][nyl][P] per peer rank.  Both are  (ky >> sh) * qstride + (ky & mask) + z * zmul ; with one rank they coincide.
+// [nzl][nyl][P] per peer rank.  Both are  q * qstride + (ky - q * nyl) + z * zmul  with q = ky / nyl taken as
+// (ky * magic) >> 20, magic = 2^20 / nyl + 1: exact while ky * nyl < 2^20 (lines have at most 640 elements); the natural
+// layout has magic = 0, hence q = 0.
 struct RowAddr
 {
-  uint32_t sh, mask, qstride, zmul;
+  uint32_t magic, nyl, qstride, zmul;
   uint32_t estride; // 1 for y-lines; ny for lines along z (probe / plain z transform)
   // 32-bit element indices throughout the pipeline: every scratch / field array has < 2^32 elements (checked in
   // kw_fused_supported), so addresses are "uniform base + 32-bit lane offset" and need no 64-bit VALU arithmetic
   __device__ __forceinline__ uint32_t row(uint32_t z, uint32_t ky) const
   {
-    return (ky >> sh) * qstride + (ky & mask) * estride + z * zmul;
+    const uint32_t q = (ky * magic) >> 20;
+    return q * qstride + (ky - q * nyl) * estride + z * zmul;
   }
 };
 
@@ -1389,10 +1392,8 @@ kw_status launch_ypass(kw_ctx* ctx, int dir, int narr, float2* const* in, float2
   a.nxc = c.nx_complex;
   a.P   = f.P;
   a.PX  = f.PX;
-  uint32_t sh = 0;
-  while ((1u << sh) < f.nyl) sh++;
-  const RowAddr natural{31u, 0xffffffffu, 0u, c.ny, 1u};
-  const RowAddr packed{sh, f.nyl - 1u, c.nz * f.nyl, f.nyl, 1u};
+  const RowAddr natural{0u, 0u, 0u, c.ny, 1u};
+  const RowAddr packed{(1u << 20) / f.nyl + 1u, f.nyl, c.nz * f.nyl, f.nyl, 1u};
   a.ain  = pack_in ? packed : natural;
   a.aout = pack_out ? packed : natural;
   a.narr = f.ypass_loop ? narr : 1;
@@ -1706,11 +1707,7 @@ kw_status kw_fused_supported(kw_ctx* ctx, int* out)
   const auto& f         = ctx->fused;
   const uint32_t nzg    = (f.slab) ? f.nz_global : c.nz;
   bool ok = supported_len(c.nx) && supported_len(c.ny) && supported_len(nzg) && ((c.ny * c.nz) % (2 * NLMAX) == 0);
-  if (f.slab)
-  { // the packed (exchange-side) row addressing splits ky with a shift and a mask: power-of-two ky chunk per rank
-    const uint32_t nyl = c.ny / f.nranks;
-    ok = ok && (nzg == c.nz * f.nranks) && (c.ny % f.nranks == 0) && ((nyl & (nyl - 1u)) == 0);
-  }
+  if (f.slab) ok = ok && (nzg == c.nz * f.nranks) && (c.ny % f.nranks == 0);
   const uint64_t P64 = (c.nx_complex + NLMAX - 1) / NLMAX * NLMAX;
   ok = ok && (P64 * c.ny * c.nz < (1ull << 32)) && (static_cast<uint64_t>(c.nx) * c.ny * c.nz < (1ull << 32));
   *out = ok ? 1 : 0;
@@ -2004,7 +2001,7 @@ kw_status kw_fused_probe(kw_ctx* ctx, int which, const float* op)
     a.nxc = c.nx_complex;
     a.P   = f.P;
     a.narr = 1;
-    a.ain = a.aout = RowAddr{31u, 0xffffffffu, 0u, 1u, c.ny}; // element k of line (ky = blockIdx.y): row k*ny + ky
+    a.ain = a.aout = RowAddr{0u, 0u, 0u, 1u, c.ny}; // element k of line (ky = blockIdx.y): row k*ny + ky
     const dim3 grid(f.P / nl_of(c.nz), c.ny, 1);
 #define M(LEN) LAUNCH((k_ypass<LEN, kFwd, false, false>), grid, dim3(Geo<LEN>::THREADS), a)
     KW_LEN_SWITCH(c.nz, M)
@@ -2024,7 +2021,7 @@ kw_status kw_fused_probe(kw_ctx* ctx, int which, const float* op)
     a.out[0] = f.s[0];
     a.nxc = c.nx_complex;
     a.P   = f.P;
-    a.ain = (which <= 12) ? RowAddr{31u, 0xffffffffu, 0u, c.ny, 1u} : RowAddr{31u, 0xffffffffu, 0u, 1u, c.ny};
+    a.ain = (which <= 12) ? RowAddr{0u, 0u, 0u, c.ny, 1u} : RowAddr{0u, 0u, 0u, 1u, c.ny};
     const dim3 grid(f.P / nl_of(c.ny), c.nz, 1);
 #define M(LEN)                                                                                                         \
   if (which & 1) LAUNCH((k_probe_tile<LEN, 0>), grid, dim3(Geo<LEN>::THREADS), a);                                    \
@@ -2040,7 +2037,7 @@ kw_status kw_fused_probe(kw_ctx* ctx, int which, const float* op)
     a.out[0] = f.s[0];
     a.nxc = c.nx_complex;
     a.P   = f.P;
-    a.ain = (which == 15) ? RowAddr{31u, 0xffffffffu, 0u, c.ny, 1u} : RowAddr{31u, 0xffffffffu, 0u, 1u, c.ny};
+    a.ain = (which == 15) ? RowAddr{0u, 0u, 0u, c.ny, 1u} : RowAddr{0u, 0u, 0u, 1u, c.ny};
     LAUNCH((k_probe_tile_wide<256>), dim3((f.P + 31) / 32, c.nz, 1), dim3(256), a);
     return KW_OK;
   }
@@ -2052,7 +2049,7 @@ kw_status kw_fused_probe(kw_ctx* ctx, int which, const float* op)
     a.out[0] = f.s[0];
     a.nxc = c.nx_complex;
     a.P   = f.P;
-    a.ain = (w & 1) ? RowAddr{31u, 0xffffffffu, 0u, 1u, c.ny} : RowAddr{31u, 0xffffffffu, 0u, c.ny, 1u};
+    a.ain = (w & 1) ? RowAddr{0u, 0u, 0u, 1u, c.ny} : RowAddr{0u, 0u, 0u, c.ny, 1u};
     const int  vec = (w & 2) ? 2 : 1;
     const dim3 grid((f.P + 16 * vec - 1) / (16 * vec), c.nz, 1);
     KW_REQUIRE(!(w & 4) || (grid.x * grid.y) % 8 == 0);

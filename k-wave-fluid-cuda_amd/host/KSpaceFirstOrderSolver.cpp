@@ -55,7 +55,7 @@ void KSpaceFirstOrderSolver::initializeFftPlans()
     kwCheck(kw_fused_supported(ctx, &fusedOk));
   mFused = (fusedOk != 0);
   if (mParameters.isSlabDecomposed() && !mFused)
-    throw std::invalid_argument("Z-slab decomposition needs the fused pipeline (supported line lengths, Nz divisible by the rank count, power-of-two Ny per rank)");
+    throw std::invalid_argument("Z-slab decomposition needs the fused pipeline (supported line lengths; Ny and Nz divisible by the rank count)");
   if (mFused)
   { // hand-written FFT passes: no library plans needed for the 3-D transforms
     if (opt.scratch[0] != nullptr) kwCheck(kw_fused_create_with_scratch(ctx, opt.scratch, opt.scratch + 3));

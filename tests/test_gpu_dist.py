@@ -33,6 +33,8 @@ def run_ranks(world, dims, steps, source, mode, tmp_path, backend="gloo", medium
     (2, (64, 32, 16), "u_source", 1),
     (2, (16, 512, 16), "p0", 0),        # 512-point y lines (2 x 256 kernels) with packed per-peer addressing
     (2, (16, 16, 512), "p0", 0),        # 512-point z lines on the transposed spectra
+    (2, (48, 96, 80), "p0", 0),         # radix-3 / radix-5 lines; 48 ky rows per rank (no power of two)
+    (4, (32, 120, 48), "p_source", 2),  # 30 ky rows, 12 planes per rank
 ])
 def test_slab_ranks_match_oracle(orc, syn, tmp_path, world, dims, source, mode):
     steps = 20
