@@ -55,7 +55,10 @@ typedef struct kwh_options
   void*    scratch[6]; /* optional caller-owned pipeline scratch (kw_fused_create_with_scratch), else all NULL */
   /* post-processed quantities (--I_avg, --Q_term, --Q_term_c; KSpaceFirstOrderSolver.cpp:977-1024): time-averaged
    * intensity from the stored p / u_non_staggered series, and Q = -div(I_avg) from it or from the compressed one */
-  int32_t  i_avg, q_term, q_term_c, reserved_;
+  int32_t  i_avg, q_term, q_term_c;
+  int32_t  u_c;        /* --u_c: compression coefficients of the staggered velocities (OutputStreamContainer.cpp:133-142) */
+  float    frequency;  /* --frequency [Hz]: period = 1 / (frequency * dt) (Parameters.cpp:468-480); not together with period */
+  int32_t  reserved_;
 } kwh_options;
 
 KWH_API const char* kwh_last_error(void);

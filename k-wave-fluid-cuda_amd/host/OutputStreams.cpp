@@ -420,6 +420,13 @@ void OutputStreamContainer::init(MatrixContainer& mc)
   }
   // ---- compression streams (OutputStreamContainer.cpp:92-96,157-168,272-321); index masks only ----
   const bool wantIAvgC = params.getStoreIntensityAvgCFlag() || params.getStoreQTermCFlag();
+  if (mc.has(MI::kSensorMaskIndex) && params.getStoreVelocityCFlag())
+  { // --u_c: the staggered velocities on the unshifted basis (OutputStreamContainer.cpp:133-142, BaseOutputStream.cpp:68-83)
+    IndexMatrix& mask = mc.getMatrix<IndexMatrix>(MI::kSensorMaskIndex);
+    mContainer[OI::kVelocityXC] = new CompressedIndexOutputStream(kUxName + "_c", mc.getMatrix<RealMatrix>(MI::kUxSgx), mask, false);
+    mContainer[OI::kVelocityYC] = new CompressedIndexOutputStream(kUyName + "_c", mc.getMatrix<RealMatrix>(MI::kUySgy), mask, false);
+    if (is3D) mContainer[OI::kVelocityZC] = new CompressedIndexOutputStream(kUzName + "_c", mc.getMatrix<RealMatrix>(MI::kUzSgz), mask, false);
+  }
   if (mc.has(MI::kSensorMaskIndex) && (params.getStorePressureCFlag() || params.getStoreVelocityNonStaggeredCFlag() || wantIAvgC))
   {
     IndexMatrix& mask = mc.getMatrix<IndexMatrix>(MI::kSensorMaskIndex);

@@ -204,7 +204,8 @@ class OutputStreamContainer
     kVelocityXMinAll, kVelocityYMinAll, kVelocityZMinAll,
     kPressureC, kVelocityXNonStaggeredC, kVelocityYNonStaggeredC, kVelocityZNonStaggeredC,
     kIntensityXAvgC, kIntensityYAvgC, kIntensityZAvgC,
-    kIntensityXAvg, kIntensityYAvg, kIntensityZAvg, kQTerm, kQTermC
+    kIntensityXAvg, kIntensityYAvg, kIntensityZAvg, kQTerm, kQTermC,
+    kVelocityXC, kVelocityYC, kVelocityZC
   };
   ~OutputStreamContainer() { freeStreams(); }
   void init(MatrixContainer& matrixContainer); // OutputStreamContainer.cpp:70-325

@@ -138,9 +138,13 @@ void Parameters::init(const InputProvider& in, const Options& options)
     mBOnAScalarFlag = in.getDatasetDimensionSizes(kBonAName) == scalarSizes;
     if (mBOnAScalarFlag) in.readScalarValue(kBonAName, mBOnAScalar);
   }
-  if (mOptions.storePressureC || mOptions.storeVelocityNonStaggeredC || mOptions.storeIntensityAvgC || mOptions.storeQTermC)
+  if (mOptions.storePressureC || mOptions.storeVelocityNonStaggeredC || mOptions.storeIntensityAvgC || mOptions.storeQTermC ||
+      mOptions.storeVelocityC)
   { // Parameters.cpp:462-551: the period (in time steps) is given (--period) or found from the pressure source signal:
     // the last <= 500 samples of the middle source point (:488-512)
+    if (mOptions.period > 0.0f && mOptions.frequency > 0.0f) // :468-471
+      throw std::ios_base::failure("Error: --period and --frequency cannot be given together");
+    if (mOptions.frequency > 0.0f) mOptions.period = 1.0f / (mOptions.frequency * mDt); // :473-477
     if (!(mOptions.period > 0.0f))
     {
       if (!in.datasetExists(kPressureSourceInputName))

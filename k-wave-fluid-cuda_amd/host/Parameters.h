@@ -53,6 +53,8 @@ class Parameters
     bool   storeVelocityNonStaggeredRaw = false;
     bool   storePressureC = false, storeVelocityNonStaggeredC = false, storeIntensityAvgC = false;
     bool   storeIntensityAvg = false, storeQTerm = false, storeQTermC = false; // --I_avg, --Q_term, --Q_term_c
+    bool   storeVelocityC = false; // --u_c
+    float  frequency = 0.0f;       // --frequency [Hz], alternative to --period
     float  period = 0.0f; // --period (time steps per period)
     size_t mos = 1, harmonics = 1;
     bool   noCompressionOverlap = false;
@@ -166,6 +168,7 @@ class Parameters
   bool getStoreIntensityAvgFlag() const { return mOptions.storeIntensityAvg; }
   bool getStoreQTermFlag() const { return mOptions.storeQTerm; }
   bool getStoreQTermCFlag() const { return mOptions.storeQTermC; }
+  bool getStoreVelocityCFlag() const { return mOptions.storeVelocityC; }
   bool getNoCompressionOverlapFlag() const { return mOptions.noCompressionOverlap; }
   float  getPeriod() const { return mOptions.period; }
   size_t getMOS() const { return mOptions.mos; }

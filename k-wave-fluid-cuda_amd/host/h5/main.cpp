@@ -1,6 +1,8 @@
 // main.cpp — command-line front end "kspaceFirstOrder-HIP": input file -> simulation on an MI355X -> output file.
 // Mirrors the sequence of the reference's main() (main.cpp:840-966) and the subset of its flags that select what
 // the loop computes and stores (CommandLineParameters.cpp:264-292); cosmetics (usage box, progress table) are out of scope.
+#include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -19,16 +21,21 @@ static void usage()
   std::printf("kspaceFirstOrder-HIP -i <input.h5> -o <output.h5> [-g dev] [-s start (1-based)] [--benchmark N]\n"
               "  [-p|--p_raw] [--p_rms] [--p_max] [--p_min] [--p_max_all] [--p_min_all] [--p_final]\n"
               "  [-u|--u_raw] [--u_rms] [--u_max] [--u_min] [--u_max_all] [--u_min_all] [--u_final] [--u_non_staggered_raw]\n"
-              "  [--p_c] [--u_non_staggered_c] [--I_avg_c] [--I_avg] [--Q_term] [--Q_term_c] [--period P] [--mos M] [--harmonics H] [--no_overlap] [--granular]\n"
+              "  [--p_c] [--u_c] [--u_non_staggered_c] [--I_avg_c] [--I_avg] [--Q_term] [--Q_term_c]\n"
+              "  [--period P | --frequency F] [--mos M] [--harmonics H] [--no_overlap] [--granular]\n"
               "  [-c <deflate 0..9>] [--copy_sensor_mask]\n"
-              "  [--checkpoint_file <ckpt.h5> --checkpoint_timesteps N]  stop after N steps, leaving a checkpoint; the\n"
-              "      same command line resumes from it (CommandLineParameters.cpp:264-292)\n");
+              "  [--checkpoint_file <ckpt.h5> --checkpoint_timesteps N | --checkpoint_interval SECONDS]  stop after N steps\n"
+              "      (or once SECONDS of wall-clock time have passed), leaving a checkpoint; the same command line resumes\n"
+              "      from it (CommandLineParameters.cpp:264-292)\n"
+              "  [--version] [-h|--help]; accepted without effect: -r <percent>, -t <threads>, --verbose <level>,\n"
+              "      --block_size <n>.  Not available: --post, --40-bit_complex\n");
 }
 
 int main(int argc, char** argv)
 {
   std::string in, out, ckpt;
   size_t ckptSteps = 0;
+  double ckptSeconds = 0.0;
   unsigned compressionLevel = 0; // -c (CommandLineParameters.h:791: default 0)
   bool copySensorMask = false;
   kwh_options o{};
@@ -63,6 +70,8 @@ int main(int argc, char** argv)
     else if (a == "--u_non_staggered_c") o.u_non_staggered_c = 1;
     else if (a == "--I_avg_c") o.i_avg_c = 1;
     else if (a == "--I_avg") o.i_avg = 1;
+    else if (a == "--u_c") o.u_c = 1;
+    else if (a == "--frequency") o.frequency = std::strtof(next(), nullptr);
     else if (a == "--Q_term") o.q_term = 1;
     else if (a == "--Q_term_c") o.q_term_c = 1;
     else if (a == "--period") o.period = std::strtof(next(), nullptr);
@@ -74,6 +83,11 @@ int main(int argc, char** argv)
     else if (a == "--copy_sensor_mask") copySensorMask = true;
     else if (a == "--checkpoint_file") ckpt = next();
     else if (a == "--checkpoint_timesteps") ckptSteps = std::strtoull(next(), nullptr, 10);
+    else if (a == "--checkpoint_interval") ckptSeconds = std::strtod(next(), nullptr);
+    else if (a == "--version") { std::printf("%s\n", KSpaceFirstOrderSolver().getCodeName().c_str()); return EXIT_SUCCESS; }
+    else if (a == "-r" || a == "-t" || a == "--verbose" || a == "--block_size") (void)next(); // progress / threads / log level / host block: nothing to set here
+    else if (a == "--post" || a == "--40-bit_complex")
+    { std::fprintf(stderr, "Error: %s is not available in this build\n", a.c_str()); return EXIT_FAILURE; }
     else if (a == "-h" || a == "--help") { usage(); return EXIT_SUCCESS; }
     else { std::fprintf(stderr, "unknown flag %s\n", a.c_str()); usage(); return EXIT_FAILURE; }
   }
@@ -87,7 +101,7 @@ int main(int argc, char** argv)
     std::printf("%s on %s\n", s.solver->getCodeName().c_str(),
                 Parameters::getInstance().getHipParameters().getDeviceName().c_str());
     Parameters& params = Parameters::getInstance();
-    const bool checkpointing = !ckpt.empty() && ckptSteps > 0;
+    const bool checkpointing = !ckpt.empty() && (ckptSteps > 0 || ckptSeconds > 0.0);
     if (checkpointing)
     { // recover if a checkpoint exists (KSpaceFirstOrderSolver.cpp:186-228), run one leg, stop with a new checkpoint
       if (FILE* f = std::fopen(ckpt.c_str(), "rb"))
@@ -96,7 +110,18 @@ int main(int argc, char** argv)
         kwh_checkpoint_read_impl(&s, ckpt);
         std::printf("recovered from %s at time step %zu\n", ckpt.c_str(), params.getTimeIndex());
       }
-      s.solver->runTimeSteps(ckptSteps);
+      if (ckptSeconds > 0.0)
+      { // --checkpoint_interval: step until the leg has used its wall-clock budget (isTimeToCheckpoint, :1100-1117)
+        const auto   t0    = std::chrono::steady_clock::now();
+        const size_t limit = (ckptSteps > 0) ? params.getTimeIndex() + ckptSteps : params.getNt();
+        while (params.getTimeIndex() < std::min(limit, params.getNt()))
+        {
+          s.solver->runTimeSteps(1);
+          kwCheck(kw_sync(params.getHipParameters().getContext()));
+          if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() >= ckptSeconds) break;
+        }
+      }
+      else s.solver->runTimeSteps(ckptSteps);
       kwCheck(kw_sync(params.getHipParameters().getContext()));
       if (params.getTimeIndex() < params.getNt())
       {

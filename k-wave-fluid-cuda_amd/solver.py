@@ -40,7 +40,8 @@ class Options(C.Structure):
                 ("slab_ranks", C.c_uint64), ("slab_rank", C.c_uint64), ("nz_global", C.c_uint64),
                 ("exchange_fn", C.c_void_p), ("exchange_user", C.c_void_p),
                 ("exchange_start_fn", C.c_void_p), ("exchange_wait_fn", C.c_void_p), ("scratch", C.c_void_p * 6),
-                ("i_avg", C.c_int32), ("q_term", C.c_int32), ("q_term_c", C.c_int32), ("reserved_", C.c_int32)]
+                ("i_avg", C.c_int32), ("q_term", C.c_int32), ("q_term_c", C.c_int32), ("u_c", C.c_int32),
+                ("frequency", C.c_float), ("reserved_", C.c_int32)]
 
 
 _hlib: Optional[C.CDLL] = None
@@ -123,6 +124,7 @@ class HostSolver:
         o.sampling_start_time_index = opts.pop("sampling_start", 0)
         o.benchmark_time_steps = opts.pop("benchmark_steps", 0)
         o.period = float(opts.pop("period", 0.0))
+        o.frequency = float(opts.pop("frequency", 0.0))
         o.mos = int(opts.pop("mos", 1))
         o.harmonics = int(opts.pop("harmonics", 1))
         # Z-slab decomposition (see dist.py): the problem dict is this rank's slab

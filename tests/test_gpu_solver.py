@@ -251,6 +251,37 @@ def test_config5_compression_and_intensity_streams(orc, syn):
     g.close()
 
 
+def test_u_c_streams_and_frequency_option(orc, syn):
+    """--u_c: the staggered velocities on the unshifted basis (OutputStreamContainer.cpp:133-142); --frequency f is
+    --period 1 / (f dt) (Parameters.cpp:473-477) and excludes --period."""
+    from kwave_amd import capi
+    n, nt = 32, 100
+    pr = syn.make_problem(n, heterogeneous=True, nonlinear=False, absorbing=False, source="p_source", source_mode=1,
+                          nt=nt, pml_size=4, sensor="random")
+    dt = float(pr["dt"].ravel()[0])
+    period, harm = 1.0 / (1.0e6 * dt), 2
+    g = make_gpu(pr, u_raw=1, u_c=1, p_c=1, frequency=1.0e6, mos=1, harmonics=harm)
+    g.run(nt)
+    g.finish()
+    nsens = pr["sensor_mask_index"].size
+    for nm in ("ux", "uy", "uz"):
+        comp = orc.Compressor(nsens, period, 1, harm, False)
+        for row in g.stream(nm):
+            comp.step(row)
+        got = g.stream(nm + "_c").reshape(-1, nsens, harm, 2)
+        assert got.shape[0] == len(comp.frames) > 0
+        assert rel_l2(got, np.array(comp.frames)) < 2e-6, nm
+    pc = g.stream("p_c").copy()
+    g.close()
+    g = make_gpu(pr, p_c=1, period=period, mos=1, harmonics=harm)
+    g.run(nt)
+    g.finish()
+    assert rel_l2(g.stream("p_c"), pc) < 1e-6   # same period up to the rounding of 1 / (f dt)
+    g.close()
+    with pytest.raises(capi.KWaveError):
+        make_gpu(pr, p_c=1, period=period, frequency=1.0e6)
+
+
 def test_compression_period_found_from_the_source_signal(syn):
     """No --period: the period comes from the pressure source signal (Parameters.cpp:488-512, CompressHelper::findPeriod);
     the run equals one given that period explicitly."""
