@@ -7,6 +7,7 @@
 #include <cmath>
 #include <complex>
 #include <limits>
+#include <string>
 
 #include "HipError.h"
 #include "SolverHipKernels.h"
@@ -114,6 +115,43 @@ template<SD sd> void KSpaceFirstOrderSolver::preProcessing()
     index(MI::kVelocitySourceIndex).recomputeIndicesToCPP();
   if (mParameters.getTransducerSourceFlag() != 0) index(MI::kDelayMask).recomputeIndicesToCPP();
   if (mParameters.getPressureSourceFlag() != 0) index(MI::kPressureSourceIndex).recomputeIndicesToCPP();
+  // an index outside the grid would be an out-of-bounds access in a gather / scatter kernel: refuse it here (the
+  // reference trusts the file)
+  const DimensionSizes grid = mParameters.getFullDimensionSizes();
+  auto checkIndices = [&](MI idx, const char* name) {
+    if (!mMatrixContainer.has(idx)) return;
+    const IndexMatrix& m = index(idx);
+    const size_t* v = m.getHostData();
+    for (size_t i = 0; i < m.size(); i++)
+      if (v[i] >= grid.nElements())
+        throw std::invalid_argument(std::string(name) + ": index " + std::to_string(v[i] + 1) + " (1-based) lies outside the " +
+                                    std::to_string(grid.nx) + " x " + std::to_string(grid.ny) + " x " + std::to_string(grid.nz) + " grid");
+  };
+  checkIndices(MI::kSensorMaskIndex, "sensor_mask_index");
+  if ((mParameters.getTransducerSourceFlag() != 0) || (mParameters.getVelocityXSourceFlag() != 0) ||
+      (mParameters.getVelocityYSourceFlag() != 0) || (mParameters.getVelocityZSourceFlag() != 0))
+    checkIndices(MI::kVelocitySourceIndex, "u_source_index");
+  if (mParameters.getPressureSourceFlag() != 0) checkIndices(MI::kPressureSourceIndex, "p_source_index");
+  if (mParameters.getTransducerSourceFlag() != 0)
+  { // every point reads signal[delay + step] for the steps the source is on (SolverCudaKernels.cu:430-449)
+    const IndexMatrix& d = index(MI::kDelayMask);
+    const size_t steps  = std::min(mParameters.getNt(), mParameters.getTransducerSourceFlag());
+    const size_t length = real(MI::kTransducerSourceInput).size();
+    for (size_t i = 0; i < d.size(); i++)
+      if (d.getHostData()[i] + steps > length)
+        throw std::invalid_argument("delay_mask: delay " + std::to_string(d.getHostData()[i] + 1) + " plus " + std::to_string(steps) +
+                                    " steps runs past the end of transducer_source_input (" + std::to_string(length) + " samples)");
+  }
+  if (mMatrixContainer.has(MI::kSensorMaskCorners))
+  {
+    const IndexMatrix& m = index(MI::kSensorMaskCorners);
+    for (size_t c = 0; c < m.getDimensionSizes().ny; c++)
+    {
+      const DimensionSizes a = m.getTopLeftCorner(c), b = m.getBottomRightCorner(c);
+      if (a.nx > b.nx || a.ny > b.ny || a.nz > b.nz || b.nx >= grid.nx || b.ny >= grid.ny || b.nz >= grid.nz)
+        throw std::invalid_argument("sensor_mask_corners: cuboid " + std::to_string(c + 1) + " is empty or lies outside the grid");
+    }
+  }
 
   if (mParameters.getNonUniformGridFlag() != 0) generateInitialDenisty();
   else if (!mParameters.getRho0ScalarFlag())
