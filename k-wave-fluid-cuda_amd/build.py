@@ -5,6 +5,7 @@
 """
 from __future__ import annotations
 
+import concurrent.futures
 import glob
 import os
 import subprocess
@@ -43,7 +44,7 @@ def build_hip(force: bool = False, verbose: bool = False) -> str:
     srcs = sorted(glob.glob(os.path.join(CSRC, "*.hip")))
     deps = srcs + glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(INCLUDE, "*.h"))
     if force or _newer(HIP_LIB, deps):
-        objs = []
+        objs, jobs = [], []
         for s in srcs:
             o = os.path.join(LIB_DIR, os.path.basename(s) + ".o")
             if force or _newer(o, [s] + [d for d in deps if d.endswith(".h")]):
@@ -54,10 +55,13 @@ def build_hip(force: bool = False, verbose: bool = False) -> str:
                     "-I" + INCLUDE, "-I" + CSRC, "-I" + os.path.join(ROCM, "include"), "-c", s, "-o", o]
                 if verbose:
                     cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
-                out = _run(cmd)
+                jobs.append(cmd)
+            objs.append(o)
+        # the translation units compile side by side (kw_fused.hip alone takes minutes: one kernel set per line length)
+        with concurrent.futures.ThreadPoolExecutor(max_workers=max(1, min(4, len(jobs)))) as pool:
+            for out in pool.map(_run, jobs):
                 if verbose:
                     print(out)
-            objs.append(o)
         _run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", HIP_LIB] + objs +
              ["-L" + os.path.join(ROCM, "lib"), "-lrocfft", "-Wl,-rpath," + os.path.join(ROCM, "lib")])
     return HIP_LIB
