@@ -26,6 +26,8 @@ KWH_API int kwh_write_output_file_ex(kwh_solver* s, const char* path, uint32_t c
 KWH_API int kwh_write_input_file(const char* path, const kwh_dataset* datasets, size_t n, const int32_t* is_complex);
 /* reading back: dims (x,y,z), dtype (0 float / 1 uint64), domain; whole dataset; string attribute ("/" = root) */
 KWH_API int kwh_h5_dataset_info(const char* path, const char* name, uint64_t dims[3], int32_t* dtype, int32_t* is_complex);
+/* dims = (x, y, z, t); t = 0 for a 3-D dataset, > 0 for the per-cuboid series "/<stream>/<cuboid>" of a corners mask */
+KWH_API int kwh_h5_dataset_info_4d(const char* path, const char* name, uint64_t dims[4], int32_t* dtype, int32_t* is_complex);
 KWH_API int kwh_h5_read(const char* path, const char* name, void* dst, uint64_t n, int32_t dtype);
 KWH_API int kwh_h5_read_attribute(const char* path, const char* dataset, const char* attr, char* out, uint64_t cap);
 /* checkpoint file (file_type = "checkpoint"): p, rhox, rhoy, rhoz, ux_sgx, uy_sgy, uz_sgz, t_index, Nx, Ny, Nz as in the

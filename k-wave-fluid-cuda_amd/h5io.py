@@ -36,6 +36,8 @@ def load_h5() -> C.CDLL:
         L.kwh_create_from_file.argtypes = [C.c_char_p, C.POINTER(Options), C.POINTER(C.c_void_p)]
         L.kwh_write_output_file.argtypes = [C.c_void_p, C.c_char_p]
         L.kwh_write_input_file.argtypes = [C.c_char_p, C.POINTER(Dataset), C.c_size_t, C.POINTER(C.c_int32)]
+        L.kwh_h5_dataset_info_4d.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(C.c_uint64 * 4), C.POINTER(C.c_int32),
+                                             C.POINTER(C.c_int32)]
         L.kwh_h5_dataset_info.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(C.c_uint64 * 3), C.POINTER(C.c_int32),
                                           C.POINTER(C.c_int32)]
         L.kwh_h5_read.argtypes = [C.c_char_p, C.c_char_p, C.c_void_p, C.c_uint64, C.c_int32]
@@ -83,9 +85,18 @@ def dataset_info(path: str, name: str):
     return tuple(int(d) for d in dims), ("long" if dt.value else "float"), ("complex" if cx.value else "real")
 
 
+def dataset_info_4d(path: str, name: str):
+    """((nx, ny, nz, nt), type, domain); nt = 0 for a 3-D dataset."""
+    dims = (C.c_uint64 * 4)()
+    dt, cx = C.c_int32(), C.c_int32()
+    _h5check(load_h5().kwh_h5_dataset_info_4d(path.encode(), name.encode(), C.byref(dims), C.byref(dt), C.byref(cx)))
+    return tuple(int(d) for d in dims), ("long" if dt.value else "float"), ("complex" if cx.value else "real")
+
+
 def read_dataset(path: str, name: str) -> np.ndarray:
-    (nx, ny, nz), dtype, _ = dataset_info(path, name)
-    out = np.empty((nz, ny, nx), dtype=np.uint64 if dtype == "long" else np.float32)
+    """3-D datasets as [nz][ny][nx]; the per-cuboid series of a corners mask ("p/1") as [nt][nz][ny][nx]."""
+    (nx, ny, nz, nt), dtype, _ = dataset_info_4d(path, name)
+    out = np.empty((nt, nz, ny, nx) if nt else (nz, ny, nx), dtype=np.uint64 if dtype == "long" else np.float32)
     _h5check(load_h5().kwh_h5_read(path.encode(), name.encode(), out.ctypes.data, out.size, 1 if dtype == "long" else 0))
     return out
 

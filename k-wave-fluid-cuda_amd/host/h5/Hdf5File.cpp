@@ -44,6 +44,7 @@ DimensionSizes Hdf5File::getDatasetDimensionSizes(const std::string& name) const
   if (H5LTget_dataset_info(mFile, name.c_str(), dims.data(), nullptr, nullptr) < 0)
     fail("Error: cannot read dimension sizes of dataset \"" + name + "\"");
   if (rank == 3) return DimensionSizes(dims[2], dims[1], dims[0]);
+  if (rank == 4 && dims[0] == 0) fail("Error: dataset \"" + name + "\" is empty");
   if (rank == 4) return DimensionSizes(dims[3], dims[2], dims[1], dims[0]);
   fail("Error: dataset \"" + name + "\" is not 3-D / 4-D");
   return DimensionSizes();
@@ -139,6 +140,43 @@ void Hdf5File::writeMatrix(const std::string& name, const DimensionSizes& dims, 
   writeDataset(mFile, name, dims, H5T_STD_U64LE, H5T_NATIVE_UINT64, data, mChunkedOutput && dims.nElements() > 1,
                mCompressionLevel);
   writeStringAttribute(name, kMatrixDataTypeName, kDataNames[1]);
+  writeStringAttribute(name, kMatrixDomainTypeName, kDomainNames[0]);
+}
+void Hdf5File::createGroup(const std::string& name)
+{
+  hid_t g = H5Gcreate2(mFile, name.c_str(), H5P_DEFAULT, H5P_DEFAULT, H5P_DEFAULT);
+  if (g < 0) fail("Error: cannot create group \"" + name + "\"");
+  H5Gclose(g);
+}
+void Hdf5File::writeCuboid(const std::string& name, const DimensionSizes& d, const float* data)
+{
+  const int rank = (d.nt > 0) ? 4 : 3;
+  hsize_t dims[4] = {d.nt, d.nz, d.ny, d.nx};
+  hsize_t* dp = (rank == 4) ? dims : dims + 1;
+  hid_t space = H5Screate_simple(rank, dp, nullptr);
+  hid_t plist = H5P_DEFAULT;
+  if (mChunkedOutput && d.nx * d.ny * d.nz > 0)
+  { // CuboidOutputStream.cpp:677-690
+    constexpr size_t kChunkSize4MB = 1048576;
+    hsize_t cdims[4] = {1, d.nz, d.ny, d.nx};
+    if (d.nx * d.ny * d.nz > kChunkSize4MB * 8)
+    {
+      size_t nSlabs = 1;
+      while (nSlabs * d.nx * d.ny < kChunkSize4MB) nSlabs++;
+      cdims[1] = nSlabs;
+    }
+    plist = H5Pcreate(H5P_DATASET_CREATE);
+    H5Pset_chunk(plist, rank, (rank == 4) ? cdims : cdims + 1);
+    if (mCompressionLevel > 0) H5Pset_deflate(plist, mCompressionLevel);
+  }
+  hid_t set = H5Dcreate2(mFile, name.c_str(), H5T_IEEE_F32LE, space, H5P_DEFAULT, plist, H5P_DEFAULT);
+  herr_t st = -1;
+  if (set >= 0) st = (d.nElements() == 0) ? 0 : H5Dwrite(set, H5T_NATIVE_FLOAT, H5S_ALL, H5S_ALL, H5P_DEFAULT, data);
+  if (set >= 0) H5Dclose(set);
+  if (plist != H5P_DEFAULT) H5Pclose(plist);
+  H5Sclose(space);
+  if (set < 0 || st < 0) fail("Error: cannot write dataset \"" + name + "\"");
+  writeStringAttribute(name, kMatrixDataTypeName, kDataNames[0]);
   writeStringAttribute(name, kMatrixDomainTypeName, kDomainNames[0]);
 }
 void Hdf5File::writeScalarValue(const std::string& name, float value) { writeMatrix(name, DimensionSizes(1, 1, 1), &value, MatrixDomainType::kReal); }

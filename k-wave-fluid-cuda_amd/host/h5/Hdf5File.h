@@ -41,6 +41,10 @@ class Hdf5File
   /// write a whole 3-D dataset (x,y,z sizes) + its data_type / domain_type attributes
   void writeMatrix(const std::string& name, const DimensionSizes& dims, const float* data, MatrixDomainType domain);
   void writeMatrix(const std::string& name, const DimensionSizes& dims, const size_t* data);
+  /// group + dataset of one sampled cuboid (CuboidOutputStream.cpp:656-722): dims = (nx, ny, nz[, nt]); 4-D when nt > 0;
+  /// chunk = one time step of the cuboid, cut into z-slabs of ~4 MB above 32 MB
+  void createGroup(const std::string& name);
+  void writeCuboid(const std::string& name, const DimensionSizes& dims, const float* data);
   void writeScalarValue(const std::string& name, float value);
   void writeScalarValue(const std::string& name, size_t value);
   void writeStringAttribute(const std::string& dataset, const std::string& attr, const std::string& value); // "/" = root

@@ -1,6 +1,7 @@
 // h5_capi.cpp — HDF5 entry points of libkwave_host_h5.so: run the solver from a k-Wave input file and write a k-Wave
 // output file (main.cpp:840-966 sequence; dataset shapes IndexOutputStream.cpp:91-117, WholeDomainOutputStream.cpp,
 // KSpaceFirstOrderSolver.cpp:952-973,1100-1169), plus a writer for synthetic input files.
+#include <algorithm>
 #include <cstring>
 #include <exception>
 
@@ -48,6 +49,28 @@ void kwh_write_output(kwh_solver* s, const std::string& path, unsigned compressi
     DimensionSizes d(st->size(), series ? st->sampledSteps() : 1, 1);
     if (!series && st->size() == dims.nElements()) d = dims;
     if (st->dataset().size() != d.nElements()) continue; // nothing sampled yet
+    MatrixContainer& mcs = s->solver->getMatrixContainer();
+    if (mcs.has(MatrixContainer::MatrixIdx::kSensorMaskCorners) && dynamic_cast<WholeDomainOutputStream*>(st) == nullptr)
+    { // corners mask: a group per stream, a dataset per cuboid — (nx, ny, nz, Nt - s) for series, (nx, ny, nz) for
+      // aggregates (CuboidOutputStream.cpp:95-140, :656-722); the stream buffer holds the cuboids back to back per step
+      const IndexMatrix& corners = mcs.getMatrix<IndexMatrix>(MatrixContainer::MatrixIdx::kSensorMaskCorners);
+      const size_t steps = series ? st->sampledSteps() : 1;
+      out.createGroup(name);
+      size_t offset = 0;
+      std::vector<float> block;
+      for (size_t c = 0; c < corners.getDimensionSizes().ny; c++)
+      {
+        const DimensionSizes a = corners.getTopLeftCorner(c), b = corners.getBottomRightCorner(c);
+        DimensionSizes cd(b.nx - a.nx + 1, b.ny - a.ny + 1, b.nz - a.nz + 1, series ? steps : 0);
+        const size_t n = corners.getSizeOfCuboid(c);
+        block.resize(n * steps);
+        for (size_t t = 0; t < steps; t++)
+          std::copy_n(st->dataset().data() + t * st->size() + offset, n, block.data() + t * n);
+        out.writeCuboid(name + "/" + std::to_string(c + 1), cd, block.data());
+        offset += n;
+      }
+      continue;
+    }
     out.writeMatrix(name, d, st->dataset().data(), Hdf5File::MatrixDomainType::kReal);
   }
   auto writeFinal = [&](MatrixContainer::MatrixIdx idx, const std::string& name) {
@@ -209,6 +232,18 @@ KWH_API int kwh_h5_dataset_info(const char* path, const char* name, uint64_t dim
   f.open(path, true);
   const DimensionSizes d = f.getDatasetDimensionSizes(name);
   dims[0] = d.nx; dims[1] = d.ny; dims[2] = d.nz;
+  *dtype      = f.readMatrixDataType(name) == Hdf5File::MatrixDataType::kFloat ? 0 : 1;
+  *is_complex = f.readMatrixDomainType(name) == Hdf5File::MatrixDomainType::kComplex ? 1 : 0;
+  KWH_CATCH
+}
+/* the same with the 4th (time) extent of per-cuboid series: dims = (x, y, z, t), t = 0 for 3-D datasets */
+KWH_API int kwh_h5_dataset_info_4d(const char* path, const char* name, uint64_t dims[4], int32_t* dtype, int32_t* is_complex)
+{
+  KWH_TRY
+  Hdf5File f;
+  f.open(path, true);
+  const DimensionSizes d = f.getDatasetDimensionSizes(name);
+  dims[0] = d.nx; dims[1] = d.ny; dims[2] = d.nz; dims[3] = d.nt;
   *dtype      = f.readMatrixDataType(name) == Hdf5File::MatrixDataType::kFloat ? 0 : 1;
   *is_complex = f.readMatrixDomainType(name) == Hdf5File::MatrixDomainType::kComplex ? 1 : 0;
   KWH_CATCH

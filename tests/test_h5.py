@@ -135,3 +135,38 @@ def test_output_compression_level_and_copied_sensor_mask(h5io, syn, tmp_path):
     assert r.returncode == 0, r.stdout
     assert np.array_equal(h5io.read_dataset(cli, "p"), h5io.read_dataset(plain, "p"))
     assert np.array_equal(h5io.read_dataset(cli, "sensor_mask_index").ravel(), pr["sensor_mask_index"].ravel())
+
+
+@pytest.mark.gpu
+def test_corners_mask_output_is_one_group_per_stream_with_a_dataset_per_cuboid(h5io, syn, tmp_path):
+    """sensor_mask_type = corners: "/p/1", "/p/2" ... — (nx, ny, nz, Nt - s) for series, (nx, ny, nz) for aggregates and the
+    post-processed intensities (CuboidOutputStream.cpp:95-140, :656-722); whole-domain streams stay plain datasets."""
+    nt, start = 14, 3
+    pr = syn.make_problem(32, heterogeneous=True, nonlinear=False, absorbing=True, source="p0", nt=nt, pml_size=4)
+    pr = {k: v for k, v in pr.items() if k != "sensor_mask_index"}
+    corners = np.array([[3, 4, 5, 10, 9, 7], [12, 2, 20, 12, 2, 20]], dtype=np.uint64)
+    pr["sensor_mask_type"] = np.array([[[1]]], dtype=np.uint64)
+    pr["sensor_mask_corners"] = corners.reshape(1, 2, 6)
+    path_in, path_out = str(tmp_path / "in.h5"), str(tmp_path / "out.h5")
+    h5io.write_input_file(pr, path_in)
+    fs = h5io.FileSolver(path_in, p_raw=1, p_max=1, u_rms=1, p_max_all=1, i_avg=1, sampling_start=start)
+    fs.run(nt)
+    fs.finish()
+    fs.write_output(path_out, compression_level=4, copy_sensor_mask=True)
+    series, pmax, iavg = fs.stream("p"), fs.stream("p_max").reshape(-1), fs.stream("Ix_avg").reshape(-1)
+    offset = 0
+    for c, (x0, y0, z0, x1, y1, z1) in enumerate(corners.astype(int), start=1):
+        shape = (z1 - z0 + 1, y1 - y0 + 1, x1 - x0 + 1)
+        n = int(np.prod(shape))
+        assert h5io.dataset_info_4d(path_out, f"p/{c}") == ((shape[2], shape[1], shape[0], nt - start), "float", "real")
+        assert h5io.dataset_info_4d(path_out, f"p_max/{c}")[0] == (shape[2], shape[1], shape[0], 0)
+        got = h5io.read_dataset(path_out, f"p/{c}")
+        assert np.array_equal(got.reshape(nt - start, n), series[:, offset:offset + n])
+        assert np.array_equal(h5io.read_dataset(path_out, f"p_max/{c}").reshape(-1), pmax[offset:offset + n])
+        assert np.array_equal(h5io.read_dataset(path_out, f"Ix_avg/{c}").reshape(-1), iavg[offset:offset + n])
+        assert h5io.dataset_info_4d(path_out, f"ux_non_staggered/{c}")[0][3] == nt - start
+        offset += n
+    # the first step of cuboid 1 is the field sampled in x-fastest order
+    assert h5io.dataset_info(path_out, "p_max_all")[0] == (32, 32, 32)
+    assert np.array_equal(h5io.read_dataset(path_out, "sensor_mask_corners").reshape(-1), corners.reshape(-1))
+    fs.close()
