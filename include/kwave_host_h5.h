@@ -30,6 +30,8 @@ KWH_API int kwh_h5_dataset_info(const char* path, const char* name, uint64_t dim
 KWH_API int kwh_h5_dataset_info_4d(const char* path, const char* name, uint64_t dims[4], int32_t* dtype, int32_t* is_complex);
 KWH_API int kwh_h5_read(const char* path, const char* name, void* dst, uint64_t n, int32_t dtype);
 KWH_API int kwh_h5_read_attribute(const char* path, const char* dataset, const char* attr, char* out, uint64_t cap);
+/* integer or float attribute (the compression parameters c_harmonics, c_period, ... of a coefficient dataset) */
+KWH_API int kwh_h5_read_numeric_attribute(const char* path, const char* dataset, const char* attr, double* out);
 /* checkpoint file (file_type = "checkpoint"): p, rhox, rhoy, rhoz, ux_sgx, uy_sgy, uz_sgz, t_index, Nx, Ny, Nz as in the
  * reference, plus the state of every output stream (stream_<name>, stream_<name>_steps).  kwh_checkpoint_read refuses a
  * file whose type or dimensions do not match (KSpaceFirstOrderSolver.cpp:1132-1168) and leaves the solver at the stored

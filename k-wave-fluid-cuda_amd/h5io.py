@@ -107,6 +107,14 @@ def read_attribute(path: str, dataset: str, attr: str) -> str:
     return buf.value.decode()
 
 
+def read_numeric_attribute(path: str, dataset: str, attr: str) -> float:
+    v = C.c_double()
+    L = load_h5()
+    L.kwh_h5_read_numeric_attribute.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.POINTER(C.c_double)]
+    _h5check(L.kwh_h5_read_numeric_attribute(path.encode(), dataset.encode(), attr.encode(), C.byref(v)))
+    return float(v.value)
+
+
 class FileSolver(HostSolver):
     """HostSolver created from a k-Wave HDF5 input file instead of in-memory datasets."""
 

@@ -111,6 +111,7 @@ class CompressedIndexOutputStream : public BaseOutputStream
   void restoreState(const float* state, size_t n, size_t sampledSteps) override;
   size_t frames() const { return mCompressedTimeStep; }
   size_t points() const { return mSensorMask.size(); }
+  bool   shiftedBasis() const { return mShifted; }
 
  private:
   const IndexMatrix& mSensorMask;

@@ -63,6 +63,23 @@ void Hdf5File::writeStringAttribute(const std::string& dataset, const std::strin
   if (H5LTset_attribute_string(mFile, dataset.c_str(), attr.c_str(), value.c_str()) < 0)
     fail("Error: cannot write attribute \"" + attr + "\" of \"" + dataset + "\"");
 }
+void Hdf5File::writeLongLongAttribute(const std::string& dataset, const std::string& attr, long long value)
+{
+  if (H5LTset_attribute_long_long(mFile, dataset.c_str(), attr.c_str(), &value, 1) < 0)
+    fail("Error: cannot write attribute \"" + attr + "\" of \"" + dataset + "\"");
+}
+void Hdf5File::writeFloatAttribute(const std::string& dataset, const std::string& attr, float value)
+{
+  if (H5LTset_attribute_float(mFile, dataset.c_str(), attr.c_str(), &value, 1) < 0)
+    fail("Error: cannot write attribute \"" + attr + "\" of \"" + dataset + "\"");
+}
+double Hdf5File::readNumericAttribute(const std::string& dataset, const std::string& attr) const
+{
+  double v = 0.0;
+  if (H5LTget_attribute_double(mFile, dataset.c_str(), attr.c_str(), &v) < 0)
+    fail("Error: cannot read attribute \"" + attr + "\" of \"" + dataset + "\"");
+  return v;
+}
 Hdf5File::MatrixDataType Hdf5File::readMatrixDataType(const std::string& name) const
 {
   const std::string v = readStringAttribute(name, kMatrixDataTypeName);

@@ -48,6 +48,9 @@ class Hdf5File
   void writeScalarValue(const std::string& name, float value);
   void writeScalarValue(const std::string& name, size_t value);
   void writeStringAttribute(const std::string& dataset, const std::string& attr, const std::string& value); // "/" = root
+  void writeLongLongAttribute(const std::string& dataset, const std::string& attr, long long value);
+  void writeFloatAttribute(const std::string& dataset, const std::string& attr, float value);
+  double readNumericAttribute(const std::string& dataset, const std::string& attr) const; // integer or float attribute
   std::string readStringAttribute(const std::string& dataset, const std::string& attr) const;
   /// root header attributes (Hdf5FileHeader.cpp:126-149 write, :155-200 read/check)
   void writeHeader(const std::string& fileType, const std::string& description);

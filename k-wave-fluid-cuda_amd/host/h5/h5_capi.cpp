@@ -5,6 +5,7 @@
 #include <cstring>
 #include <exception>
 
+#include "../CompressHelper.h"
 #include "../HipError.h"
 #include "../HostSolverHandle.h"
 #include "../MatrixNames.h"
@@ -72,6 +73,17 @@ void kwh_write_output(kwh_solver* s, const std::string& path, unsigned compressi
       continue;
     }
     out.writeMatrix(name, d, st->dataset().data(), Hdf5File::MatrixDomainType::kReal);
+    if (auto* cs = dynamic_cast<CompressedIndexOutputStream*>(st))
+    { // what a reader needs to expand the coefficients again (IndexOutputStream.cpp:146-157)
+      const CompressHelper& ch = CompressHelper::getInstance();
+      out.writeLongLongAttribute(name, "c_harmonics", static_cast<long long>(ch.getHarmonics()));
+      out.writeStringAttribute(name, "c_type", "c");
+      out.writeFloatAttribute(name, "c_period", ch.getPeriod());
+      out.writeLongLongAttribute(name, "c_mos", static_cast<long long>(ch.getMos()));
+      out.writeLongLongAttribute(name, "c_shift", cs->shiftedBasis() ? 1 : 0);
+      out.writeFloatAttribute(name, "c_complex_size", 2.0f);
+      out.writeLongLongAttribute(name, "c_max_exp", cs->shiftedBasis() ? CompressHelper::kMaxExpU : CompressHelper::kMaxExpP);
+    }
   }
   auto writeFinal = [&](MatrixContainer::MatrixIdx idx, const std::string& name) {
     RealMatrix& m = s->solver->getMatrixContainer().getMatrix<RealMatrix>(idx);
@@ -255,6 +267,14 @@ KWH_API int kwh_h5_read(const char* path, const char* name, void* dst, uint64_t 
   f.open(path, true);
   if (dtype == 0) f.readCompleteDataset(name, n, static_cast<float*>(dst));
   else f.readCompleteDataset(name, n, static_cast<size_t*>(dst));
+  KWH_CATCH
+}
+KWH_API int kwh_h5_read_numeric_attribute(const char* path, const char* dataset, const char* attr, double* out)
+{
+  KWH_TRY
+  Hdf5File f;
+  f.open(path, true);
+  *out = f.readNumericAttribute(dataset, attr);
   KWH_CATCH
 }
 KWH_API int kwh_h5_read_attribute(const char* path, const char* dataset, const char* attr, char* out, uint64_t cap)

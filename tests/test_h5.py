@@ -170,3 +170,30 @@ def test_corners_mask_output_is_one_group_per_stream_with_a_dataset_per_cuboid(h
     assert h5io.dataset_info(path_out, "p_max_all")[0] == (32, 32, 32)
     assert np.array_equal(h5io.read_dataset(path_out, "sensor_mask_corners").reshape(-1), corners.reshape(-1))
     fs.close()
+
+
+@pytest.mark.gpu
+def test_compression_datasets_carry_their_parameters(h5io, syn, tmp_path):
+    """c_harmonics / c_type / c_period / c_mos / c_shift / c_complex_size / c_max_exp (IndexOutputStream.cpp:146-157)"""
+    nt = 100
+    pr = syn.make_problem(32, heterogeneous=False, nonlinear=False, absorbing=False, source="p_source", source_mode=1,
+                          nt=nt, pml_size=4, sensor="random")
+    dt = float(pr["dt"].ravel()[0])
+    path_in, path_out = str(tmp_path / "in.h5"), str(tmp_path / "out.h5")
+    h5io.write_input_file(pr, path_in)
+    fs = h5io.FileSolver(path_in, p_c=1, u_non_staggered_c=1, frequency=1.0e6, mos=1, harmonics=2)
+    fs.run(nt)
+    fs.finish()
+    fs.write_output(path_out)
+    frames = fs.stream("p_c").reshape(-1, pr["sensor_mask_index"].size * 2 * 2).shape[0]
+    fs.close()
+    assert h5io.dataset_info(path_out, "p_c")[0] == (pr["sensor_mask_index"].size * 2 * 2, frames, 1)
+    assert h5io.read_attribute(path_out, "p_c", "c_type") == "c"
+    period = 1.0 / (1.0e6 * dt)
+    for name, shift, e in (("p_c", 0, 138), ("ux_non_staggered_c", 1, 114)):
+        assert h5io.read_numeric_attribute(path_out, name, "c_harmonics") == 2
+        assert h5io.read_numeric_attribute(path_out, name, "c_mos") == 1
+        assert h5io.read_numeric_attribute(path_out, name, "c_shift") == shift
+        assert h5io.read_numeric_attribute(path_out, name, "c_max_exp") == e
+        assert h5io.read_numeric_attribute(path_out, name, "c_complex_size") == 2.0
+        assert h5io.read_numeric_attribute(path_out, name, "c_period") == pytest.approx(period, rel=1e-6)
