@@ -51,6 +51,13 @@ void Parameters::init(const InputProvider& in, const Options& options)
   in.readScalarValue(kDyName, mDy);
   in.readScalarValue(kDzName, mDz);
   in.readScalarValue(kCRefName, mCRef);
+  const char* const pmlSizeNames[3]  = {"pml_x_size", "pml_y_size", "pml_z_size"};
+  const char* const pmlAlphaNames[3] = {"pml_x_alpha", "pml_y_alpha", "pml_z_alpha"};
+  for (int a = 0; a < 3; a++)
+  {
+    if (in.datasetExists(pmlSizeNames[a])) in.readScalarValue(pmlSizeNames[a], mPmlSize[a]);
+    if (in.datasetExists(pmlAlphaNames[a])) in.readScalarValue(pmlAlphaNames[a], mPmlAlpha[a]);
+  }
 
   // sensor mask (file version 1.1: Parameters.cpp:262-312)
   mSensorMaskIndexSize = mSensorMaskCornersSize = 0;

@@ -103,6 +103,10 @@ class Parameters
   float getDy() const { return mDy; }
   float getDz() const { return mDz; }
   float getCRef() const { return mCRef; }
+  /// PML description of the input file: not used by the loop (the pml_* vectors are), copied to the output file
+  /// (Parameters.cpp:580-592); 0 when the input does not carry them
+  size_t getPmlSize(int axis) const { return mPmlSize[axis]; }
+  float  getPmlAlpha(int axis) const { return mPmlAlpha[axis]; }
 
   bool  getC0ScalarFlag() const { return mC0ScalarFlag; }
   float getC0Scalar() const { return mC0Scalar; }
@@ -189,6 +193,8 @@ class Parameters
   DimensionSizes mFullDimensionSizes, mReducedDimensionSizes, mGlobalDimensionSizes;
   size_t mNt = 0, mTimeIndex = 0;
   float  mDt = 0, mDx = 0, mDy = 0, mDz = 0, mCRef = 0;
+  size_t mPmlSize[3]  = {0, 0, 0};
+  float  mPmlAlpha[3] = {0, 0, 0};
   bool   mC0ScalarFlag = true;
   float  mC0Scalar = 0;
   bool   mRho0ScalarFlag = true;

@@ -35,10 +35,34 @@ void kwh_write_output(kwh_solver* s, const std::string& path, unsigned compressi
   out.writeScalarValue(kDtName, params.getDt());
   out.writeScalarValue(kDxName, params.getDx());
   out.writeScalarValue(kDyName, params.getDy());
-  out.writeScalarValue(kDzName, params.getDz());
+  if (params.isSimulation3D()) out.writeScalarValue(kDzName, params.getDz());
   out.writeScalarValue(kCRefName, params.getCRef());
-  out.writeScalarValue(kNonLinearFlagName, params.getNonLinearFlag());
+  // the rest of the reference's output scalars (Parameters.cpp:580-647)
+  const char* const pmlSizeNames[3]  = {"pml_x_size", "pml_y_size", "pml_z_size"};
+  const char* const pmlAlphaNames[3] = {"pml_x_alpha", "pml_y_alpha", "pml_z_alpha"};
+  const int axes = params.isSimulation3D() ? 3 : 2;
+  for (int a = 0; a < axes; a++) out.writeScalarValue(pmlSizeNames[a], params.getPmlSize(a));
+  for (int a = 0; a < axes; a++) out.writeScalarValue(pmlAlphaNames[a], params.getPmlAlpha(a));
+  out.writeScalarValue(kPressureSourceFlagName, params.getPressureSourceFlag());
+  out.writeScalarValue(kInitialPressureSourceFlagName, params.getInitialPressureSourceFlag());
+  out.writeScalarValue("transducer_source_flag", params.getTransducerSourceFlag());
+  out.writeScalarValue("ux_source_flag", params.getVelocityXSourceFlag());
+  out.writeScalarValue("uy_source_flag", params.getVelocityYSourceFlag());
+  if (params.isSimulation3D()) out.writeScalarValue("uz_source_flag", params.getVelocityZSourceFlag());
+  out.writeScalarValue(kNonUniformGridFlagName, params.getNonUniformGridFlag());
   out.writeScalarValue(kAbsorbingFlagName, params.getAbsorbingFlag());
+  out.writeScalarValue(kNonLinearFlagName, params.getNonLinearFlag());
+  if (params.getVelocityXSourceFlag() > 0 || params.getVelocityYSourceFlag() > 0 || params.getVelocityZSourceFlag() > 0)
+  {
+    out.writeScalarValue(kVelocitySourceManyName, params.getVelocitySourceMany());
+    out.writeScalarValue(kVelocitySourceModeName, static_cast<size_t>(params.getVelocitySourceMode()));
+  }
+  if (params.getPressureSourceFlag() != 0)
+  {
+    out.writeScalarValue(kPressureSourceManyName, params.getPressureSourceMany());
+    out.writeScalarValue(kPressureSourceModeName, static_cast<size_t>(params.getPressureSourceMode()));
+  }
+  if (params.getAbsorbingFlag() != 0) out.writeScalarValue(kAlphaPowerName, params.getAlphaPower());
   out.writeScalarValue(kSensorMaskTypeName, static_cast<size_t>(params.getSensorMaskType()));
   // streams: raw series (Nsens, Nt - s, 1); aggregates (Nsens, 1, 1); whole-domain (Nx, Ny, Nz)
   OutputStreamContainer& streams = s->solver->getOutputStreamContainer();

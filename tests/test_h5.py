@@ -75,6 +75,13 @@ def test_file_driven_run_equals_memory_run_and_output_file(h5io, syn, tmp_path):
     assert np.array_equal(h5io.read_dataset(path_out, "p").reshape(15, nsens), mem.stream("p"))
     assert np.array_equal(h5io.read_dataset(path_out, "p_final"), mem.field("p"))
     assert int(h5io.read_dataset(path_out, "t_index").ravel()[0]) == 15
+    # the simulation flags and the PML description travel from the input to the output file (Parameters.cpp:559-647)
+    for name in ("Nx", "Ny", "Nz", "Nt", "dt", "dx", "dy", "dz", "c_ref", "pml_x_size", "pml_y_size", "pml_z_size",
+                 "pml_x_alpha", "pml_y_alpha", "pml_z_alpha", "p_source_flag", "p0_source_flag", "transducer_source_flag",
+                 "ux_source_flag", "uy_source_flag", "uz_source_flag", "nonuniform_grid_flag", "absorbing_flag",
+                 "nonlinear_flag", "alpha_power"):
+        want = np.asarray(pr[name]).ravel()[0] if name in pr else 0
+        assert h5io.read_dataset(path_out, name).ravel()[0] == want, name
     fs.close()
     mem.close()
 
