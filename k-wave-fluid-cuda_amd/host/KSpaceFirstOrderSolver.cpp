@@ -4,6 +4,7 @@
 #include <cstdlib>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <complex>
 #include <limits>
@@ -14,6 +15,17 @@
 
 using SD = Parameters::SimulationDimension;
 using MI = MatrixContainer::MatrixIdx;
+
+namespace
+{
+struct PhaseTimer
+{ // adds the lifetime of the object to one of the solver's phase counters
+  explicit PhaseTimer(double& acc) : mAcc(acc), mStart(std::chrono::steady_clock::now()) {}
+  ~PhaseTimer() { mAcc += std::chrono::duration<double>(std::chrono::steady_clock::now() - mStart).count(); }
+  double& mAcc;
+  std::chrono::steady_clock::time_point mStart;
+};
+} // namespace
 
 KSpaceFirstOrderSolver::KSpaceFirstOrderSolver() : mParameters(Parameters::getInstance()) {}
 KSpaceFirstOrderSolver::~KSpaceFirstOrderSolver() { freeMemory(); }
@@ -36,6 +48,7 @@ void KSpaceFirstOrderSolver::freeMemory()
 
 void KSpaceFirstOrderSolver::loadInputData(const InputProvider& input)
 {
+  PhaseTimer timer(mPhaseTime[0]);
   mMatrixContainer.loadDataFromInputFile(input);
   mOutputStreamContainer.createStreams();
 }
@@ -78,6 +91,7 @@ void KSpaceFirstOrderSolver::initializeFftPlans()
 void KSpaceFirstOrderSolver::prepare()
 {
   if (mPrepared) return;
+  PhaseTimer timer(mPhaseTime[1]);
   mParameters.getHipParameters().setUpDeviceConstants(); // dims first: plans need them
   initializeFftPlans();
   preProcessing<SD::k3D>();
@@ -182,6 +196,7 @@ template<SD sd> void KSpaceFirstOrderSolver::computeMainLoop()
 void KSpaceFirstOrderSolver::runTimeSteps(size_t nSteps)
 {
   prepare();
+  PhaseTimer timer(mPhaseTime[2]);
   mPressureInScratch = false;
   for (size_t s = 0; s < nSteps && mParameters.getTimeIndex() < mParameters.getNt(); s++)
   {
@@ -243,6 +258,11 @@ void KSpaceFirstOrderSolver::runTimeSteps(size_t nSteps)
 template<SD sd> void KSpaceFirstOrderSolver::postProcessing()
 { // KSpaceFirstOrderSolver.cpp:950-1053 (streams part); p_final/u_final stay on the device until asked for
   using OI = OutputStreamContainer::OutputStreamIdx;
+  {
+    PhaseTimer loop(mPhaseTime[2]); // launches still in flight belong to the time loop
+    kwCheck(kw_sync(mParameters.getHipParameters().getContext()));
+  }
+  PhaseTimer timer(mPhaseTime[3]);
   // average intensity from the stored p and u_non_staggered series (:982-987)
   if (mParameters.getStoreQTermFlag() || mParameters.getStoreIntensityAvgFlag()) computeAverageIntensities();
   mOutputStreamContainer.postProcessStreams();

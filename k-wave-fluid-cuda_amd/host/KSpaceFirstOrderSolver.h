@@ -35,6 +35,9 @@ class KSpaceFirstOrderSolver
   OutputStreamContainer& getOutputStreamContainer() { return mOutputStreamContainer; }
   /// true once prepare() has chosen the hand-written FFT pipeline for this grid (false: rocFFT + one kernel per stage)
   bool usesFusedPipeline() const { return mFused; }
+  /// wall-clock seconds spent so far in: 0 data loading, 1 pre-processing, 2 the time loop, 3 post-processing — what
+  /// the reference writes into the header of the output file (Hdf5FileHeader.cpp:372-384)
+  double getPhaseTime(int phase) const { return mPhaseTime[phase]; }
   /// "kspaceFirstOrder-HIP" code name (reference: getCodeName, KSpaceFirstOrderSolver.h)
   std::string getCodeName() const { return "kspaceFirstOrder-HIP v0.1 (gfx950)"; }
 
@@ -92,6 +95,7 @@ class KSpaceFirstOrderSolver
   OutputStreamContainer mOutputStreamContainer;
   Parameters&           mParameters;
   bool                  mPrepared = false;
+  double                mPhaseTime[4] = {0.0, 0.0, 0.0, 0.0};
   bool                  mFused    = false;   // fused pipeline active for this grid
   bool                  mTermsFused = false; // pressure terms of this step already produced by the density stage
   bool                  mVelocityChained = false; // x-spectra of u handed over by the velocity stage this step

@@ -2,7 +2,11 @@
 // output file (main.cpp:840-966 sequence; dataset shapes IndexOutputStream.cpp:91-117, WholeDomainOutputStream.cpp,
 // KSpaceFirstOrderSolver.cpp:952-973,1100-1169), plus a writer for synthetic input files.
 #include <algorithm>
+#include <cstdio>
 #include <cstring>
+#include <string>
+#include <thread>
+#include <unistd.h>
 #include <exception>
 
 #include "../CompressHelper.h"
@@ -26,6 +30,33 @@ void kwh_write_output(kwh_solver* s, const std::string& path, unsigned compressi
   out.create(path);
   out.setOutputLayout(true, compressionLevel); // chunked like the reference's output; -c N deflate level
   out.writeHeader("output", "k-Wave output written by kspaceFirstOrder-HIP");
+  { // the rest of the output header (Hdf5FileHeader.cpp:78-87, :340-384): host, cores, memory, phase times as strings
+    char host[256] = "unknown";
+    gethostname(host, sizeof(host) - 1);
+    out.writeStringAttribute("/", "host_names", host);
+    out.writeStringAttribute("/", "number_of_cpu_cores", std::to_string(std::max(1u, std::thread::hardware_concurrency())));
+    long rssKb = 0, peakKb = 0;
+    if (FILE* f = std::fopen("/proc/self/status", "r"))
+    {
+      char line[256];
+      while (std::fgets(line, sizeof(line), f))
+      {
+        std::sscanf(line, "VmRSS: %ld kB", &rssKb);
+        std::sscanf(line, "VmHWM: %ld kB", &peakKb);
+      }
+      std::fclose(f);
+    }
+    out.writeStringAttribute("/", "total_memory_in_use", std::to_string(rssKb >> 10) + " MB");
+    out.writeStringAttribute("/", "peak_core_memory_in_use", std::to_string(peakKb >> 10) + " MB");
+    auto seconds = [](double t) { char b[32]; std::snprintf(b, sizeof(b), "%8.2fs", t); return std::string(b); };
+    const KSpaceFirstOrderSolver& sv = *s->solver;
+    const double total = sv.getPhaseTime(0) + sv.getPhaseTime(1) + sv.getPhaseTime(2) + sv.getPhaseTime(3);
+    out.writeStringAttribute("/", "total_execution_time", seconds(total));
+    out.writeStringAttribute("/", "data_loading_phase_execution_time", seconds(sv.getPhaseTime(0)));
+    out.writeStringAttribute("/", "pre-processing_phase_execution_time", seconds(sv.getPhaseTime(1)));
+    out.writeStringAttribute("/", "simulation_phase_execution_time", seconds(sv.getPhaseTime(2)));
+    out.writeStringAttribute("/", "post-processing_phase_execution_time", seconds(sv.getPhaseTime(3)));
+  }
   const DimensionSizes dims = params.getGlobalDimensionSizes();
   out.writeScalarValue(kNxName, dims.nx);
   out.writeScalarValue(kNyName, dims.ny);

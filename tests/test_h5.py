@@ -75,6 +75,12 @@ def test_file_driven_run_equals_memory_run_and_output_file(h5io, syn, tmp_path):
     assert np.array_equal(h5io.read_dataset(path_out, "p").reshape(15, nsens), mem.stream("p"))
     assert np.array_equal(h5io.read_dataset(path_out, "p_final"), mem.field("p"))
     assert int(h5io.read_dataset(path_out, "t_index").ravel()[0]) == 15
+    for attr in ("created_by", "creation_date", "file_description", "major_version", "minor_version", "host_names",
+                 "number_of_cpu_cores", "total_memory_in_use", "peak_core_memory_in_use", "total_execution_time",
+                 "data_loading_phase_execution_time", "pre-processing_phase_execution_time",
+                 "simulation_phase_execution_time", "post-processing_phase_execution_time"):
+        assert h5io.read_attribute(path_out, "/", attr) != "", attr         # Hdf5FileHeader.cpp:71-87
+    assert h5io.read_attribute(path_out, "/", "simulation_phase_execution_time").strip().endswith("s")
     # the simulation flags and the PML description travel from the input to the output file (Parameters.cpp:559-647)
     for name in ("Nx", "Ny", "Nz", "Nt", "dt", "dx", "dy", "dz", "c_ref", "pml_x_size", "pml_y_size", "pml_z_size",
                  "pml_x_alpha", "pml_y_alpha", "pml_z_alpha", "p_source_flag", "p0_source_flag", "transducer_source_flag",
