@@ -200,6 +200,13 @@ def main():
         return run_distributed(args)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # started without the launcher: become the parent of `torch.distributed.run` (nothing has touched the GPU yet)
+        import subprocess
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", os.environ.get("MASTER_PORT", "29541"),
+               os.path.abspath(__file__)] + sys.argv[1:]
+        return subprocess.call(cmd, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
     if args.gpus > 1 or world > 1:
         return run_distributed(args)
 
