@@ -29,6 +29,12 @@ KWH_API int kwh_h5_dataset_info(const char* path, const char* name, uint64_t dim
 /* dims = (x, y, z, t); t = 0 for a 3-D dataset, > 0 for the per-cuboid series "/<stream>/<cuboid>" of a corners mask */
 KWH_API int kwh_h5_dataset_info_4d(const char* path, const char* name, uint64_t dims[4], int32_t* dtype, int32_t* is_complex);
 KWH_API int kwh_h5_read(const char* path, const char* name, void* dst, uint64_t n, int32_t dtype);
+KWH_API int kwh_h5_dataset_exists(const char* path, const char* name, int32_t* exists);
+/* planes [z0, z0 + n_planes) of a 3-D float dataset: the part of a grid-sized input array one slab rank needs */
+KWH_API int kwh_h5_read_planes(const char* path, const char* name, uint64_t z0, uint64_t n_planes, float* dst);
+/* file of any type ("input", "output") from in-memory datasets; kwh_write_input_file is this with type "input" */
+KWH_API int kwh_write_file(const char* path, const char* file_type, const char* description, const kwh_dataset* sets,
+                           size_t n, const int32_t* is_complex);
 KWH_API int kwh_h5_read_attribute(const char* path, const char* dataset, const char* attr, char* out, uint64_t cap);
 /* integer or float attribute (the compression parameters c_harmonics, c_period, ... of a coefficient dataset) */
 KWH_API int kwh_h5_read_numeric_attribute(const char* path, const char* dataset, const char* attr, double* out);

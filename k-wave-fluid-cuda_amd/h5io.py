@@ -101,6 +101,78 @@ def read_dataset(path: str, name: str) -> np.ndarray:
     return out
 
 
+# every dataset a k-Wave 1.1 input file may hold (main.cpp:446-563, Utils/MatrixNames.h:48-275)
+INPUT_DATASETS = (
+    "Nx", "Ny", "Nz", "Nt", "dt", "dx", "dy", "dz", "c_ref", "pml_x_size", "pml_y_size", "pml_z_size", "pml_x_alpha",
+    "pml_y_alpha", "pml_z_alpha", "ux_source_flag", "uy_source_flag", "uz_source_flag", "p_source_flag", "p0_source_flag",
+    "transducer_source_flag", "nonuniform_grid_flag", "nonlinear_flag", "absorbing_flag", "sensor_mask_type",
+    "u_source_mode", "p_source_mode", "u_source_many", "p_source_many", "alpha_power",
+    "c0", "rho0", "rho0_sgx", "rho0_sgy", "rho0_sgz", "BonA", "alpha_coeff",
+    "ddx_k_shift_pos_r", "ddx_k_shift_neg_r", "ddy_k_shift_pos", "ddy_k_shift_neg", "ddz_k_shift_pos", "ddz_k_shift_neg",
+    "x_shift_neg_r", "y_shift_neg_r", "z_shift_neg_r", "pml_x", "pml_x_sgx", "pml_y", "pml_y_sgy", "pml_z", "pml_z_sgz",
+    "dxudxn", "dyudyn", "dzudzn", "dxudxn_sgx", "dyudyn_sgy", "dzudzn_sgz",
+    "p0_source_input", "p_source_index", "p_source_input", "u_source_index", "ux_source_input", "uy_source_input",
+    "uz_source_input", "transducer_source_input", "delay_mask", "sensor_mask_index", "sensor_mask_corners")
+
+
+def dataset_exists(path: str, name: str) -> bool:
+    L = load_h5()
+    L.kwh_h5_dataset_exists.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(C.c_int32)]
+    v = C.c_int32()
+    _h5check(L.kwh_h5_dataset_exists(path.encode(), name.encode(), C.byref(v)))
+    return bool(v.value)
+
+
+def read_planes(path: str, name: str, z0: int, z1: int) -> np.ndarray:
+    """Planes [z0, z1) of a grid-sized float dataset as [z1 - z0][ny][nx]."""
+    (nx, ny, _nz), _, _ = dataset_info(path, name)
+    out = np.empty((z1 - z0, ny, nx), dtype=np.float32)
+    L = load_h5()
+    L.kwh_h5_read_planes.argtypes = [C.c_char_p, C.c_char_p, C.c_uint64, C.c_uint64, C.c_void_p]
+    _h5check(L.kwh_h5_read_planes(path.encode(), name.encode(), z0, z1 - z0, out.ctypes.data))
+    return out
+
+
+def read_problem(path: str, zslab=None) -> Dict[str, np.ndarray]:
+    """The datasets of an input file as a problem dict (what HostSolver / dist.partition_problem take).  zslab = (z0, z1)
+    reads only those planes of the grid-sized arrays (one rank of a slab-decomposed run; pass the result to
+    partition_problem(..., arrays_are_local=True))."""
+    pr: Dict[str, np.ndarray] = {}
+    dims = tuple(int(read_dataset(path, k).ravel()[0]) for k in ("Nx", "Ny", "Nz"))
+    for name in INPUT_DATASETS:
+        if not dataset_exists(path, name):
+            continue
+        shape, dtype, _ = dataset_info(path, name)
+        if zslab is not None and shape == dims and dtype == "float" and dims[2] > 1:
+            pr[name] = read_planes(path, name, int(zslab[0]), int(zslab[1]))
+        else:
+            pr[name] = read_dataset(path, name)
+    return pr
+
+
+def write_file(datasets: Dict[str, np.ndarray], path: str, file_type: str = "output",
+               description: str = "k-Wave output written by kwave_amd") -> None:
+    """Write named arrays (shape = HDF5 dims, i.e. (z, y, x) order; float32 or uint64) as a k-Wave file of the given type."""
+    L = load_h5()
+    L.kwh_write_file.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.POINTER(Dataset), C.c_size_t, C.POINTER(C.c_int32)]
+    keep = []
+    sets = (Dataset * len(datasets))()
+    cplx = (C.c_int32 * len(datasets))()
+    for i, (name, a) in enumerate(datasets.items()):
+        a = np.asarray(a)
+        arr = np.ascontiguousarray(a, dtype=np.uint64 if a.dtype == np.uint64 else np.float32)
+        shp = list(arr.shape)[::-1]
+        while len(shp) < 3:
+            shp.append(1)
+        if len(shp) != 3:
+            raise ValueError(f"{name}: at most 3 dimensions")
+        nm = name.encode()
+        keep += [arr, nm]
+        sets[i].name, sets[i].data, sets[i].dtype = nm, arr.ctypes.data, (1 if arr.dtype == np.uint64 else 0)
+        sets[i].nx, sets[i].ny, sets[i].nz = shp
+    _h5check(L.kwh_write_file(path.encode(), file_type.encode(), description.encode(), sets, len(datasets), cplx))
+
+
 def read_attribute(path: str, dataset: str, attr: str) -> str:
     buf = C.create_string_buffer(256)
     _h5check(load_h5().kwh_h5_read_attribute(path.encode(), dataset.encode(), attr.encode(), buf, 256))

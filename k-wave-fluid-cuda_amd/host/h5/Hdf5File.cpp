@@ -108,6 +108,23 @@ void Hdf5File::readCompleteDataset(const std::string& name, size_t nElements, si
   if (nElements == 0) return;
   if (H5LTread_dataset(mFile, name.c_str(), H5T_NATIVE_UINT64, data) < 0) fail("Error: cannot read dataset \"" + name + "\"");
 }
+void Hdf5File::readPlanes(const std::string& name, size_t z0, size_t nPlanes, float* data) const
+{
+  const DimensionSizes d = getDatasetDimensionSizes(name);
+  if (d.nt > 0 || z0 + nPlanes > d.nz) fail("Error: dataset \"" + name + "\" does not hold the requested planes");
+  if (nPlanes == 0) return;
+  hid_t set = H5Dopen2(mFile, name.c_str(), H5P_DEFAULT);
+  if (set < 0) fail("Error: cannot open dataset \"" + name + "\"");
+  hid_t fspace = H5Dget_space(set);
+  const hsize_t start[3] = {z0, 0, 0}, count[3] = {nPlanes, d.ny, d.nx};
+  H5Sselect_hyperslab(fspace, H5S_SELECT_SET, start, nullptr, count, nullptr);
+  hid_t mspace = H5Screate_simple(3, count, nullptr);
+  const herr_t st = H5Dread(set, H5T_NATIVE_FLOAT, mspace, fspace, H5P_DEFAULT, data);
+  H5Sclose(mspace);
+  H5Sclose(fspace);
+  H5Dclose(set);
+  if (st < 0) fail("Error: cannot read dataset \"" + name + "\"");
+}
 // Chunking of output datasets as the reference lays them out: one z-plane per chunk for 2-D / 3-D data, 256 KiB - 4 MiB
 // pieces for long 1-D data (RealMatrix.cpp:88-110), deflate at the requested level (Hdf5File.cpp:330-350).
 static DimensionSizes chunkSizes(const DimensionSizes& d)

@@ -37,6 +37,9 @@ class Hdf5File
   MatrixDataType   readMatrixDataType(const std::string& name) const;
   MatrixDomainType readMatrixDomainType(const std::string& name) const;
   void readCompleteDataset(const std::string& name, size_t nElements, float* data) const;  // :791-803
+  /// planes [z0, z0 + nPlanes) of a 3-D float dataset (readHyperSlab, :817-870) — what one rank of a slab-decomposed
+  /// run needs of a grid-sized input array
+  void readPlanes(const std::string& name, size_t z0, size_t nPlanes, float* data) const;
   void readCompleteDataset(const std::string& name, size_t nElements, size_t* data) const; // :805-815
   /// write a whole 3-D dataset (x,y,z sizes) + its data_type / domain_type attributes
   void writeMatrix(const std::string& name, const DimensionSizes& dims, const float* data, MatrixDomainType domain);

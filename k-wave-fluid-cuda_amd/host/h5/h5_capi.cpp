@@ -272,12 +272,22 @@ KWH_API int kwh_write_output_file(kwh_solver* s, const char* path)
 
 /* write an input file from in-memory datasets (the synthetic generator's output); complex[i] != 0 marks interleaved
  * complex datasets (domain_type "complex") */
+KWH_API int kwh_write_file(const char* path, const char* file_type, const char* description, const kwh_dataset* sets,
+                           size_t n, const int32_t* is_complex);
 KWH_API int kwh_write_input_file(const char* path, const kwh_dataset* sets, size_t n, const int32_t* is_complex)
+{
+  return kwh_write_file(path, "input", "synthetic k-Wave input written by kwave_amd.synthetic", sets, n, is_complex);
+}
+/* the same for any file type ("input" / "output"): the output file of a slab-decomposed run is assembled by rank 0 from
+ * gathered datasets; output files get the chunked layout of the reference's output */
+KWH_API int kwh_write_file(const char* path, const char* file_type, const char* description, const kwh_dataset* sets,
+                           size_t n, const int32_t* is_complex)
 {
   KWH_TRY
   Hdf5File f;
   f.create(path);
-  f.writeHeader("input", "synthetic k-Wave input written by kwave_amd.synthetic");
+  if (std::string(file_type) == "output") f.setOutputLayout(true, 0);
+  f.writeHeader(file_type, description);
   for (size_t i = 0; i < n; i++)
   {
     const DimensionSizes d(sets[i].nx, sets[i].ny, sets[i].nz);
@@ -288,6 +298,23 @@ KWH_API int kwh_write_input_file(const char* path, const kwh_dataset* sets, size
       f.writeMatrix(sets[i].name, d, static_cast<const size_t*>(sets[i].data));
   }
   f.close();
+  KWH_CATCH
+}
+
+KWH_API int kwh_h5_dataset_exists(const char* path, const char* name, int32_t* exists)
+{
+  KWH_TRY
+  Hdf5File f;
+  f.open(path, true);
+  *exists = f.datasetExists(name) ? 1 : 0;
+  KWH_CATCH
+}
+KWH_API int kwh_h5_read_planes(const char* path, const char* name, uint64_t z0, uint64_t n_planes, float* dst)
+{
+  KWH_TRY
+  Hdf5File f;
+  f.open(path, true);
+  f.readPlanes(name, z0, n_planes, dst);
   KWH_CATCH
 }
 

@@ -1,0 +1,113 @@
+"""File-driven multi-GPU run: one process per GPU, Z-slab decomposition (dist.py), k-Wave HDF5 input and output files.
+
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 \\
+      -m kwave_amd.run_slab -i in.h5 -o out.h5 --p_raw --p_max --p_final
+
+Every rank reads its own planes of the grid-sized input arrays (and the small datasets whole), runs its slab, and
+rank 0 writes the output file from the gathered pieces: sampled series / aggregates in the order of the global sensor
+mask, whole-domain streams and final fields with the slabs stacked along z, and the scalars of the reference's output
+file (Parameters.cpp:559-647).  The reference is single-GPU; the flags are the subset of its command line
+(CommandLineParameters.cpp:264-292) that the slab path carries: index sensor masks, p / u raw and aggregated streams.
+"""
+from __future__ import annotations
+
+import argparse
+import os
+import sys
+
+import numpy as np
+
+STREAM_FLAGS = ("p_raw", "p_rms", "p_max", "p_min", "p_max_all", "p_min_all", "p_final",
+                "u_raw", "u_rms", "u_max", "u_min", "u_max_all", "u_min_all", "u_final")
+OUTPUT_SCALARS = ("Nx", "Ny", "Nz", "Nt", "dt", "dx", "dy", "dz", "c_ref", "pml_x_size", "pml_y_size", "pml_z_size",
+                  "pml_x_alpha", "pml_y_alpha", "pml_z_alpha", "p_source_flag", "p0_source_flag", "transducer_source_flag",
+                  "ux_source_flag", "uy_source_flag", "uz_source_flag", "nonuniform_grid_flag", "absorbing_flag",
+                  "nonlinear_flag", "u_source_many", "u_source_mode", "p_source_many", "p_source_mode", "alpha_power",
+                  "sensor_mask_type")
+
+
+def main(argv=None) -> int:
+    ap = argparse.ArgumentParser(prog="kwave_amd.run_slab", description=__doc__.split("\n")[0])
+    ap.add_argument("-i", dest="input", required=True)
+    ap.add_argument("-o", dest="output", required=True)
+    ap.add_argument("-s", dest="start", type=int, default=1, help="first sampled time step (1-based, as on the reference's command line)")
+    ap.add_argument("--benchmark", type=int, default=0)
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend: nccl (= RCCL) or gloo (ranks sharing a GPU)")
+    ap.add_argument("-p", action="store_true", help="same as --p_raw")
+    ap.add_argument("-u", action="store_true", help="same as --u_raw")
+    for f in STREAM_FLAGS:
+        ap.add_argument("--" + f, action="store_true")
+    a = ap.parse_args(argv)
+    a.p_raw |= a.p
+    a.u_raw |= a.u
+
+    import torch
+    import torch.distributed as dist
+    import kwave_amd  # noqa: F401
+    from kwave_amd import h5io
+    from kwave_amd.dist import DistSolver, partition_problem, slab_range
+
+    dist.init_process_group(a.backend)
+    rank, world = dist.get_rank(), dist.get_world_size()
+    dev = int(os.environ.get("LOCAL_RANK", "0")) if a.backend == "nccl" else 0
+    if dev >= torch.cuda.device_count():
+        dev = 0
+    torch.cuda.set_device(dev)
+
+    nz = int(h5io.read_dataset(a.input, "Nz").ravel()[0])
+    z0, z1 = slab_range(nz, rank, world)
+    pr = h5io.read_problem(a.input, zslab=(z0, z1))
+    if "sensor_mask_corners" in pr:
+        raise SystemExit("run_slab: corner (cuboid) sensor masks are not supported in slab mode")
+    loc, info = partition_problem(pr, rank, world, arrays_are_local=True)
+    opts = {f: 1 for f in STREAM_FLAGS if getattr(a, f)}
+    sim = DistSolver(loc, rank, world, nz, device_index=dev, sampling_start=a.start - 1, benchmark_steps=a.benchmark, **opts)
+    nt = a.benchmark or int(np.asarray(pr["Nt"]).ravel()[0])
+    sim.run(nt)
+    sim.finish()
+
+    piece = {"pos": info.get("sensor_positions", np.zeros(0, dtype=np.int64)), "streams": {}, "fields": {}}
+    for name in sim.stream_names():
+        piece["streams"][name] = sim.stream(name)
+    if a.p_final:
+        piece["fields"]["p_final"] = sim.field("p")
+    if a.u_final:
+        for c in "xyz":
+            piece["fields"][f"u{c}_final"] = sim.field("u" + c)
+    gathered = [None] * world if rank == 0 else None
+    dist.gather_object(piece, gathered, dst=0)
+    if rank == 0:
+        nx, ny = (int(np.asarray(pr[k]).ravel()[0]) for k in ("Nx", "Ny"))
+        plane = nx * ny
+        out = {}
+        for k in OUTPUT_SCALARS:
+            if k in pr:
+                out[k] = np.asarray(pr[k]).reshape(1, 1, 1)
+        out["Nz"] = np.array([[[nz]]], dtype=np.uint64)
+        out["Nt"] = np.array([[[nt]]], dtype=np.uint64)
+        out["t_index"] = np.array([[[sim.t]]], dtype=np.uint64)
+        nsens = int(np.asarray(pr["sensor_mask_index"]).size) if "sensor_mask_index" in pr else 0
+        for name in piece["streams"]:
+            parts = [g["streams"][name] for g in gathered]
+            if name.endswith("_all"):      # whole-domain aggregate: the slabs stacked along z
+                out[name] = np.concatenate([p.reshape(-1, ny, nx) for p in parts], axis=0)
+                continue
+            steps = max((p.size // max(g["pos"].size, 1) for p, g in zip(parts, gathered) if g["pos"].size), default=0)
+            full = np.zeros((steps, nsens), dtype=np.float32)
+            for p, g in zip(parts, gathered):
+                if g["pos"].size:
+                    full[:, g["pos"]] = p.reshape(steps, g["pos"].size)
+            out[name] = full.reshape(1, steps, nsens)     # dataset dims (Nsens, steps, 1)
+        for name in piece["fields"]:
+            out[name] = np.concatenate([g["fields"][name].reshape(-1, ny, nx) for g in gathered], axis=0)
+        assert all(v.size == plane * nz for k, v in out.items() if k.endswith(("_final", "_all")))
+        h5io.write_file(out, a.output, "output", f"k-Wave output written by kwave_amd.run_slab ({world} slab ranks)")
+        print(f"time steps: {sim.t}, ranks: {world}, output: {a.output}")
+    sim.close()
+    dist.barrier()
+    dist.destroy_process_group()
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -92,3 +92,39 @@ def test_slab_ranks_other_media(orc, syn, tmp_path, world, dims, source, mode, m
     for f in ("p", "ux", "uz", "rhoy"):
         assert rel_l2(res[f], o.field(f)) < TOL, f
     o.close()
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_file_driven_slab_run_matches_the_single_gpu_output_file(syn, tmp_path, world):
+    """kwave_amd.run_slab: input file -> slab ranks (each reads its own planes) -> one output file assembled by rank 0,
+    against the output file of a single-GPU run of the same input."""
+    import kwave_amd  # noqa: F401
+    from kwave_amd import h5io
+    if not os.path.exists(h5io.H5_LIB_PATH):
+        pytest.skip("HDF5 component not built")
+    nt, start = 18, 3
+    pr = syn.make_problem(32, 48, 64, heterogeneous=True, nonlinear=True, absorbing=True, source="p_source", source_mode=2,
+                          source_many=1, nt=nt, pml_size=4, sensor="random")
+    path_in, one, many = (str(tmp_path / n) for n in ("in.h5", "one.h5", f"slab{world}.h5"))
+    h5io.write_input_file(pr, path_in)
+    flags = dict(p_raw=1, p_max=1, u_rms=1, p_final=1, u_final=1, p_max_all=1, u_min_all=1)
+    fs = h5io.FileSolver(path_in, sampling_start=start - 1, **flags)
+    fs.run(nt)
+    fs.finish()
+    fs.write_output(one)
+    fs.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr",
+           "127.0.0.1", "--master-port", str(29750 + world), "-m", "kwave_amd.run_slab", "-i", path_in, "-o", many,
+           "-s", str(start), "--backend", "gloo"] + ["--" + f for f in flags]
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600,
+                       cwd=os.path.dirname(HERE), env=dict(os.environ, OMP_NUM_THREADS="4", HSA_ENABLE_IPC_MODE_LEGACY="0"))
+    assert r.returncode == 0, r.stdout[-4000:]
+    assert h5io.read_attribute(many, "/", "file_type") == "output"
+    for name in ("Nx", "Ny", "Nz", "Nt", "t_index", "dt", "c_ref", "pml_z_size", "p_source_flag", "p_source_mode",
+                 "absorbing_flag", "alpha_power"):
+        assert np.array_equal(h5io.read_dataset(many, name), h5io.read_dataset(one, name)), name
+    assert h5io.dataset_info(many, "p") == h5io.dataset_info(one, "p")
+    for name in ("p", "p_max", "ux_rms", "uz_rms", "p_final", "ux_final", "uz_final", "p_max_all", "uy_min_all"):
+        a, b = h5io.read_dataset(many, name), h5io.read_dataset(one, name)
+        assert a.shape == b.shape, name
+        assert rel_l2(a, b) < TOL, name
