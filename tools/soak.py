@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Sustained run of the bench workload: N steps at 256^3 in legs, rate per leg and max|p| at the sensor plane per leg
-(the PML absorbs the p0 pulse: the field must stay finite and decay)."""
+"""Sustained run of the bench workload: N steps in legs, rate per leg and max|p| per leg (the PML absorbs the p0
+pulse: the field must stay finite and decay).   python tools/soak.py [n = 256] [legs = 10] [steps per leg = 1000]"""
 import sys
 import os
 import numpy as np
@@ -10,7 +10,7 @@ import kwave_amd  # noqa: E402,F401
 from kwave_amd import synthetic  # noqa: E402
 from kwave_amd.solver import HostSolver  # noqa: E402
 
-n, legs, per = 256, 10, 1000
+n, legs, per = (int(a) for a in (sys.argv[1:4] + ["256", "10", "1000"][len(sys.argv) - 1:]))
 pr = synthetic.make_problem(n, heterogeneous=True, nonlinear=True, absorbing=True, source="p0", nt=legs * per + 8)
 sim = HostSolver(pr, p_max=1)
 sim.run(5)
