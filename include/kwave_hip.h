@@ -354,6 +354,13 @@ KW_API kw_status kw_fused_absorption_pressure(kw_ctx* ctx, float* p, const float
 KW_API kw_status kw_fused_probe(kw_ctx* ctx, int which, const float* padded_reduced_operator);
 /* FFT part of scaleSource (KSpaceFirstOrderSolver.cpp:2346-2351; .cu:740-745), in place on scaled_source */
 KW_API kw_status kw_fused_scale_source(kw_ctx* ctx, float* scaled_source, const float* source_kappa_padded);
+/* Non-staggered velocity (computeShiftedVelocity, KSpaceFirstOrderSolver.cpp:2714-2735): one kernel per axis instead of
+ * R2C + computeVelocityShiftIn{X,Y,Z} (SolverCudaKernels.cu:2617-2710) + C2R.  out = F^-1{ filter .* F{in} } along
+ * `axis` (0 x, 1 y, 2 z) of the real [nz][ny][nx] array; filter = device array of N_axis complex values, the
+ * Hermitian extension of the reference's half-length shift vector with the 1/N of the transform pair folded in:
+ *   filter[k] = shift[k]/N (0 < k < N/2), filter[N-k] = conj(filter[k]), filter[0] = Re(shift[0])/N,
+ *   filter[N/2] = Re(shift[N/2])/N  (what C2R keeps of those two bins).  Single-GPU pipeline only. */
+KW_API kw_status kw_fused_shift_velocity(kw_ctx* ctx, int axis, const float* in, float* out, const float* filter);
 
 /* ------------------------------------------------------------------------------------------------------------------
  * Sampling kernels — replace namespace OutputStreamsCudaKernels (OutputStreams/OutputStreamsCudaKernels.cuh:47-106)

@@ -131,6 +131,7 @@ _SIG: Dict[str, list] = {
     "kw_fused_scratch_bytes": [_P, C.POINTER(C.c_size_t)],
     "kw_fused_create_with_scratch": [_P, _P, _P],
     "kw_fused_supported": [_P, C.POINTER(C.c_int)],
+    "kw_fused_shift_velocity": [_P, C.c_int, _P, _P, _P],
     "kw_fused_create": [_P],
     "kw_fused_destroy": [_P],
     "kw_fused_reduced_elems": [_P, C.POINTER(C.c_size_t)],

@@ -233,7 +233,10 @@ __global__ __launch_bounds__(Geo<L>::THREADS) void k_ypass(PassArgs a)
 // =====================================================================================================================
 // z-fused: forward along z, spectral multiply, inverse along z.  Tile (y = blockIdx.y, kx tile = blockIdx.x).
 // =====================================================================================================================
-enum ZMode { Z_PGRAD = 0, Z_VGRAD = 1, Z_ABSORB = 2, Z_SOURCE = 3 };
+// Z_SHIFT: plain "transform along a line, multiply bin k by a complex H[k], transform back" on lines with arbitrary
+// strides — the half-cell shift of a staggered velocity (computeVelocityShiftInY / InZ) done on pairs of real
+// x-neighbours packed as one complex value
+enum ZMode { Z_PGRAD = 0, Z_VGRAD = 1, Z_ABSORB = 2, Z_SOURCE = 3, Z_SHIFT = 4 };
 
 struct ZArgs
 {
@@ -248,6 +251,7 @@ struct ZArgs
   uint32_t      arr0; // first array of this launch
   uint32_t      narr; // arrays processed back to back by each block (VGRAD / ABSORB)
   uint32_t      ky0;  // global ky of local row 0 (slab mode: rank * ny/nranks); ny above = number of LOCAL rows
+  uint32_t      lstride, bstride; // Z_SHIFT: element stride along a line, offset per blockIdx.y (both in complex units)
 };
 
 // inverse along the line, started from the step-B register layout (thread (c,k1) holds X[k1 + R1*k2]); result:
@@ -292,10 +296,11 @@ template<int L, int MODE> __global__ __launch_bounds__(Geo<L>::THREADS) void k_z
   const uint32_t kx     = blockIdx.x * G::NL + c;
   const uint32_t ky     = blockIdx.y;
   const bool     valid  = kx < a.nxc;
-  const uint32_t zstr   = a.ny * a.P;
-  const uint32_t base   = ky * a.P + kx;
+  const uint32_t zstr   = (MODE == Z_SHIFT) ? a.lstride : a.ny * a.P;
+  const uint32_t bstr   = (MODE == Z_SHIFT) ? a.bstride : a.P;
+  const uint32_t base   = ky * bstr + kx;
   const uint32_t kxl    = min(kx, a.nxc - 1u); // pad lanes re-read the last column; their results are never stored
-  const uint32_t basel  = ky * a.P + kxl;
+  const uint32_t basel  = ky * bstr + kxl;
   // operators live in a tile-blocked layout [ky][kx tile][kz][16]: the 16 x nz values of this block's tile are one
   // contiguous run (k_import_reduced), instead of 64-B pieces a whole plane apart
   const uint32_t opbase = ((ky * (a.Pop / NLMAX) + kxl / NLMAX) * a.nz) * NLMAX + kxl % NLMAX, opzstr = NLMAX;
@@ -315,7 +320,7 @@ template<int L, int MODE> __global__ __launch_bounds__(Geo<L>::THREADS) void k_z
   }
   // spectral operator of the elements this thread will hold after the forward transform (kz = j + R1*k2)
   float kap[R2];
-  if (ACT(R1, j))
+  if (MODE != Z_SHIFT && ACT(R1, j))
   {
     const float* __restrict__ op = a.op[(MODE == Z_ABSORB) ? arr0 : 0];
 #pragma unroll
@@ -353,12 +358,20 @@ template<int L, int MODE> __global__ __launch_bounds__(Geo<L>::THREADS) void k_z
       //   Z_VGRAD  :1220-1236                      e = X*(kappa*divider);  out   = e (x) dd_neg of this array's own axis
       //   Z_ABSORB :1817-1818                      out = X*nabla
       //   Z_SOURCE :742-744                        out = X*(sourceKappa*divider)
+      if (MODE == Z_SHIFT)
+      { // SolverCudaKernels.cu:2617-2710: bin k times shift[k] / N (both folded into H by the host)
 #pragma unroll
-      for (int k2 = 0; k2 < R2; k2++)
+        for (int k2 = 0; k2 < R2; k2++) X[k2] = cmulf(X[k2], a.dd[2][j + R1 * k2]);
+      }
+      else
       {
-        float sc = kap[k2];
-        if (MODE == Z_VGRAD || MODE == Z_SOURCE) sc *= a.divider;
-        X[k2] = make_float2(X[k2].x * sc, X[k2].y * sc);
+#pragma unroll
+        for (int k2 = 0; k2 < R2; k2++)
+        {
+          float sc = kap[k2];
+          if (MODE == Z_VGRAD || MODE == Z_SOURCE) sc *= a.divider;
+          X[k2] = make_float2(X[k2].x * sc, X[k2].y * sc);
+        }
       }
       if (MODE == Z_ABSORB && ia + 1 < narr)
       {
@@ -1155,6 +1168,103 @@ __global__ __launch_bounds__(Geo<L>::THREADS, (EPI == EPI_DENSITY && L == 256) ?
       lds_barrier(); // the real tile aliases the exchange buffer
       xfwd_tail<L>(v, lds, c, f, twl, a.fout[(NA == 1) ? comp : jf], a.P, tile);
     }
+  }
+}
+
+// Half-cell shift along x (computeVelocityShiftInX, SolverCudaKernels.cu:2617-2640): rows 2c and 2c+1 travel as the
+// real and imaginary part of one complex line — the filter H is Hermitian with a real Nyquist bin (what the reference's
+// R2C -> multiply -> C2R applies to each row), so it acts on both parts independently.  One read and one write of the
+// array; loads as in k_xfwd, stores as coalesced float4 through the real tile like the x-inverse epilogues.
+struct XshiftArgs
+{
+  const float*  in;
+  float*        out;
+  const float2* tw;
+  const float2* H; // L complex: shift[k] / L on 0 < k < L/2, conjugate above, real parts at k = 0 and L/2
+};
+
+template<int L> __global__ __launch_bounds__(Geo<L>::THREADS) void k_xshift(XshiftArgs a)
+{
+  using G = Geo<L>;
+  constexpr int R1 = G::R1, R2 = G::R2;
+  constexpr int RP = L + 8, Q4 = L / 4, NQ = (2 * G::NL * Q4) / G::THREADS;
+  static_assert((2 * G::NL * Q4) % G::THREADS == 0, "tile must divide evenly");
+  __shared__ float2 lds[G::LDSX];
+  __shared__ float2 twl[G::TWN];
+  load_twiddles<L>(twl, a.tw);
+  float* ldsr = reinterpret_cast<float*>(lds);
+  const int f = threadIdx.x % G::TPL;
+  const int c = threadIdx.x / G::TPL;
+  const uint32_t tile_row0 = blockIdx.x * G::NL * 2;
+  float2 v[R1];
+  if (ACT(R2, f))
+  {
+    const float* __restrict__ ra = a.in + (tile_row0 + 2 * c) * L;
+    const float* __restrict__ rb = ra + L;
+#pragma unroll
+    for (int n1 = 0; n1 < R1; n1++) v[n1] = make_float2(ra[n1 * R2 + f], rb[n1 * R2 + f]);
+  }
+  lds_barrier(); // twiddle table visible
+  if (ACT(R2, f))
+  {
+    step_a<L, kFwd>(v, f, twl);
+#pragma unroll
+    for (int k1 = 0; k1 < R1; k1++) lds[c * G::LP + k1 * (R2 + 1) + f] = v[k1];
+  }
+  lds_barrier();
+  float2 w[R2];
+  if (ACT(R1, f))
+  {
+#pragma unroll
+    for (int n2 = 0; n2 < R2; n2++) w[n2] = lds[c * G::LP + f * (R2 + 1) + n2];
+    Dft<R2, kFwd>::run(w);
+#pragma unroll
+    for (int k2 = 0; k2 < R2; k2++) w[k2] = cmulf(w[k2], a.H[f + R1 * k2]);
+  }
+  lds_barrier();
+  if (ACT(R1, f))
+  { // natural-order spectrum of the line, the starting point of the inverse (as in xinv_lines)
+#pragma unroll
+    for (int k2 = 0; k2 < R2; k2++) lds[c * G::ZP + f + R1 * k2] = w[k2];
+  }
+  lds_barrier();
+  if (ACT(R2, f))
+  {
+#pragma unroll
+    for (int n1 = 0; n1 < R1; n1++) v[n1] = lds[c * G::ZP + n1 * R2 + f];
+  }
+  lds_barrier();
+  if (ACT(R2, f))
+  {
+    step_a<L, kInv>(v, f, twl);
+#pragma unroll
+    for (int k1 = 0; k1 < R1; k1++) lds[c * G::LP + k1 * (R2 + 1) + f] = v[k1];
+  }
+  lds_barrier();
+  if (ACT(R1, f))
+  {
+#pragma unroll
+    for (int n2 = 0; n2 < R2; n2++) w[n2] = lds[c * G::LP + f * (R2 + 1) + n2];
+    Dft<R2, kInv>::run(w);
+  }
+  lds_barrier();
+  if (ACT(R1, f))
+  {
+#pragma unroll
+    for (int k2 = 0; k2 < R2; k2++)
+    {
+      ldsr[(2 * c) * RP + f + R1 * k2]     = w[k2].x;
+      ldsr[(2 * c + 1) * RP + f + R1 * k2] = w[k2].y;
+    }
+  }
+  lds_barrier();
+#pragma unroll
+  for (int q = 0; q < NQ; q++)
+  {
+    const int e   = threadIdx.x + q * G::THREADS;
+    const int row = e / Q4;
+    const int x4  = e - row * Q4;
+    st4(a.out + (tile_row0 + row) * L + 4 * x4, *reinterpret_cast<const float4*>(&ldsr[row * RP + 4 * x4]));
   }
 }
 
@@ -1956,6 +2066,49 @@ kw_status kw_fused_absorption_pressure(kw_ctx* ctx, float* p, const float* vel_g
   }
   else if (chain_p) KW_TRY((launch_xinv<EPI_PSUM, true>(ctx, 1, x)));
   else KW_TRY(launch_xinv<EPI_PSUM>(ctx, 1, x));
+  return KW_OK;
+}
+
+// computeVelocityShiftInX/Y/Z + the two 1-D transforms around it (KSpaceFirstOrderSolver.cpp:2714-2735,
+// SolverCudaKernels.cu:2617-2710) in one kernel per axis: out = F_axis^-1{ H .* F_axis{in} }, H = full-length Hermitian
+// filter with the 1/N of the transform pair folded in (see kwave_hip.h)
+kw_status kw_fused_shift_velocity(kw_ctx* ctx, int axis, const float* in, float* out, const float* filter)
+{
+  KW_FUSED_READY(ctx);
+  auto& f = ctx->fused;
+  const kw_constants& c = ctx->c;
+  KW_REQUIRE(!f.slab && axis >= 0 && axis <= 2 && in != nullptr && out != nullptr && filter != nullptr);
+  static const char* const names[3] = { "k_xshift", "k_zfused_shift_y", "k_zfused_shift_z" };
+  KW_PROF(ctx, names[axis]);
+  if (axis == 0)
+  {
+    XshiftArgs a{ in, out, f.tw[0], reinterpret_cast<const float2*>(filter) };
+    const dim3 grid(c.ny * c.nz / (2 * nl_of(c.nx)), 1, 1);
+#define M(LEN) LAUNCH((k_xshift<LEN>), grid, dim3(Geo<LEN>::THREADS), a)
+    KW_LEN_SWITCH(c.nx, M)
+#undef M
+    return KW_OK;
+  }
+  // y / z: the real array is read as nx/2 complex columns; lines run along the axis with the matching stride
+  ZArgs z{};
+  z.in[0]  = reinterpret_cast<const float2*>(in);
+  z.out[0] = reinterpret_cast<float2*>(out);
+  z.dd[2]  = reinterpret_cast<const float2*>(filter);
+  z.tw     = f.tw[axis];
+  z.nxc    = c.nx / 2;
+  z.P      = c.nx / 2;
+  z.ny     = c.ny;
+  z.nz     = c.nz;
+  z.narr   = 1;
+  const uint32_t len   = (axis == 1) ? c.ny : c.nz;
+  const uint32_t lines = (axis == 1) ? c.nz : c.ny;
+  z.lstride = (axis == 1) ? z.P : c.ny * z.P;
+  z.bstride = (axis == 1) ? c.ny * z.P : z.P;
+  const uint32_t nl = nl_of(len);
+  const dim3 grid((z.nxc + nl - 1) / nl, lines, 1);
+#define M(LEN) LAUNCH((k_zfused<LEN, Z_SHIFT>), grid, dim3(Geo<LEN>::THREADS), z)
+  KW_LEN_SWITCH(len, M)
+#undef M
   return KW_OK;
 }
 

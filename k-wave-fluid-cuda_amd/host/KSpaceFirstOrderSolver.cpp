@@ -676,6 +676,15 @@ template<SD sd> void KSpaceFirstOrderSolver::addInitialPressureSource()
 
 template<SD sd> void KSpaceFirstOrderSolver::computeShiftedVelocity()
 { // :2714-2735
+  if (mFused && mShiftFilter[0] != nullptr)
+  { // fast path: forward transform, shift and inverse transform of an axis in one kernel (kw_fused_shift_velocity)
+    kw_ctx* ctx = mParameters.getHipParameters().getContext();
+    kwCheck(kw_fused_shift_velocity(ctx, 0, real(MI::kUxSgx).getDeviceData(), real(MI::kUxShifted).getDeviceData(), mShiftFilter[0]));
+    kwCheck(kw_fused_shift_velocity(ctx, 1, real(MI::kUySgy).getDeviceData(), real(MI::kUyShifted).getDeviceData(), mShiftFilter[1]));
+    if (mParameters.isSimulation3D())
+      kwCheck(kw_fused_shift_velocity(ctx, 2, real(MI::kUzSgz).getDeviceData(), real(MI::kUzShifted).getDeviceData(), mShiftFilter[2]));
+    return;
+  }
   HipFftComplexMatrix& tempShift = fft(MI::kTempHipFftShift);
   tempShift.computeR2CFft1DX(real(MI::kUxSgx));
   SolverHipKernels::computeVelocityShiftInX(tempShift, mMatrixContainer.getMatrix<ComplexMatrix>(MI::kXShiftNegR));
@@ -717,13 +726,42 @@ void KSpaceFirstOrderSolver::initializeFusedPipeline()
     mNabla2Padded = importPadded(MI::kAbsorbNabla2);
   }
   if (mMatrixContainer.has(MI::kSourceKappa)) mSourceKappaPadded = importPadded(MI::kSourceKappa);
+  if (mParameters.needsShiftedVelocity() && !mParameters.isSlabDecomposed())
+  { // filters of the one-kernel-per-axis shift: the half-length shift vectors of the input file extended to full length
+    // the way R2C -> multiply -> C2R acts on a real line (imaginary parts of the DC and Nyquist bins are dropped), with
+    // the 1/N of the transform pair folded in (the reference multiplies by it in computeVelocityShiftIn*, .cu:2617-2710)
+    kw_ctx* ctx = mParameters.getHipParameters().getContext();
+    const DimensionSizes dims = mParameters.getFullDimensionSizes();
+    const size_t n[3]   = {dims.nx, dims.ny, dims.nz};
+    const MI     idx[3] = {MI::kXShiftNegR, MI::kYShiftNegR, MI::kZShiftNegR};
+    const int    axes   = mParameters.isSimulation3D() ? 3 : 2;
+    for (int a = 0; a < axes; a++)
+    {
+      const float* half = mMatrixContainer.getMatrix<ComplexMatrix>(idx[a]).getHostData(); // (re, im) pairs
+      const float  divider = 1.0f / static_cast<float>(n[a]);
+      std::vector<float> full(2 * n[a], 0.0f);
+      full[0] = half[0] * divider;
+      for (size_t k = 1; k < (n[a] + 1) / 2; k++)
+      {
+        full[2 * k]     = full[2 * (n[a] - k)] = half[2 * k] * divider;
+        full[2 * k + 1] = half[2 * k + 1] * divider;
+        full[2 * (n[a] - k) + 1] = -(half[2 * k + 1] * divider);
+      }
+      if (n[a] % 2 == 0) full[n[a]] = half[n[a]] * divider; // index 2 * (n/2): real part of the Nyquist bin
+      void* d = nullptr;
+      kwCheck(kw_malloc(ctx, full.size() * sizeof(float), &d));
+      kwCheck(kw_memcpy_h2d(ctx, d, full.data(), full.size() * sizeof(float)));
+      mShiftFilter[a] = static_cast<float*>(d);
+    }
+  }
 }
 
 void KSpaceFirstOrderSolver::releaseFusedPipeline()
 {
   kw_ctx* ctx = mParameters.getHipParameters().getContext();
   if (!ctx) return;
-  float** bufs[] = { &mKappaPadded, &mNabla1Padded, &mNabla2Padded, &mSourceKappaPadded };
+  float** bufs[] = { &mKappaPadded, &mNabla1Padded, &mNabla2Padded, &mSourceKappaPadded, &mShiftFilter[0], &mShiftFilter[1],
+                     &mShiftFilter[2] };
   for (float** b : bufs)
   {
     if (*b) kw_free(ctx, *b);

@@ -105,6 +105,7 @@ class KSpaceFirstOrderSolver
   // previous step) are recorded once and replayed (kw_graph_*)
   kw_graph*             mStepGraph = nullptr;
   bool                  mUseStepGraph = false, mStepGraphFailed = false;
+  float*                mShiftFilter[3] = {nullptr, nullptr, nullptr}; // kw_fused_shift_velocity filters (x, y, z)
   float*                mKappaPadded = nullptr;
   float*                mNabla1Padded = nullptr;
   float*                mNabla2Padded = nullptr;

@@ -63,6 +63,42 @@ def test_shifted_velocity_matches_oracle(dev, orc, syn, axis):
     assert rel_l2(d_o.download(), orc.shifted_velocity(u, sh, axis)) < 1e-6
 
 
+def hermitian_filter(half, n):
+    """Full-length filter of kw_fused_shift_velocity from the reference's half-length shift vector (see kwave_hip.h)."""
+    half = np.asarray(half, dtype=np.float32).reshape(-1, 2)
+    h = half[:, 0].astype(np.complex64) + 1j * half[:, 1].astype(np.complex64)
+    out = np.zeros(n, dtype=np.complex64)
+    out[0] = h[0].real
+    for k in range(1, (n + 1) // 2):
+        out[k], out[n - k] = h[k], np.conj(h[k])
+    if n % 2 == 0:
+        out[n // 2] = h[n // 2].real
+    return (out / np.float32(n)).astype(np.complex64)
+
+
+@pytest.mark.parametrize("dims", [(32, 48, 16), (64, 16, 96), (256, 32, 16), (16, 256, 32), (32, 16, 512), (80, 72, 120)])
+@pytest.mark.parametrize("axis", [0, 1, 2])
+def test_fused_shift_velocity_matches_oracle(orc, syn, dims, axis):
+    """One kernel per axis (two real x-neighbours or rows packed into one complex line) against the oracle's
+    R2C -> shift -> C2R restatement, for line lengths of every factorisation family."""
+    import kwave_amd  # noqa: F401
+    from kwave_amd import capi
+    nx, ny, nz = dims
+    d = capi.Device()
+    set_dims(d, nx, ny, nz)
+    d.call("fused_create")
+    ops = syn.kspace_operators(nx, ny, nz, 1e-4, 1e-4, 1e-4)
+    sh = ops["xyz"[axis] + "_shift_neg_r"]
+    u = np.random.default_rng(axis + nx).standard_normal((nz, ny, nx)).astype(np.float32)
+    d_u, d_o = d.array(u), d.zeros(u.shape)
+    d_h = d.array(hermitian_filter(sh, dims[axis]).view(np.float32))
+    d.call("fused_shift_velocity", axis, d_u, d_o, d_h)
+    assert rel_l2(d_o.download(), orc.shifted_velocity(u, sh, axis)) < 1e-6, (dims, axis)
+    d.call("fused_shift_velocity", axis, d_u, d_u, d_h)          # in place
+    assert rel_l2(d_u.download(), orc.shifted_velocity(u, sh, axis)) < 1e-6, (dims, axis)
+    d.close()
+
+
 @pytest.mark.parametrize("op", [0, 1, 2, 3])
 def test_sample_index_bit_exact(dev, orc, op):
     rng = np.random.default_rng(op)
