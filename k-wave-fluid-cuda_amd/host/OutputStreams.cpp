@@ -1,5 +1,6 @@
 // OutputStreams.cpp — see OutputStreams.h.
 #include "OutputStreams.h"
+#include <cstdlib>
 
 #include <algorithm>
 #include <cstring>
@@ -67,6 +68,11 @@ void BaseOutputStream::allocateMemory()
   kwCheck(kw_memcpy_h2d(ctx(), mDeviceBuffer, init.data(), mSize * sizeof(float)));
   if (mReduceOp == ReduceOperator::kNone)
   {
+    // the whole series is known in advance (Nt - s rows): growing the vector step by step would re-copy it several
+    // times and stall the launching thread for milliseconds at a time, long enough for the GPU queue to run dry
+    const Parameters& params = Parameters::getInstance();
+    if (params.getNt() > params.getSamplingStartTimeIndex())
+      mDataset.reserve((params.getNt() - params.getSamplingStartTimeIndex()) * mSize);
     mDeviceRaw[0] = mDeviceBuffer;
     void* d2 = nullptr;
     kwCheck(kw_malloc(ctx(), mSize * sizeof(float), &d2));
@@ -150,9 +156,16 @@ void BaseOutputStream::restoreState(const float* state, size_t n, size_t sampled
 }
 
 // ---- raw helpers ----------------------------------------------------------------------------------------------------
+static bool rawZeroCopy()
+{ // KW_RAW_ZERO_COPY=1: the sampling kernel writes the pinned host buffer itself, as the reference's zero-copy mapped
+  // buffers do (BaseOutputStream.cpp:369-388) — measured equal to the staged copy (both ~10 us per step at 256^3 with
+  // 65 536 points), so the staged copy on the copy stream stays the default
+  static const bool on = std::getenv("KW_RAW_ZERO_COPY") != nullptr && std::getenv("KW_RAW_ZERO_COPY")[0] == '1';
+  return on;
+}
 static void rawSampleTail(kw_ctx* c, float* dev, float* pinned, void* event, size_t n)
 {
-  kwCheck(kw_memcpy_d2h_overlapped(c, pinned, dev, n * sizeof(float), event));
+  kwCheck(kw_memcpy_d2h_overlapped(c, pinned, dev, rawZeroCopy() ? 0 : n * sizeof(float), event));
 }
 
 // ---- IndexOutputStream ----------------------------------------------------------------------------------------------
@@ -165,6 +178,11 @@ void IndexOutputStream::sample()
 {
   OutputStreamsHipKernels::sampleIndex(kernelOp(), sampleTarget(), mSourceMatrix.getDeviceData(), mSensorMask.getDeviceData(), mSize);
   sampleDone();
+}
+float* IndexOutputStream::sampleTarget()
+{
+  if (mReduceOp != ReduceOperator::kNone) return mDeviceBuffer;
+  return rawZeroCopy() ? mPinned[mSampledSteps & 1] : mDeviceRaw[mSampledSteps & 1];
 }
 void IndexOutputStream::sampleDone()
 {

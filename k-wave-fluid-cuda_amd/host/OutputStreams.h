@@ -84,7 +84,7 @@ class IndexOutputStream : public BaseOutputStream
   void flushRaw() override; // IndexOutputStream.cpp:348-371 (raw branch)
   /// sample() in two halves, so that the container can serve several streams of one field with one kernel launch:
   /// where this step's values go and with which operator / what follows the kernel (raw: the D2H copy)
-  float* sampleTarget() { return (mReduceOp == ReduceOperator::kNone) ? mDeviceRaw[mSampledSteps & 1] : mDeviceBuffer; }
+  float* sampleTarget();
   void   sampleDone();
   const RealMatrix&  source() const { return mSourceMatrix; }
   const IndexMatrix& mask() const { return mSensorMask; }
