@@ -269,6 +269,7 @@ template<> struct Fac<320>  { static constexpr int R1 = 16, R2 = 20; };
 template<> struct Fac<480>  { static constexpr int R1 = 20, R2 = 24; };
 template<> struct Fac<576>  { static constexpr int R1 = 24, R2 = 24; };
 template<> struct Fac<640>  { static constexpr int R1 = 20, R2 = 32; };
+template<> struct Fac<768>  { static constexpr int R1 = 24, R2 = 32; };
 template<> struct Fac<96>   { static constexpr int R1 = 8,  R2 = 12; };
 template<> struct Fac<192>  { static constexpr int R1 = 12, R2 = 16; };
 template<> struct Fac<384>  { static constexpr int R1 = 16, R2 = 24; };

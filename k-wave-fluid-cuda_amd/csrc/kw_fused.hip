@@ -120,7 +120,7 @@ template<int L, int DIR> __device__ __forceinline__ void step_a(float2 (&v)[Fac<
 // Row addressing of a y-line element.  Natural layout: row(z, ky) = z*ny + ky.  Packed layout (slab mode, the send /
 // receive side of the all-to-all): row(z, ky) = ((ky / nyl) * nzl + z) * nyl + ky % nyl, i.e. one contiguous chunk
 // [nzl][nyl][P] per peer rank.  Both are  q * qstride + (ky - q * nyl) + z * zmul  with q = ky / nyl taken as
-// (ky * magic) >> 20, magic = 2^20 / nyl + 1: exact while ky * nyl < 2^20 (lines have at most 640 elements); the natural
+// (ky * magic) >> 20, magic = 2^20 / nyl + 1: exact while ky * nyl < 2^20 (lines have at most 1024 elements); the natural
 // layout has magic = 0, hence q = 0.
 struct RowAddr
 {
@@ -1425,7 +1425,7 @@ template<int L> __global__ __launch_bounds__(Geo<L>::THREADS) void k_probe_xinv(
 // ---- host side ------------------------------------------------------------------------------------------------------
 // line lengths with a two-factor register decomposition: 2^m, 3 * 2^m, 9 * 2^m, 5 * 2^m, 15 * 2^m
 #define KW_FUSED_LENGTHS(X) X(16) X(32) X(48) X(64) X(72) X(80) X(96) X(120) X(128) X(144) X(160) X(192) X(240) X(256) \
-  X(288) X(320) X(384) X(480) X(512) X(576) X(640)
+  X(288) X(320) X(384) X(480) X(512) X(576) X(640) X(768) X(1024)
 bool supported_len(uint32_t n)
 {
 #define X(LEN) if (n == LEN) return true;

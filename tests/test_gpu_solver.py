@@ -126,6 +126,7 @@ def test_fused_line_length_512(orc, syn, dims):
     (80, 160, 16), (160, 16, 80), (16, 80, 160), (320, 16, 16), (16, 320, 16), (16, 16, 320), (640, 16, 16),
     (16, 640, 16), (16, 16, 640),                                                         # 5 * 2^m
     (120, 240, 16), (240, 16, 120), (16, 120, 240), (480, 16, 16), (16, 480, 16), (16, 16, 480),  # 15 * 2^m
+    (768, 16, 16), (16, 768, 16), (16, 16, 768), (1024, 16, 16), (16, 1024, 16), (16, 16, 1024),  # the longest lines
 ])
 def test_fused_line_lengths_mixed_radix(orc, syn, dims):
     """Line lengths with one radix-3 or radix-5 stage (or two radix-3) inside the register DFTs: every supported
