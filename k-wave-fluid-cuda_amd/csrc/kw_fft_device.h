@@ -260,7 +260,10 @@ template<> struct Fac<16>   { static constexpr int R1 = 4,  R2 = 4; };
 template<> struct Fac<48>   { static constexpr int R1 = 6,  R2 = 8; };
 template<> struct Fac<72>   { static constexpr int R1 = 6,  R2 = 12; };
 template<> struct Fac<80>   { static constexpr int R1 = 8,  R2 = 10; };
+template<> struct Fac<100>  { static constexpr int R1 = 10, R2 = 10; };
 template<> struct Fac<120>  { static constexpr int R1 = 10, R2 = 12; };
+template<> struct Fac<200>  { static constexpr int R1 = 10, R2 = 20; };
+template<> struct Fac<400>  { static constexpr int R1 = 20, R2 = 20; };
 template<> struct Fac<144>  { static constexpr int R1 = 12, R2 = 12; };
 template<> struct Fac<160>  { static constexpr int R1 = 10, R2 = 16; };
 template<> struct Fac<240>  { static constexpr int R1 = 12, R2 = 20; };

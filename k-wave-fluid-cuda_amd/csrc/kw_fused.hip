@@ -1423,9 +1423,9 @@ template<int L> __global__ __launch_bounds__(Geo<L>::THREADS) void k_probe_xinv(
 }
 
 // ---- host side ------------------------------------------------------------------------------------------------------
-// line lengths with a two-factor register decomposition: 2^m, 3 * 2^m, 9 * 2^m, 5 * 2^m, 15 * 2^m
-#define KW_FUSED_LENGTHS(X) X(16) X(32) X(48) X(64) X(72) X(80) X(96) X(120) X(128) X(144) X(160) X(192) X(240) X(256) \
-  X(288) X(320) X(384) X(480) X(512) X(576) X(640) X(768) X(1024)
+// line lengths with a two-factor register decomposition: 2^m, 3 * 2^m, 9 * 2^m, 5 * 2^m, 15 * 2^m, 25 * 2^m
+#define KW_FUSED_LENGTHS(X) X(16) X(32) X(48) X(64) X(72) X(80) X(96) X(100) X(120) X(128) X(144) X(160) X(192) X(200)  \
+  X(240) X(256) X(288) X(320) X(384) X(400) X(480) X(512) X(576) X(640) X(768) X(1024)
 bool supported_len(uint32_t n)
 {
 #define X(LEN) if (n == LEN) return true;

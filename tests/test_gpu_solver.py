@@ -127,6 +127,7 @@ def test_fused_line_length_512(orc, syn, dims):
     (16, 640, 16), (16, 16, 640),                                                         # 5 * 2^m
     (120, 240, 16), (240, 16, 120), (16, 120, 240), (480, 16, 16), (16, 480, 16), (16, 16, 480),  # 15 * 2^m
     (768, 16, 16), (16, 768, 16), (16, 16, 768), (1024, 16, 16), (16, 1024, 16), (16, 16, 1024),  # the longest lines
+    (100, 200, 16), (200, 16, 100), (16, 100, 200), (400, 16, 16), (16, 400, 16), (16, 16, 400),  # 25 * 2^m
 ])
 def test_fused_line_lengths_mixed_radix(orc, syn, dims):
     """Line lengths with one radix-3 or radix-5 stage (or two radix-3) inside the register DFTs: every supported
