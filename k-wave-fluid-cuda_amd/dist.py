@@ -15,6 +15,7 @@ partition_problem() cuts a global problem dict (HDF5 dataset names) into the sla
 from __future__ import annotations
 
 import ctypes as C
+import time
 from typing import Dict, Optional, Tuple
 
 import numpy as np
@@ -111,6 +112,8 @@ class SlabExchange:
         self._view_cache: Dict[tuple, tuple] = {}
         self.callback = self.CB(self._exchange)
         self.calls = 0
+        self.host_seconds = 0.0  # time the launching thread spent inside the split-phase callbacks (diagnostic)
+        self.wait_seconds = 0.0  # ... of which in work.wait()
         # split-phase form (RCCL only): the transpose of one array is in flight while other arrays compute
         self.works: Dict[int, object] = {}
         self.start_callback = self.CB_START(self._start) if self.backend == "nccl" else None
@@ -148,13 +151,19 @@ class SlabExchange:
     def _start(self, user, send, recv, bytes_per_peer, slot):
         """all_to_all_single(async_op=True): the RCCL stream waits for the work enqueued so far on the solver's stream
         and the call returns; later launches on the solver's stream overlap with the collective."""
+        t0 = time.perf_counter()
         self.calls += 1
         src, dst = self._views(send, recv, bytes_per_peer * self.nranks)
         self.works[slot] = self.dist.all_to_all_single(dst, src, async_op=True)
+        self.host_seconds += time.perf_counter() - t0
 
     def _wait(self, user, slot):
         """work.wait(): the solver's stream waits for the collective (the host does not block)."""
+        t0 = time.perf_counter()
         self.works.pop(slot).wait()
+        dt = time.perf_counter() - t0
+        self.host_seconds += dt
+        self.wait_seconds += dt
 
     def _exchange(self, user, send, recv, bytes_per_peer):
         self.calls += 1
