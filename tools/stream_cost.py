@@ -8,7 +8,8 @@ import kwave_amd  # noqa: E402,F401
 from kwave_amd import synthetic  # noqa: E402
 from kwave_amd.solver import HostSolver  # noqa: E402
 
-n, steps, warm = 256, 300, 20
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+steps, warm = (300, 20) if n >= 256 else (2000, 100)
 pr = synthetic.make_problem(n, heterogeneous=True, nonlinear=True, absorbing=True, source="p0", nt=steps * 2 + warm + 8)
 for name, opts in (("none", {}), ("p_max", dict(p_max=1)), ("p_raw", dict(p_raw=1)), ("p_raw+p_max", dict(p_raw=1, p_max=1))):
     sim = HostSolver(pr, **opts)
