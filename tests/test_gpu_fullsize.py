@@ -49,6 +49,35 @@ def test_config3_fused_pipeline_equals_rocfft_path_256(syn):
     b.close()
 
 
+def test_config5_streams_fused_shift_equals_rocfft_shift_256(syn):
+    """BASELINE config 5 at full size: the non-staggered velocity of the one-kernel-per-axis shift against the
+    R2C -> multiply -> C2R form (rocFFT 1-D transforms), and the compression / intensity streams built on it."""
+    nt = 48
+    pr = syn.make_problem(N, heterogeneous=True, nonlinear=True, absorbing=True, source="p_source", source_mode=1, nt=nt)
+    dt = float(pr["dt"].ravel()[0])
+    opts = dict(u_non_staggered_raw=1, p_c=1, u_non_staggered_c=1, i_avg_c=1, period=1.0 / (1.0e6 * dt), mos=1, harmonics=2)
+    out = {}
+    for fused in (True, False):
+        g = gpu(pr, fused_kernels=fused, **opts)
+        g.run(nt)
+        g.finish()
+        out[fused] = ({f: g.field(f) for f in ("ux_shifted", "uy_shifted", "uz_shifted")},
+                      {s: g.stream(s) for s in ("ux_non_staggered", "uz_non_staggered", "p_c", "ux_non_staggered_c",
+                                                "uy_non_staggered_c", "Ix_avg_c", "Iz_avg_c")})
+        g.close()
+    for f in out[True][0]:
+        assert np.abs(out[False][0][f]).max() > 0 and rel_l2(out[True][0][f], out[False][0][f]) < TOL, f
+    # on the sensor plane (z = N/2, a symmetry plane of the source) the y / z components are rounding noise: errors are
+    # taken relative to the x component of the same kind
+    scale = {"ux_non_staggered": "ux_non_staggered", "uz_non_staggered": "ux_non_staggered", "p_c": "p_c",
+             "ux_non_staggered_c": "ux_non_staggered_c", "uy_non_staggered_c": "ux_non_staggered_c", "Ix_avg_c": "Ix_avg_c",
+             "Iz_avg_c": "Ix_avg_c"}
+    for s, ref in scale.items():
+        a, b = out[True][1][s], out[False][1][s]
+        assert a.shape == b.shape, s
+        assert np.abs(a - b).max() < 2e-5 * np.abs(out[False][1][ref]).max(), s
+
+
 def test_linearity_256(syn):
     """linear lossless heterogeneous medium: the field scales with the source amplitude"""
     pr = syn.make_problem(N, heterogeneous=True, nonlinear=False, absorbing=False, source="p0", nt=30)
