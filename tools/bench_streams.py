@@ -29,8 +29,18 @@ def main(n=256, steps=200, warm=20):
         sim.run(warm)
         sim.sync()
         ms = sim.time_steps(steps)
-        sim.close()
         print(f"{n}^3 {name:55s} {steps / (ms * 1e-3):8.1f} steps/s  {ms / steps:7.4f} ms/step", flush=True)
+        if "config 5" in name:  # what the sampling side of that configuration consists of, per step
+            from kwave_amd import capi
+            hip = capi.load()
+            capi.check(hip.kw_profile_enable(sim.ctx, 1))
+            sim.run(10)
+            prof = capi.profile_collect(sim.ctx)
+            capi.check(hip.kw_profile_enable(sim.ctx, 0))
+            for kname, (calls, total_ms) in sorted(prof.items(), key=lambda kv: -kv[1][1]):
+                if not kname.startswith(("k_xinv", "k_ypass", "k_zfused_pgrad", "k_zfused_vgrad", "k_zfused_absorb")):
+                    print(f"      {kname:28s} {calls / 10:5.1f} calls/step  {1e3 * total_ms / max(calls, 1):8.1f} us each")
+        sim.close()
 
 
 if __name__ == "__main__":
