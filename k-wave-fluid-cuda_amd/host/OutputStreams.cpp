@@ -1,6 +1,7 @@
 // OutputStreams.cpp — see OutputStreams.h.
 #include "OutputStreams.h"
 #include <cstdlib>
+#include <new>
 
 #include <algorithm>
 #include <cstring>
@@ -72,7 +73,10 @@ void BaseOutputStream::allocateMemory()
     // times and stall the launching thread for milliseconds at a time, long enough for the GPU queue to run dry
     const Parameters& params = Parameters::getInstance();
     if (params.getNt() > params.getSamplingStartTimeIndex())
-      mDataset.reserve((params.getNt() - params.getSamplingStartTimeIndex()) * mSize);
+    {
+      try { mDataset.reserve((params.getNt() - params.getSamplingStartTimeIndex()) * mSize); }
+      catch (const std::bad_alloc&) {} // a series this long is better compressed or checkpointed; fall back to growing
+    }
     mDeviceRaw[0] = mDeviceBuffer;
     void* d2 = nullptr;
     kwCheck(kw_malloc(ctx(), mSize * sizeof(float), &d2));
