@@ -45,10 +45,12 @@ def build_hip(force: bool = False, verbose: bool = False) -> str:
     deps = srcs + glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(INCLUDE, "*.h"))
     if force or _newer(HIP_LIB, deps):
         objs, jobs = [], []
-        for s in srcs:
-            o = os.path.join(LIB_DIR, os.path.basename(s) + ".o")
+        # kw_fused.hip is compiled in three passes (its x-inverse epilogue kernels in two of them, see the file's header)
+        units = [(s, tu) for s in srcs for tu in ((0, 1, 2) if os.path.basename(s) == "kw_fused.hip" else (None,))]
+        for s, tu in units:
+            o = os.path.join(LIB_DIR, os.path.basename(s) + (".o" if not tu else f".tu{tu}.o"))
             if force or _newer(o, [s] + [d for d in deps if d.endswith(".h")]):
-                extra = os.environ.get("KW_HIPCC_EXTRA", "").split()
+                extra = os.environ.get("KW_HIPCC_EXTRA", "").split() + ([f"-DKW_FUSED_TU={tu}"] if tu else [])
                 # -fno-slp-vectorize: packed-f32 pairing buys nothing here (same instruction count, more moves; measured +0.6 %)
                 cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden",
                        "-fno-slp-vectorize"] + extra + [
@@ -58,7 +60,7 @@ def build_hip(force: bool = False, verbose: bool = False) -> str:
                 jobs.append(cmd)
             objs.append(o)
         # the translation units compile side by side (kw_fused.hip alone takes minutes: one kernel set per line length)
-        with concurrent.futures.ThreadPoolExecutor(max_workers=max(1, min(4, len(jobs)))) as pool:
+        with concurrent.futures.ThreadPoolExecutor(max_workers=max(1, min(6, len(jobs)))) as pool:
             for out in pool.map(_run, jobs):
                 if verbose:
                     print(out)

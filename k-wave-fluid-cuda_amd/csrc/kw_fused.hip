@@ -26,6 +26,17 @@
 
 using namespace kwfft;
 
+// The x-inverse + epilogue kernels are the bulk of this file's compile time (one kernel per epilogue variant and line
+// length).  They are compiled in two extra passes over this file, side by side with the main pass (build.py):
+//   KW_FUSED_TU == 0  everything except those kernels;  1  the density epilogues;  2  the other epilogues.
+// The main pass reaches them through the two functions below (XinvArgs passed as an opaque pointer: the struct lives in
+// this file's anonymous namespace).
+#ifndef KW_FUSED_TU
+#define KW_FUSED_TU 0
+#endif
+kw_status kw_fused_xinv_density(int chain, int terms, kw_ctx* ctx, int ncomp, const void* xinv_args, uint32_t z0, uint32_t nzc);
+kw_status kw_fused_xinv_other(int epi, int chain, kw_ctx* ctx, int ncomp, const void* xinv_args, uint32_t z0, uint32_t nzc);
+
 namespace {
 
 constexpr int NLMAX = 16; // widest tile: 16 complex = 128-B segments (also the row-pitch granule)
@@ -1461,6 +1472,7 @@ bool supported_len(uint32_t n)
     if (st_ != KW_OK) return st_;                                                                                      \
   } while (0)
 
+#if KW_FUSED_TU == 0
 kw_status launch_xfwd(kw_ctx* ctx, int narr, const float* const* in, float2* const* out)
 {
   const kw_constants& c = ctx->c;
@@ -1561,8 +1573,16 @@ template<int MODE> kw_status launch_zfused(kw_ctx* ctx, int narr, ZArgs a)
   return KW_OK;
 }
 
+// main pass: forward to the pass that holds this epilogue's kernels
 template<int EPI, bool CHAIN = false, int TERMS = 0>
 kw_status launch_xinv(kw_ctx* ctx, int ncomp, XinvArgs a, uint32_t z0 = 0, uint32_t nzc = 0)
+{
+  if (EPI == EPI_DENSITY) return kw_fused_xinv_density(CHAIN ? 1 : 0, TERMS, ctx, ncomp, &a, z0, nzc);
+  return kw_fused_xinv_other(EPI, CHAIN ? 1 : 0, ctx, ncomp, &a, z0, nzc);
+}
+#else
+template<int EPI, bool CHAIN = false, int TERMS = 0>
+kw_status launch_xinv_impl(kw_ctx* ctx, int ncomp, XinvArgs a, uint32_t z0, uint32_t nzc)
 {
   const kw_constants& c = ctx->c;
   static const char* const names[5][2] = { { "k_xinv_store", "k_xinv_store" }, { "k_xinv_velocity", "k_xinv_velocity_chain" },
@@ -1580,6 +1600,9 @@ kw_status launch_xinv(kw_ctx* ctx, int ncomp, XinvArgs a, uint32_t z0 = 0, uint3
 #undef M
   return KW_OK;
 }
+#endif
+
+#if KW_FUSED_TU == 0
 
 // split-phase exchange of scratch array `slot`: start is ordered after the work enqueued so far; wait orders later
 // work after its completion.  Without asynchronous callbacks, start is the blocking exchange and wait a no-op.
@@ -1780,8 +1803,43 @@ kw_status create_impl(kw_ctx* ctx, void* const s[3], void* const t[3])
   return KW_OK;
 }
 
+#endif // KW_FUSED_TU == 0
 } // namespace
 
+#if KW_FUSED_TU == 1
+kw_status kw_fused_xinv_density(int chain, int terms, kw_ctx* ctx, int ncomp, const void* xinv_args, uint32_t z0, uint32_t nzc)
+{
+  const XinvArgs& a = *static_cast<const XinvArgs*>(xinv_args);
+  switch (2 * terms + chain)
+  {
+    case 0: return launch_xinv_impl<EPI_DENSITY, false, 0>(ctx, ncomp, a, z0, nzc);
+    case 2: return launch_xinv_impl<EPI_DENSITY, false, 1>(ctx, ncomp, a, z0, nzc);
+    case 3: return launch_xinv_impl<EPI_DENSITY, true, 1>(ctx, ncomp, a, z0, nzc);
+    case 4: return launch_xinv_impl<EPI_DENSITY, false, 2>(ctx, ncomp, a, z0, nzc);
+    case 5: return launch_xinv_impl<EPI_DENSITY, true, 2>(ctx, ncomp, a, z0, nzc);
+    case 6: return launch_xinv_impl<EPI_DENSITY, false, 3>(ctx, ncomp, a, z0, nzc);
+    case 7: return launch_xinv_impl<EPI_DENSITY, true, 3>(ctx, ncomp, a, z0, nzc);
+    default: kw_set_error("fused pipeline: no density epilogue for chain = %d, terms = %d", chain, terms); return KW_ERR_INVALID;
+  }
+}
+#elif KW_FUSED_TU == 2
+kw_status kw_fused_xinv_other(int epi, int chain, kw_ctx* ctx, int ncomp, const void* xinv_args, uint32_t z0, uint32_t nzc)
+{
+  const XinvArgs& a = *static_cast<const XinvArgs*>(xinv_args);
+  switch (2 * epi + chain)
+  {
+    case 2 * EPI_STORE: return launch_xinv_impl<EPI_STORE, false>(ctx, ncomp, a, z0, nzc);
+    case 2 * EPI_VELOCITY: return launch_xinv_impl<EPI_VELOCITY, false>(ctx, ncomp, a, z0, nzc);
+    case 2 * EPI_VELOCITY + 1: return launch_xinv_impl<EPI_VELOCITY, true>(ctx, ncomp, a, z0, nzc);
+    case 2 * EPI_INITVEL: return launch_xinv_impl<EPI_INITVEL, false>(ctx, ncomp, a, z0, nzc);
+    case 2 * EPI_PSUM: return launch_xinv_impl<EPI_PSUM, false>(ctx, ncomp, a, z0, nzc);
+    case 2 * EPI_PSUM + 1: return launch_xinv_impl<EPI_PSUM, true>(ctx, ncomp, a, z0, nzc);
+    default: kw_set_error("fused pipeline: no epilogue %d with chain = %d", epi, chain); return KW_ERR_INVALID;
+  }
+}
+#endif
+
+#if KW_FUSED_TU == 0
 extern "C" {
 
 kw_status kw_fused_set_slab(kw_ctx* ctx, uint32_t nranks, uint32_t rank, uint32_t nz_global, kw_exchange_fn fn, void* user)
@@ -2245,3 +2303,4 @@ kw_status kw_fused_probe(kw_ctx* ctx, int which, const float* op)
 }
 
 } // extern "C"
+#endif // KW_FUSED_TU == 0

@@ -16,9 +16,20 @@ SRC = os.path.join(ROOT, "k-wave-fluid-cuda_amd", "csrc", "kw_fused.hip")
 def main():
     extra = sys.argv[1:]
     out = os.environ.get("KW_ISA_OUT", "/tmp/kw_fused_isa.s")
-    cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize", "--cuda-device-only",
-           "-S", "-I" + os.path.join(ROOT, "include"), "-I" + os.path.dirname(SRC), SRC, "-o", out] + extra
-    subprocess.check_call(cmd)
+    # the file is built in three passes (KW_FUSED_TU = 0, 1, 2: see its header); all three are listed
+    procs, outs = [], []
+    for tu in (0, 1, 2):
+        o = f"{out}.tu{tu}"
+        outs.append(o)
+        procs.append(subprocess.Popen(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize",
+                                       "--cuda-device-only", "-S", "-I" + os.path.join(ROOT, "include"),
+                                       "-I" + os.path.dirname(SRC), SRC, "-o", o, f"-DKW_FUSED_TU={tu}"] + extra))
+    for pr in procs:
+        if pr.wait() != 0:
+            raise SystemExit("hipcc failed")
+    with open(out, "w") as f:
+        for o in outs:
+            f.write(open(o).read())
     kern, stats, meta = None, collections.OrderedDict(), {}
     for line in open(out):
         m = re.match(r"^(_Z\w+):", line)
