@@ -271,7 +271,8 @@ KW_API kw_status kw_compute_velocity_shift(kw_ctx* ctx, int axis, float* spectru
  * Fused spectral pipeline (MI355X fast path; csrc/kw_fused.hip).  Each entry computes one whole stage of the step —
  * FFTs, spectral multiply and the real-space update — with hand-written FFT passes, so the gradients and spectra never
  * make an HBM round trip as separate arrays.  Same arithmetic as the kernels cited; supported when each of Nx, Ny, Nz
- * is one of 16 32 48 64 72 80 96 100 120 128 144 160 192 200 240 256 288 320 384 400 480 512 576 640 768 1024 (kw_fused_supported says;
+ * is one of 16 32 48 64 72 80 96 100 108 120 128 144 160 192 200 216 240 256 288 300 320 324 384 400 432 480 500 512
+ * 576 600 640 648 768 1024 (kw_fused_supported says;
  * other grids use the rocFFT entry points above).  kappa / nabla / sourceKappa must first be imported into the
  * pipeline's padded row layout.
  * ---------------------------------------------------------------------------------------------------------------- */

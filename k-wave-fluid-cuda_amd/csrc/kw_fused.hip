@@ -1434,9 +1434,11 @@ template<int L> __global__ __launch_bounds__(Geo<L>::THREADS) void k_probe_xinv(
 }
 
 // ---- host side ------------------------------------------------------------------------------------------------------
-// line lengths with a two-factor register decomposition: 2^m, 3 * 2^m, 9 * 2^m, 5 * 2^m, 15 * 2^m, 25 * 2^m
-#define KW_FUSED_LENGTHS(X) X(16) X(32) X(48) X(64) X(72) X(80) X(96) X(100) X(120) X(128) X(144) X(160) X(192) X(200)  \
-  X(240) X(256) X(288) X(320) X(384) X(400) X(480) X(512) X(576) X(640) X(768) X(1024)
+// line lengths with a two-factor register decomposition L = R1 * R2, R1, R2 in {4 ... 32} with at most one odd prime
+// power (3, 9, 27, 5, 25) each: 2^m, 3 * 2^m, 9 * 2^m, 27 * 2^m, 81 * 4, 5 * 2^m, 15 * 2^m, 25 * 2^m, 75 * 2^m, 125 * 4
+#define KW_FUSED_LENGTHS(X) X(16) X(32) X(48) X(64) X(72) X(80) X(96) X(100) X(108) X(120) X(128) X(144) X(160) X(192)  \
+  X(200) X(216) X(240) X(256) X(288) X(300) X(320) X(324) X(384) X(400) X(432) X(480) X(500) X(512) X(576) X(600) X(640) \
+  X(648) X(768) X(1024)
 bool supported_len(uint32_t n)
 {
 #define X(LEN) if (n == LEN) return true;

@@ -128,6 +128,10 @@ def test_fused_line_length_512(orc, syn, dims):
     (120, 240, 16), (240, 16, 120), (16, 120, 240), (480, 16, 16), (16, 480, 16), (16, 16, 480),  # 15 * 2^m
     (768, 16, 16), (16, 768, 16), (16, 16, 768), (1024, 16, 16), (16, 1024, 16), (16, 16, 1024),  # the longest lines
     (100, 200, 16), (200, 16, 100), (16, 100, 200), (400, 16, 16), (16, 400, 16), (16, 16, 400),  # 25 * 2^m
+    (108, 216, 16), (216, 16, 108), (16, 108, 216), (324, 16, 16), (16, 324, 16), (16, 16, 324), (432, 16, 16),
+    (16, 432, 16), (16, 16, 432), (648, 16, 16), (16, 648, 16), (16, 16, 648),                    # 27 * 2^m, 81 * 4
+    (300, 16, 16), (16, 300, 16), (16, 16, 300), (500, 16, 16), (16, 500, 16), (16, 16, 500), (600, 16, 16),
+    (16, 600, 16), (16, 16, 600),                                                                 # 75 * 2^m, 125 * 4
 ])
 def test_fused_line_lengths_mixed_radix(orc, syn, dims):
     """Line lengths with one radix-3 or radix-5 stage (or two radix-3) inside the register DFTs: every supported
