@@ -244,6 +244,8 @@ def main():
             table[name]["alg_gbs"] = None
     # dominant GPU kernel (fused pipeline: the "k_*" records; granular path: one kernel per entry point)
     kernels = [k for k in table if per.get(k) and (k.startswith("k_") or args.granular)]
+    if not kernels:  # a grid the fused pipeline does not take (kw_fused_supported): the run used the rocFFT path
+        kernels = [k for k in table if per.get(k)]
     dom = max(kernels, key=lambda k: table[k]["ms_per_step"])
     achieved = per[dom] / (table[dom]["avg_ms"] * 1e-3) / 1e9
     traffic, traffic_src = None, None

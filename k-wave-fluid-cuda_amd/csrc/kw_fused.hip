@@ -1876,7 +1876,9 @@ kw_status kw_fused_supported(kw_ctx* ctx, int* out)
   const kw_constants& c = ctx->c;
   const auto& f         = ctx->fused;
   const uint32_t nzg    = (f.slab) ? f.nz_global : c.nz;
-  bool ok = supported_len(c.nx) && supported_len(c.ny) && supported_len(nzg) && ((c.ny * c.nz) % (2 * NLMAX) == 0);
+  // the x kernels work on tiles of 2 * NL rows (32; 16 from Nx = 400 on): Ny * Nz (local) must be a whole number of tiles
+  bool ok = supported_len(c.nx) && supported_len(c.ny) && supported_len(nzg) &&
+            ((c.ny * c.nz) % (2u * static_cast<uint32_t>(nl_of(static_cast<int>(c.nx)))) == 0);
   if (f.slab) ok = ok && (nzg == c.nz * f.nranks) && (c.ny % f.nranks == 0);
   const uint64_t P64 = (c.nx_complex + NLMAX - 1) / NLMAX * NLMAX;
   ok = ok && (P64 * c.ny * c.nz < (1ull << 32)) && (static_cast<uint64_t>(c.nx) * c.ny * c.nz < (1ull << 32));

@@ -132,6 +132,7 @@ def test_fused_line_length_512(orc, syn, dims):
     (16, 432, 16), (16, 16, 432), (648, 16, 16), (16, 648, 16), (16, 16, 648),                    # 27 * 2^m, 81 * 4
     (300, 16, 16), (16, 300, 16), (16, 16, 300), (500, 16, 16), (16, 500, 16), (16, 16, 500), (600, 16, 16),
     (16, 600, 16), (16, 16, 600),                                                                 # 75 * 2^m, 125 * 4
+    (400, 100, 100), (500, 100, 108),       # Ny * Nz a multiple of 16 but not of 32: 16-row x tiles from Nx = 400 on
 ])
 def test_fused_line_lengths_mixed_radix(orc, syn, dims):
     """Line lengths with one radix-3 or radix-5 stage (or two radix-3) inside the register DFTs: every supported
@@ -146,6 +147,18 @@ def test_fused_line_lengths_mixed_radix(orc, syn, dims):
         g.close()
         o.close()
         assert max(errs.values()) < TOL, (dims, kw, errs)
+
+
+def test_grids_without_whole_x_tiles_take_the_rocfft_path(orc, syn):
+    """Ny * Nz = 100 * 100 is not a multiple of the 32-row x tile of Nx = 300: the solver falls back (same results)."""
+    pr = syn.make_problem(300, 100, 100, heterogeneous=True, nonlinear=True, absorbing=True, source="p0", pml_size=4)
+    g, o = make_gpu(pr, fused_kernels=True), orc.OracleSim(pr)
+    g.run(10)
+    assert g.scalar("fused_pipeline") == 0.0
+    o.step(10)
+    assert rel_l2(g.field("p"), o.field("p")) < TOL
+    g.close()
+    o.close()
 
 
 def test_transducer_source(orc, syn):

@@ -1,4 +1,4 @@
-for n in 192 240 320 384; do
+for n in ${SIZES:-192 240 320 384}; do
   for g in "" "--granular"; do
     echo "== $n $g" >> gpurun_out/sizes.log
     timeout -k 10 200 python bench.py --size $n --no-cpu --steps 50 --warmup 5 $g 2>&1 | tail -1 | python -c "
