@@ -78,10 +78,18 @@ def pml_vectors(n: int, d: float, dt: float, c_ref: float, size: int, alpha: flo
 
 
 def _grid(nx, ny, nz, zlo=0, zhi=None):
+    """Open (broadcastable) coordinate grids x[1,1,nx], y[1,ny,1], z[nzl,1,1]: every closed form below is evaluated on
+    the axes it depends on and expanded by _full(); elementwise this is the arithmetic of dense grids (same operations,
+    same order, hence the same bits) at a fraction of the time and memory for 512^3."""
     zhi = nz if zhi is None else zhi
     z, y, x = np.meshgrid(np.arange(zlo, zhi, dtype=np.float64), np.arange(ny, dtype=np.float64),
-                          np.arange(nx, dtype=np.float64), indexing="ij")
+                          np.arange(nx, dtype=np.float64), indexing="ij", sparse=True)
     return x, y, z
+
+
+def _full(a: np.ndarray, shape, nzl: int) -> np.ndarray:
+    """float32 dense array [nzl][ny][nx] of a broadcastable float64 field"""
+    return np.broadcast_to(a, shape)[:nzl].astype(F32)
 
 
 def _c0_field(x, y, z, nx, ny, nz):
@@ -92,8 +100,20 @@ def _c0_field(x, y, z, nx, ny, nz):
     return np.where(r2 <= (n / 6.0) ** 2, 1600.0, c0)
 
 
+def _by_planes(fn, x, y, z, nzl: int, planes: int = 4) -> np.ndarray:
+    """float32 [nzl][ny][nx] of a genuinely 3-D closed form fn(x, y, z) -> float64, evaluated a few planes at a time so
+    that the float64 temporaries stay cache-sized (elementwise: same bits as one dense evaluation)."""
+    out = np.empty((nzl, y.shape[1], x.shape[2]), dtype=F32)
+    for a in range(0, nzl, planes):
+        b = min(a + planes, nzl)
+        out[a:b] = fn(x, y, z[a:b])
+    return out
+
+
 def _sg_mean(a: np.ndarray, axis: int) -> np.ndarray:
     """staggered-grid value = mean of the two neighbours along axis (edge replicated)."""
+    if a.shape[axis] == 1:  # the field does not depend on this axis: 0.5 * (a + a) == a exactly
+        return a
     nxt = np.concatenate([np.take(a, range(1, a.shape[axis]), axis=axis),
                           np.take(a, [a.shape[axis] - 1], axis=axis)], axis=axis)
     return 0.5 * (a + nxt)
@@ -125,6 +145,7 @@ def make_problem(nx: int, ny: Optional[int] = None, nz: Optional[int] = None, *,
     zext = min(zhi + 1, nz)  # one extra plane for the staggered-grid mean along z
     x, y, z = _grid(nx, ny, nz, zlo, zext)
     nzl = zhi - zlo
+    shape = (zext - zlo, ny, nx)
     two_pi = 2.0 * math.pi
     het = {"c0": heterogeneous, "rho0": heterogeneous, "BonA": heterogeneous, "alpha_coeff": heterogeneous}
     if hetero_subset:
@@ -140,8 +161,7 @@ def make_problem(nx: int, ny: Optional[int] = None, nz: Optional[int] = None, *,
 
     # ---- medium -------------------------------------------------------------------------------
     if het["c0"]:
-        c0 = _c0_field(x, y, z, nx, ny, nz)
-        pr["c0"] = c0[:nzl].astype(F32)
+        pr["c0"] = _by_planes(lambda xx, yy, zz: _c0_field(xx, yy, zz, nx, ny, nz), x, y, z, nzl)
         if zslab is None:
             c_ref = float(pr["c0"].max())
         else:  # c_ref is the global maximum: evaluate the closed form plane by plane
@@ -154,17 +174,17 @@ def make_problem(nx: int, ny: Optional[int] = None, nz: Optional[int] = None, *,
         c_ref = 1500.0
     if het["rho0"]:
         rho0 = 1000.0 * (1.0 + 0.04 * np.cos(two_pi * 2 * x / nx) * np.sin(two_pi * 3 * z / nz))
-        pr["rho0"] = rho0[:nzl].astype(F32)
-        pr["rho0_sgx"] = _sg_mean(rho0, 2)[:nzl].astype(F32)
-        pr["rho0_sgy"] = _sg_mean(rho0, 1)[:nzl].astype(F32)
-        pr["rho0_sgz"] = _sg_mean(rho0, 0)[:nzl].astype(F32)
+        pr["rho0"] = _full(rho0, shape, nzl)
+        pr["rho0_sgx"] = _full(_sg_mean(rho0, 2), shape, nzl)
+        pr["rho0_sgy"] = _full(_sg_mean(rho0, 1), shape, nzl)
+        pr["rho0_sgz"] = _full(_sg_mean(rho0, 0), shape, nzl)
     else:
         for nm in ("rho0", "rho0_sgx", "rho0_sgy", "rho0_sgz"):
             pr[nm] = scalar_f(1000.0)
     if nonlinear:
-        pr["BonA"] = (6.0 + 2.0 * np.sin(two_pi * y / ny))[:nzl].astype(F32) if het["BonA"] else scalar_f(6.0)
+        pr["BonA"] = _full(6.0 + 2.0 * np.sin(two_pi * y / ny), shape, nzl) if het["BonA"] else scalar_f(6.0)
     if absorbing:
-        pr["alpha_coeff"] = ((0.75 + 0.25 * np.cos(two_pi * x / nx))[:nzl].astype(F32)
+        pr["alpha_coeff"] = (_full(0.75 + 0.25 * np.cos(two_pi * x / nx), shape, nzl)
                              if het["alpha_coeff"] else scalar_f(0.75))
         pr["alpha_power"] = scalar_f(1.5)
 
@@ -204,8 +224,11 @@ def make_problem(nx: int, ny: Optional[int] = None, nz: Optional[int] = None, *,
     rng = np.random.default_rng(seed)
     if source == "p0":
         sigma = 4.0
-        r2 = (x - nx // 2) ** 2 + (y - ny // 2) ** 2 + (z - nz // 2) ** 2
-        pr["p0_source_input"] = (1.0e6 * np.exp(-r2 / (2.0 * sigma * sigma)))[:nzl].astype(F32)
+
+        def ball(xx, yy, zz):
+            r2 = (xx - nx // 2) ** 2 + (yy - ny // 2) ** 2 + (zz - nz // 2) ** 2
+            return 1.0e6 * np.exp(-r2 / (2.0 * sigma * sigma))
+        pr["p0_source_input"] = _by_planes(ball, x, y, z, nzl)
         pr["p0_source_flag"] = scalar_u(1)
     elif source in ("p_source", "u_source", "transducer"):
         xs = min(12, nx - 1)

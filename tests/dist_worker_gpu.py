@@ -23,6 +23,10 @@ def main():
     ap.add_argument("--mode", type=int, default=0)
     ap.add_argument("--backend", default="gloo")
     ap.add_argument("--medium", default="111", help="heterogeneous, nonlinear, absorbing as three 0/1 digits")
+    ap.add_argument("--pml", type=int, default=4)
+    ap.add_argument("--sensor", default="random")
+    ap.add_argument("--per-rank", action="store_true",
+                    help="full-size runs: every rank builds only its own slab of the problem and writes <out>.rank<r>.npz")
     ap.add_argument("--out", required=True)
     a = ap.parse_args()
     dist.init_process_group(a.backend)
@@ -30,19 +34,28 @@ def main():
     dev = int(os.environ.get("LOCAL_RANK", "0")) if a.backend == "nccl" else 0
     nx, ny, nz = a.dims
     het, nonlin, absorb = (c == "1" for c in a.medium)
+    zslab = (rank * nz // P, (rank + 1) * nz // P) if a.per_rank else None
     pr = synthetic.make_problem(nx, ny, nz, heterogeneous=het, nonlinear=nonlin, absorbing=absorb, source=a.source,
-                                source_mode=a.mode, source_many=1, nt=a.steps, pml_size=4, sensor="random")
-    loc, info = partition_problem(pr, rank, P)
+                                source_mode=a.mode, source_many=1, nt=a.steps, pml_size=a.pml, sensor=a.sensor, zslab=zslab)
+    loc, info = partition_problem(pr, rank, P, arrays_are_local=a.per_rank)
+    del pr
     sim = DistSolver(loc, rank, P, nz, device_index=dev, p_raw=1, p_max=1)
     sim.run(a.steps)
     sim.finish()
     fields = {k: sim.field(k) for k in ("p", "ux", "uz", "rhoy")}
     series = sim.stream("p") if info["sensor_positions"].size else np.zeros((a.steps, 0), dtype=np.float32)
+    if a.per_rank:
+        np.savez(f"{a.out}.rank{rank}.npz", series=series, pos=info["sensor_positions"],
+                 exchanges=np.array([sim.exchange.calls]), **fields)
+        sim.close()
+        dist.barrier()
+        dist.destroy_process_group()
+        return
     gathered = [None] * P if rank == 0 else None
     dist.gather_object({"fields": fields, "series": series, "pos": info["sensor_positions"]}, gathered, dst=0)
     if rank == 0:
         out = {k: np.concatenate([g["fields"][k] for g in gathered], axis=0) for k in fields}
-        n_sens = pr["sensor_mask_index"].size
+        n_sens = sum(g["pos"].size for g in gathered)
         full = np.zeros((a.steps, n_sens), dtype=np.float32)
         for g in gathered:
             if g["pos"].size:

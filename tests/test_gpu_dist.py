@@ -128,3 +128,64 @@ def test_file_driven_slab_run_matches_the_single_gpu_output_file(syn, tmp_path, 
         a, b = h5io.read_dataset(many, name), h5io.read_dataset(one, name)
         assert a.shape == b.shape, name
         assert rel_l2(a, b) < TOL, name
+
+
+# ---- BASELINE config 4 at its real size -------------------------------------------------------------------------------
+_FULL = {}
+
+
+def _full_size_reference(syn, orc, dims, steps):
+    """single-GPU fused run of the same problem (and, for p, the CPU oracle), computed once per grid"""
+    if dims not in _FULL:
+        import kwave_amd  # noqa: F401
+        from kwave_amd.solver import HostSolver
+        nx, ny, nz = dims
+        pr = syn.make_problem(nx, ny, nz, heterogeneous=True, nonlinear=True, absorbing=True, source="p0", source_mode=0,
+                              source_many=1, nt=steps, pml_size=10, sensor="random")
+        g = HostSolver(pr, p_raw=1, p_max=1)
+        g.run(steps)
+        g.finish()
+        ref = {f: g.field(f) for f in ("p", "ux", "uz", "rhoy")}
+        ref["series"] = g.stream("p")
+        g.close()
+        o = orc.OracleSim(pr)
+        o.step(steps)
+        ref["oracle_p"] = o.field("p").copy()
+        ref["oracle_uz"] = o.field("uz").copy()
+        o.close()
+        _FULL.clear()  # one grid at a time (each entry holds GBs)
+        _FULL[dims] = ref
+    return _FULL[dims]
+
+
+@pytest.mark.parametrize("world,backend,dims", [
+    (2, "gloo", (512, 512, 512)),   # 2 ranks share the one GPU (host-staged all-to-all)
+    (1, "nccl", (512, 512, 512)),   # the RCCL path exchanging with itself
+    (4, "gloo", (256, 512, 512)),   # 128 ky rows / 128 planes per rank: the 2 x 256 split y / z kernels with 4 peer chunks
+])
+def test_config4_slab_at_full_size(orc, syn, tmp_path, world, backend, dims):
+    """BASELINE config 4: 512^3 heterogeneous absorbing nonlinear medium as Z-slabs (KSpaceFirstOrderSolver.cpp:885-935
+    per rank + one all-to-all per 3-D FFT), against the single-GPU fused run of the same problem and the CPU oracle."""
+    steps = 6
+    ref = _full_size_reference(syn, orc, dims, steps)
+    assert rel_l2(ref["p"], ref["oracle_p"]) < TOL and rel_l2(ref["uz"], ref["oracle_uz"]) < TOL
+    out = str(tmp_path / "full")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
+           "--master-addr", "127.0.0.1", "--master-port", str(29790 + world),
+           os.path.join(HERE, "dist_worker_gpu.py"), "--dims", *map(str, dims), "--steps", str(steps), "--source", "p0",
+           "--backend", backend, "--pml", "10", "--per-rank", "--out", out]
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900,
+                       env=dict(os.environ, OMP_NUM_THREADS="4", HSA_ENABLE_IPC_MODE_LEGACY="0"))
+    assert r.returncode == 0, r.stdout[-4000:]
+    parts = [np.load(f"{out}.rank{k}.npz") for k in range(world)]
+    for f in ("p", "ux", "uz", "rhoy"):
+        got = np.concatenate([q[f] for q in parts], axis=0)
+        assert got.shape == ref[f].shape and rel_l2(got, ref[f]) < TOL, f
+        if f == "p":
+            assert rel_l2(got, ref["oracle_p"]) < TOL
+    series = np.zeros_like(ref["series"])
+    for q in parts:
+        if q["pos"].size:
+            series[:, q["pos"]] = q["series"]
+    assert rel_l2(series, ref["series"]) < TOL
+    assert all(int(q["exchanges"][0]) >= 13 * (steps - 1) for q in parts)

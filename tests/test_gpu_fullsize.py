@@ -49,6 +49,76 @@ def test_config3_fused_pipeline_equals_rocfft_path_256(syn):
     b.close()
 
 
+def test_config3_256_vs_oracle(orc, syn):
+    """BASELINE config 3 at its real size, straight against the CPU oracle: 20 steps of the bench medium (heterogeneous
+    c0 / rho0 / BonA / alpha_coeff, absorbing + nonlinear, p0 source) through the fused pipeline; state fields and the
+    sensor series (one xy plane, 65 536 points) within 1e-5 relative L2, sampling bit-exact on the device field."""
+    steps = 20
+    pr = syn.make_problem(N, heterogeneous=True, nonlinear=True, absorbing=True, source="p0", nt=steps + 4)
+    g = gpu(pr, p_raw=1, p_max=1)
+    g.run(steps)
+    g.finish()
+    o = orc.OracleSim(pr)
+    series = np.empty((steps, o.sensor_index.size), dtype=np.float32)
+    for t in range(steps):
+        o.step()
+        series[t] = o.field("p").reshape(-1)[o.sensor_index]
+    for f in ("p", "ux", "uy", "uz", "rhox", "rhoz"):
+        assert rel_l2(g.field(f), o.field(f)) < TOL, f
+    s = g.stream("p")
+    assert s.shape == series.shape and rel_l2(s, series) < TOL
+    assert np.array_equal(s[-1], g.field("p").reshape(-1)[o.sensor_index.astype(np.int64)])
+    assert rel_l2(g.stream("p_max"), series.max(axis=0)) < TOL
+    o.close()
+    g.close()
+
+
+def test_config5_256_vs_oracle(orc, syn):
+    """BASELINE config 5 at its real size against the oracle: 256^3 config-3 medium driven by the 1 MHz p_source plane,
+    --p_c --u_non_staggered_c --I_avg_c (+ the raw series they are built from).  The oracle runs the same 60 steps; its
+    fields, its raw pressure series, its shifted-velocity restatement (computeShiftedVelocity, :2714-2735) and its
+    compressor (IndexOutputStream.cpp:373-470, basis pinned to the compiled reference CompressHelper) are the checks."""
+    pr = syn.make_problem(N, heterogeneous=True, nonlinear=True, absorbing=True, source="p_source", source_mode=1, nt=64)
+    dt = float(pr["dt"].ravel()[0])
+    period, mos, harm = 1.0 / (1.0e6 * dt), 1, 1
+    steps = 2 * int(period * mos) + 3  # two emitted frames
+    assert steps <= 64
+    g = gpu(pr, p_raw=1, u_non_staggered_raw=1, p_c=1, u_non_staggered_c=1, i_avg_c=1, period=period, mos=mos, harmonics=harm)
+    g.run(steps)
+    g.finish()
+    o = orc.OracleSim(pr)
+    mask = o.sensor_index.astype(np.int64)
+    p_series = np.empty((steps, mask.size), dtype=np.float32)
+    ux_series = np.empty((steps, mask.size), dtype=np.float32)
+    for t in range(steps):
+        o.step()
+        p_series[t] = o.field("p").reshape(-1)[mask]
+        ux_series[t] = orc.shifted_velocity(o.field("ux"), pr["x_shift_neg_r"], 0).reshape(-1)[mask]
+    for f in ("p", "ux", "uz", "rhoy"):
+        assert rel_l2(g.field(f), o.field(f)) < TOL, f
+    assert rel_l2(g.stream("p"), p_series) < TOL
+    assert rel_l2(g.stream("ux_non_staggered"), ux_series) < TOL
+    for axis, nm in enumerate(("ux", "uy", "uz")):
+        ref = orc.shifted_velocity(o.field(nm), pr["xyz"[axis] + "_shift_neg_r"], axis)
+        assert rel_l2(g.field(nm + "_shifted"), ref) < TOL, nm
+        assert np.array_equal(g.stream(nm + "_non_staggered")[-1], g.field(nm + "_shifted").reshape(-1)[mask])
+    # compression frames of the oracle's own series vs the device's accumulation of the device's series
+    frames = {}
+    for name, series, shifted in (("p_c", p_series, False), ("ux_non_staggered_c", ux_series, True)):
+        comp = orc.Compressor(mask.size, period, mos, harm, shifted)
+        for row in series:
+            comp.step(row)
+        got = g.stream(name).reshape(-1, mask.size, harm, 2)
+        ref = np.array(comp.frames)
+        assert got.shape == ref.shape and got.shape[0] == 2, name
+        assert rel_l2(got, ref) < TOL, name
+        frames[name] = ref[..., 0] + 1j * ref[..., 1]
+    ref_i = (np.real(frames["p_c"] * np.conj(frames["ux_non_staggered_c"])).sum(axis=2) / 2.0).mean(axis=0)
+    assert rel_l2(g.stream("Ix_avg_c"), ref_i) < TOL
+    o.close()
+    g.close()
+
+
 def test_config5_streams_fused_shift_equals_rocfft_shift_256(syn):
     """BASELINE config 5 at full size: the non-staggered velocity of the one-kernel-per-axis shift against the
     R2C -> multiply -> C2R form (rocFFT 1-D transforms), and the compression / intensity streams built on it."""
