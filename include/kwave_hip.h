@@ -43,7 +43,8 @@ typedef enum kw_status
   KW_ERR_FFT       = 3, /* rocFFT error (CufftComplexMatrix.cpp:63-72,706-720) */
   KW_ERR_ALLOC     = 4, /* out of memory (std::bad_alloc of BaseFloatMatrix.cpp:140-143) */
   KW_ERR_STATE     = 5, /* call order violated (constants / plans not set) */
-  KW_ERR_NO_DEVICE = 6  /* no usable gfx950 device (CudaParameters.cpp:81-177) */
+  KW_ERR_NO_DEVICE = 6, /* no usable gfx950 device (CudaParameters.cpp:81-177) */
+  KW_ERR_COMM      = 7  /* multi-GPU exchange failed: RCCL error, or a caller-supplied exchange callback returned non-zero */
 } kw_status;
 
 /* Parameters/Parameters.h:60-94 */
@@ -280,19 +281,35 @@ KW_API kw_status kw_compute_velocity_shift(kw_ctx* ctx, int axis, float* spectru
  * all-to-all transpose per 3-D FFT.  A context in slab mode holds nz = nz_global/nranks planes of every real array
  * (kw_set_constants gets the LOCAL nz; fft_divider stays 1/(nx*ny*nz_global)) and, in k-space, ny/nranks rows with all
  * nz_global planes ("transposed" layout [nz_global][ny/nranks][P]); reduced operators (kappa, nabla, sourceKappa) are
- * supplied in that transposed layout.  The exchange itself is delegated to the caller, which owns the communicator:
- * exchange(user, send, recv, bytes_per_peer) must perform an all-to-all of equal contiguous chunks (chunk q of `send`
- * goes to rank q; chunk q of `recv` comes from rank q), ordered after all prior work on the context's stream and
- * complete (or stream-ordered) before it returns — e.g. torch.distributed.all_to_all_single over RCCL. */
-typedef void (*kw_exchange_fn)(void* user, void* send, void* recv, size_t bytes_per_peer);
+ * supplied in that transposed layout.
+ *
+ * The exchange is an all-to-all of equal contiguous chunks (chunk q of `send` goes to rank q; chunk q of `recv` comes
+ * from rank q).  Default: the library's own RCCL path — kw_comm_init gives the context a communicator and a
+ * communication stream; every exchange is ncclGroupStart / ncclSend + ncclRecv per peer / ncclGroupEnd on that stream,
+ * ordered against the context's stream by events (split-phase: the transpose of one array is in flight while the
+ * passes of the others run); no host code but the enqueueing runs per exchange.
+ *   rank 0: kw_comm_unique_id(id) -> distribute the KW_COMM_ID_BYTES bytes to all ranks by any means (file, socket,
+ *   MPI, a torch.distributed store) -> every rank: kw_comm_init(ctx, nranks, rank, id)   [collective, blocks]
+ *   -> kw_fused_set_slab(ctx, nranks, rank, nz_global, NULL, NULL) -> kw_fused_create(ctx).
+ * One rank with a communicator runs the slab path exchanging with itself (rehearsal on a one-GPU machine). */
+#define KW_COMM_ID_BYTES 128
+KW_API kw_status kw_comm_unique_id(void* out_id, size_t bytes);  /* ncclGetUniqueId; bytes >= KW_COMM_ID_BYTES */
+KW_API kw_status kw_comm_init(kw_ctx* ctx, uint32_t nranks, uint32_t rank, const void* unique_id);
+KW_API kw_status kw_comm_destroy(kw_ctx* ctx);                    /* also done by kw_destroy */
+KW_API kw_status kw_comm_info(kw_ctx* ctx, uint32_t* nranks, uint32_t* rank, uint64_t* exchanges_started);
+/* Override: a caller that owns its own communicator passes exchange(user, send, recv, bytes_per_peer), which must be
+ * ordered after all prior work on the context's stream and complete (or stream-ordered) before it returns — e.g.
+ * torch.distributed.all_to_all_single, or a host-staged all-to-all when several ranks share one GPU (tests).  The
+ * callbacks return 0 on success; anything else aborts the step with KW_ERR_COMM. */
+typedef int (*kw_exchange_fn)(void* user, void* send, void* recv, size_t bytes_per_peer);
 KW_API kw_status kw_fused_set_slab(kw_ctx* ctx, uint32_t nranks, uint32_t rank, uint32_t nz_global,
-                                   kw_exchange_fn exchange, void* user);   /* before kw_fused_create */
+                                   kw_exchange_fn exchange, void* user);   /* before kw_fused_create; NULL = RCCL path */
 /* Optional split-phase form of the same all-to-all, so that transposes overlap with compute: start(user, send, recv,
  * bytes_per_peer, slot) begins the exchange (ordered after the work enqueued so far on the context's stream) and
  * returns; wait(user, slot) makes the context's stream wait for that exchange (slot in 0..2, one exchange in flight per
  * slot).  E.g. all_to_all_single(async_op=True) / work.wait().  Without it the blocking callback is used. */
-typedef void (*kw_exchange_start_fn)(void* user, void* send, void* recv, size_t bytes_per_peer, int slot);
-typedef void (*kw_exchange_wait_fn)(void* user, int slot);
+typedef int (*kw_exchange_start_fn)(void* user, void* send, void* recv, size_t bytes_per_peer, int slot);
+typedef int (*kw_exchange_wait_fn)(void* user, int slot);
 KW_API kw_status kw_fused_set_slab_async(kw_ctx* ctx, kw_exchange_start_fn start, kw_exchange_wait_fn wait);
 KW_API kw_status kw_fused_scratch_bytes(kw_ctx* ctx, size_t* out_bytes_per_array);
 /* like kw_fused_create but with caller-owned scratch (each of kw_fused_scratch_bytes bytes): s[3], and t[3] when

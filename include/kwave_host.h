@@ -46,7 +46,8 @@ typedef struct kwh_options
   uint64_t mos, harmonics;
   /* Z-slab decomposition (one process per GPU).  With slab_ranks > 1 the datasets describe this rank's slab: "Nz" is
    * the local plane count, 3-D arrays / pml_z / pml_z_sgz are the local slices, source and sensor indices are local
-   * (re-based, 1-based) indices; ddz_* stay global.  exchange_fn is the all-to-all (kw_exchange_fn of kwave_hip.h). */
+   * (re-based, 1-based) indices; ddz_* stay global.  The all-to-all is the device library's RCCL path (comm_unique_id
+   * below) unless exchange_fn (kw_exchange_fn of kwave_hip.h) overrides it. */
   uint64_t slab_ranks, slab_rank, nz_global;
   void*    exchange_fn;
   void*    exchange_user;
@@ -59,6 +60,10 @@ typedef struct kwh_options
   int32_t  u_c;        /* --u_c: compression coefficients of the staggered velocities (OutputStreamContainer.cpp:133-142) */
   float    frequency;  /* --frequency [Hz]: period = 1 / (frequency * dt) (Parameters.cpp:468-480); not together with period */
   int32_t  reserved_;
+  /* slab runs over the library's own RCCL path (the default multi-GPU exchange): KW_COMM_ID_BYTES bytes from
+   * kw_comm_unique_id() on rank 0, the same on every rank; exchange_fn / exchange_start_fn must then be NULL.
+   * With slab_ranks == 1 the rank exchanges with itself (rehearsal of the multi-GPU path on one GPU). */
+  const void* comm_unique_id;
 } kwh_options;
 
 KWH_API const char* kwh_last_error(void);

@@ -84,6 +84,7 @@ kw_status kw_destroy(kw_ctx* ctx)
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
   kw_fft_destroy_plans(ctx);
+  (void)kw_comm_destroy(ctx);
   if (ctx->copy_stream) { (void)hipStreamSynchronize(ctx->copy_stream); (void)hipStreamDestroy(ctx->copy_stream); }
   if (ctx->copy_fence) (void)hipEventDestroy(ctx->copy_fence);
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);

@@ -1612,14 +1612,21 @@ kw_status xstart(kw_ctx* ctx, int slot, float2* send, float2* recv)
 {
   const auto& f = ctx->fused;
   const size_t bytes_per_peer = static_cast<size_t>(ctx->c.nz) * f.nyl * f.PX * sizeof(float2);
-  if (f.exchange_start != nullptr) f.exchange_start(f.exchange_user, send, recv, bytes_per_peer, slot);
-  else f.exchange(f.exchange_user, send, recv, bytes_per_peer);
+  if (f.exchange_start == nullptr && f.exchange == nullptr) return kw_comm_exchange_start(ctx, slot, send, recv, bytes_per_peer);
+  const int rc = (f.exchange_start != nullptr) ? f.exchange_start(f.exchange_user, send, recv, bytes_per_peer, slot)
+                                               : f.exchange(f.exchange_user, send, recv, bytes_per_peer);
+  if (rc != 0) { kw_set_error("slab exchange: the caller's exchange callback failed (status %d)", rc); return KW_ERR_COMM; }
   return KW_OK;
 }
 kw_status xwait(kw_ctx* ctx, int slot)
 {
   const auto& f = ctx->fused;
-  if (f.exchange_start != nullptr) f.exchange_wait(f.exchange_user, slot);
+  if (f.exchange_start == nullptr && f.exchange == nullptr) return kw_comm_exchange_wait(ctx, slot);
+  if (f.exchange_start != nullptr)
+  {
+    const int rc = f.exchange_wait(f.exchange_user, slot);
+    if (rc != 0) { kw_set_error("slab exchange: the caller's wait callback failed (status %d)", rc); return KW_ERR_COMM; }
+  }
   return KW_OK;
 }
 
@@ -1848,9 +1855,21 @@ kw_status kw_fused_set_slab(kw_ctx* ctx, uint32_t nranks, uint32_t rank, uint32_
 {
   KW_CHECK_CTX(ctx);
   KW_REQUIRE(nranks >= 1 && rank < nranks);
-  KW_REQUIRE(nranks == 1 || fn != nullptr);
   if (ctx->fused.ready) { kw_set_error("kw_fused_set_slab: must be called before kw_fused_create"); return KW_ERR_STATE; }
-  ctx->fused.slab          = (nranks > 1) || (fn != nullptr); // one rank with an exchange = the slab path against itself
+  uint32_t comm_ranks = 0, comm_rank = 0;
+  KW_TRY(kw_comm_info(ctx, &comm_ranks, &comm_rank, nullptr));
+  if (fn == nullptr && nranks > 1 && comm_ranks == 0)
+  {
+    kw_set_error("kw_fused_set_slab: %u ranks need an exchange: call kw_comm_init first or pass a callback", nranks);
+    return KW_ERR_STATE;
+  }
+  if (fn == nullptr && comm_ranks != 0 && (comm_ranks != nranks || comm_rank != rank))
+  {
+    kw_set_error("kw_fused_set_slab: rank %u of %u does not match the communicator (rank %u of %u)", rank, nranks, comm_rank, comm_ranks);
+    return KW_ERR_INVALID;
+  }
+  // one rank with an exchange (callback or communicator) = the slab path against itself
+  ctx->fused.slab          = (nranks > 1) || (fn != nullptr) || (comm_ranks != 0);
   ctx->fused.nranks        = nranks;
   ctx->fused.rank          = rank;
   ctx->fused.nz_global     = nz_global;

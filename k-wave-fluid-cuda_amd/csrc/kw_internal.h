@@ -19,6 +19,9 @@ struct kw_fft_plan
   size_t                work  = 0;
 };
 
+struct kw_comm_state; // kw_comm.hip: RCCL communicator + communication stream + per-slot events
+#define KW_COMM_SLOTS 3
+
 struct kw_ctx
 {
   int          device      = 0;
@@ -60,6 +63,7 @@ struct kw_ctx
     kw_exchange_start_fn exchange_start = nullptr; // optional split-phase pair (overlap with compute)
     kw_exchange_wait_fn  exchange_wait  = nullptr;
   } fused;
+  kw_comm_state* comm = nullptr; // multi-GPU exchange (kw_comm_init)
   // profiling (kw_profile_enable)
   struct prof_rec { const char* name; hipEvent_t e0, e1; };
   bool                  profiling = false;
@@ -87,6 +91,10 @@ struct kw_prof_scope
   }
 };
 #define KW_PROF(ctx, name) kw_prof_scope kw_prof_scope_(ctx, name)
+
+// split-phase all-to-all on the context's communicator (kw_comm.hip); slot < KW_COMM_SLOTS
+kw_status kw_comm_exchange_start(kw_ctx* ctx, int slot, const void* send, void* recv, size_t bytes_per_peer);
+kw_status kw_comm_exchange_wait(kw_ctx* ctx, int slot);
 
 // thread-local error text (kw_last_error)
 void kw_set_error(const char* fmt, ...) __attribute__((format(printf, 1, 2)));

@@ -59,6 +59,13 @@ void KSpaceFirstOrderSolver::initializeFftPlans()
   kw_ctx* ctx = mParameters.getHipParameters().getContext();
   int fusedOk = 0;
   const Parameters::Options& opt = mParameters.getOptions();
+  if (mParameters.isSlabDecomposed() && opt.commUniqueId != nullptr)
+  { // the device library's own all-to-all: RCCL communicator + communication stream on the context (collective call)
+    if (opt.exchangeFn != nullptr || opt.exchangeStartFn != nullptr)
+      throw std::invalid_argument("Z-slab decomposition: give either commUniqueId (RCCL inside the device library) or exchange callbacks");
+    kwCheck(kw_comm_init(ctx, static_cast<uint32_t>(opt.slabRanks), static_cast<uint32_t>(opt.slabRank), opt.commUniqueId));
+    mOwnsComm = true;
+  }
   if (mParameters.isSlabDecomposed())
     kwCheck(kw_fused_set_slab(ctx, static_cast<uint32_t>(opt.slabRanks), static_cast<uint32_t>(opt.slabRank),
                               static_cast<uint32_t>(opt.nzGlobal), opt.exchangeFn, opt.exchangeUser));
@@ -771,173 +778,136 @@ void KSpaceFirstOrderSolver::releaseFusedPipeline()
   mStepGraph = nullptr;
   if (mFused) kw_fused_destroy(ctx);
   mFused = false;
+  if (mOwnsComm) (void)kw_comm_destroy(ctx);
+  mOwnsComm = false;
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// Host generators: same fp32 formula order as the reference (the operators are computed, not read from the file)
+// Host generators.  The operators are computed, not read from the file, so their fp32
+// rounding has to be the reference's (KSpaceFirstOrderSolver.cpp:2404-2703): per bin
+//     s = tx[x] + (tz[z] + ty[y]),   t_axis[i] = ((0.5 - |0.5 - i * (1/N)|)^2) * (1/d^2)
+// in exactly that association.  Each t depends on one coordinate only: three short tables are built once (the y table
+// starts at this rank's first ky in slab mode) and one sweep over the bins feeds whichever operators are wanted.
 // ---------------------------------------------------------------------------------------------------------------------
-void KSpaceFirstOrderSolver::generateKappa()
-{ // :2404-2452
-  const float dx2Rec = 1.0f / (mParameters.getDx() * mParameters.getDx());
-  const float dy2Rec = 1.0f / (mParameters.getDy() * mParameters.getDy());
-  const float dz2Rec = 1.0f / (mParameters.getDz() * mParameters.getDz());
-  const float cRefDtPi = mParameters.getCRef() * mParameters.getDt() * static_cast<float>(M_PI);
-  const DimensionSizes full = mParameters.getGlobalDimensionSizes(), red = mParameters.getReducedDimensionSizes();
-  // one GPU: [nz][ny][nxc].  Z-slab mode: this rank's spectra live transposed, [nz_global][ny/ranks][nxc], rows ky0..
-  const size_t nzg = full.nz, nyl = full.ny / mParameters.getSlabRanks(), ky0 = mParameters.getSlabRank() * nyl;
-  const float nxRec = 1.0f / static_cast<float>(full.nx);
-  const float nyRec = 1.0f / static_cast<float>(full.ny);
-  const float nzRec = 1.0f / static_cast<float>(full.nz);
-  float* kappa = real(MI::kKappa).getHostData();
-#pragma omp parallel for schedule(static)
-  for (size_t z = 0; z < nzg; z++)
+namespace
+{
+struct SpectralBins
+{
+  std::vector<float> tx, ty, tz; // squared normalised frequency over squared spacing, per axis
+  size_t             nxr = 0, nyl = 0, nzg = 0;
+
+  static std::vector<float> table(size_t count, size_t first, size_t n, float spacing, bool flat)
   {
-    const float zf = static_cast<float>(z);
-    float zPart    = 0.5f - std::fabs(0.5f - zf * nzRec);
-    zPart          = (zPart * zPart) * dz2Rec;
-    for (size_t yl = 0; yl < nyl; yl++)
+    std::vector<float> t(count);
+    const float nRec  = 1.0f / static_cast<float>(n);
+    const float d2Rec = flat ? 0.0f : 1.0f / (spacing * spacing); // an axis a 2-D grid does not have contributes nothing
+    for (size_t i = 0; i < count; i++)
     {
-      const float yf = static_cast<float>(ky0 + yl);
-      float yPart    = 0.5f - std::fabs(0.5f - yf * nyRec);
-      yPart          = (yPart * yPart) * dy2Rec;
-      const float yzPart = zPart + yPart;
-      for (size_t x = 0; x < red.nx; x++)
-      {
-        const float xf = static_cast<float>(x);
-        float xPart    = 0.5f - std::fabs(0.5f - xf * nxRec);
-        xPart          = (xPart * xPart) * dx2Rec;
-        const float k  = cRefDtPi * std::sqrt(xPart + yzPart);
-        kappa[(z * nyl + yl) * red.nx + x] = (k == 0.0f) ? 1.0f : std::sin(k) / k;
-      }
+      const float f = 0.5f - std::fabs(0.5f - static_cast<float>(first + i) * nRec);
+      t[i]          = (f * f) * d2Rec;
     }
+    return t;
   }
+
+  explicit SpectralBins(const Parameters& par)
+  {
+    const DimensionSizes full = par.getGlobalDimensionSizes();
+    nxr = par.getReducedDimensionSizes().nx;
+    nzg = full.nz;
+    // one GPU: [nz][ny][nxr]; Z-slab mode: this rank's spectra live transposed, [nz_global][ny / ranks][nxr]
+    nyl = full.ny / par.getSlabRanks();
+    tx  = table(nxr, 0, full.nx, par.getDx(), false);
+    ty  = table(nyl, par.getSlabRank() * nyl, full.ny, par.getDy(), false);
+    tz  = table(nzg, 0, full.nz, par.isSimulation3D() ? par.getDz() : 1.0f, !par.isSimulation3D());
+  }
+
+  // f(i, r) for every bin i of the reduced grid with r = sqrt(s)
+  template<class F> void sweep(F&& f) const
+  {
+#pragma omp parallel for schedule(static) collapse(2)
+    for (size_t z = 0; z < nzg; z++)
+      for (size_t y = 0; y < nyl; y++)
+      {
+        const float tzy = tz[z] + ty[y];
+        const size_t row = (z * nyl + y) * nxr;
+        for (size_t x = 0; x < nxr; x++) f(row + x, std::sqrt(tx[x] + tzy));
+      }
+  }
+};
+
+inline float sincOrOne(float a) { return (a == 0.0f) ? 1.0f : std::sin(a) / a; }
+inline float finiteOrZero(float v) { return (v == std::numeric_limits<float>::infinity()) ? 0.0f : v; }
+} // namespace
+
+void KSpaceFirstOrderSolver::generateKappa()
+{ // kappa = sinc(c_ref * dt * pi * |f|)
+  const float scale = mParameters.getCRef() * mParameters.getDt() * static_cast<float>(M_PI);
+  float* kappa = real(MI::kKappa).getHostData();
+  SpectralBins(mParameters).sweep([=](size_t i, float r) { kappa[i] = sincOrOne(scale * r); });
 }
 
 void KSpaceFirstOrderSolver::generateSourceKappa()
-{ // :2460-2506
-  const float dx2Rec = 1.0f / (mParameters.getDx() * mParameters.getDx());
-  const float dy2Rec = 1.0f / (mParameters.getDy() * mParameters.getDy());
-  const float dz2Rec = 1.0f / (mParameters.getDz() * mParameters.getDz());
-  const float cRefDtPi = mParameters.getCRef() * mParameters.getDt() * static_cast<float>(M_PI);
-  const DimensionSizes full = mParameters.getGlobalDimensionSizes(), red = mParameters.getReducedDimensionSizes();
-  // one GPU: [nz][ny][nxc].  Z-slab mode: this rank's spectra live transposed, [nz_global][ny/ranks][nxc], rows ky0..
-  const size_t nzg = full.nz, nyl = full.ny / mParameters.getSlabRanks(), ky0 = mParameters.getSlabRank() * nyl;
-  const float nxRec = 1.0f / static_cast<float>(full.nx);
-  const float nyRec = 1.0f / static_cast<float>(full.ny);
-  const float nzRec = 1.0f / static_cast<float>(full.nz);
+{ // source_kappa = cos(c_ref * dt * pi * |f|)
+  const float scale = mParameters.getCRef() * mParameters.getDt() * static_cast<float>(M_PI);
   float* sourceKappa = real(MI::kSourceKappa).getHostData();
-#pragma omp parallel for schedule(static)
-  for (size_t z = 0; z < nzg; z++)
-  {
-    const float zf = static_cast<float>(z);
-    float zPart    = 0.5f - std::fabs(0.5f - zf * nzRec);
-    zPart          = (zPart * zPart) * dz2Rec;
-    for (size_t yl = 0; yl < nyl; yl++)
-    {
-      const float yf = static_cast<float>(ky0 + yl);
-      float yPart    = 0.5f - std::fabs(0.5f - yf * nyRec);
-      yPart          = (yPart * yPart) * dy2Rec;
-      const float yzPart = zPart + yPart;
-      for (size_t x = 0; x < red.nx; x++)
-      {
-        const float xf = static_cast<float>(x);
-        float xPart    = 0.5f - std::fabs(0.5f - xf * nxRec);
-        xPart          = (xPart * xPart) * dx2Rec;
-        const float k  = cRefDtPi * std::sqrt(xPart + yzPart);
-        sourceKappa[(z * nyl + yl) * red.nx + x] = std::cos(k);
-      }
-    }
-  }
+  SpectralBins(mParameters).sweep([=](size_t i, float r) { sourceKappa[i] = std::cos(scale * r); });
 }
 
 void KSpaceFirstOrderSolver::generateKappaAndNablas()
-{ // :2514-2577
-  const float dxSqRec = 1.0f / (mParameters.getDx() * mParameters.getDx());
-  const float dySqRec = 1.0f / (mParameters.getDy() * mParameters.getDy());
-  const float dzSqRec = 1.0f / (mParameters.getDz() * mParameters.getDz());
-  const float cRefDt2 = mParameters.getCRef() * mParameters.getDt() * 0.5f;
-  const float pi2     = static_cast<float>(M_PI) * 2.0f;
-  const DimensionSizes full = mParameters.getGlobalDimensionSizes(), red = mParameters.getReducedDimensionSizes();
-  // one GPU: [nz][ny][nxc].  Z-slab mode: this rank's spectra live transposed, [nz_global][ny/ranks][nxc], rows ky0..
-  const size_t nzg = full.nz, nyl = full.ny / mParameters.getSlabRanks(), ky0 = mParameters.getSlabRank() * nyl;
-  const float nxRec = 1.0f / static_cast<float>(full.nx);
-  const float nyRec = 1.0f / static_cast<float>(full.ny);
-  const float nzRec = 1.0f / static_cast<float>(full.nz);
-  float* kappa        = real(MI::kKappa).getHostData();
-  float* absorbNabla1 = real(MI::kAbsorbNabla1).getHostData();
-  float* absorbNabla2 = real(MI::kAbsorbNabla2).getHostData();
-  const float alphaPower = mParameters.getAlphaPower();
-#pragma omp parallel for schedule(static)
-  for (size_t z = 0; z < nzg; z++)
-  {
-    const float zf = static_cast<float>(z);
-    float zPart    = 0.5f - std::fabs(0.5f - zf * nzRec);
-    zPart          = (zPart * zPart) * dzSqRec;
-    for (size_t yl = 0; yl < nyl; yl++)
-    {
-      const float yf = static_cast<float>(ky0 + yl);
-      float yPart    = 0.5f - std::fabs(0.5f - yf * nyRec);
-      yPart          = (yPart * yPart) * dySqRec;
-      const float yzPart = zPart + yPart;
-      for (size_t x = 0; x < red.nx; x++)
-      {
-        const float xf = static_cast<float>(x);
-        float xPart    = 0.5f - std::fabs(0.5f - xf * nxRec);
-        xPart          = (xPart * xPart) * dxSqRec;
-        const float k     = pi2 * std::sqrt(xPart + yzPart);
-        const float cRefK = cRefDt2 * k;
-        const size_t i    = (z * nyl + yl) * red.nx + x;
-        kappa[i]          = (cRefK == 0.0f) ? 1.0f : std::sin(cRefK) / cRefK;
-        absorbNabla1[i]   = std::pow(k, alphaPower - 2.0f);
-        absorbNabla2[i]   = std::pow(k, alphaPower - 1.0f);
-        if (absorbNabla1[i] == std::numeric_limits<float>::infinity()) absorbNabla1[i] = 0.0f;
-        if (absorbNabla2[i] == std::numeric_limits<float>::infinity()) absorbNabla2[i] = 0.0f;
-      }
-    }
-  }
+{ // k = 2 pi |f|;  kappa = sinc(c_ref * dt / 2 * k),  nabla1 = k^(y - 2),  nabla2 = k^(y - 1), infinities (k = 0) -> 0
+  const float halfStep = mParameters.getCRef() * mParameters.getDt() * 0.5f;
+  const float twoPi    = static_cast<float>(M_PI) * 2.0f;
+  const float power    = mParameters.getAlphaPower();
+  float* kappa  = real(MI::kKappa).getHostData();
+  float* nabla1 = real(MI::kAbsorbNabla1).getHostData();
+  float* nabla2 = real(MI::kAbsorbNabla2).getHostData();
+  SpectralBins(mParameters).sweep([=](size_t i, float r) {
+    const float k = twoPi * r;
+    kappa[i]      = sincOrOne(halfStep * k);
+    nabla1[i]     = finiteOrZero(std::pow(k, power - 2.0f));
+    nabla2[i]     = finiteOrZero(std::pow(k, power - 1.0f));
+  });
 }
 
 void KSpaceFirstOrderSolver::generateTauAndEta()
-{ // :2584-2643
-  const float alphaPower       = mParameters.getAlphaPower();
-  const float tanPi2AlphaPower = std::tan(static_cast<float>(M_PI_2) * alphaPower);
-  const float alphaNeperCoeff =
-    (100.0f * std::pow(1.0e-6f / (2.0f * static_cast<float>(M_PI)), alphaPower)) / (20.0f * static_cast<float>(M_LOG10E));
-  if ((mParameters.getAlphaCoeffScalarFlag()) && (mParameters.getC0ScalarFlag()))
+{ // tau = -2 a c0^(y-1),  eta = 2 a c0^y tan(pi y / 2),  a = alpha_coeff * 100 (1e-6 / 2 pi)^y / (20 log10 e)  [Np]
+  const float power   = mParameters.getAlphaPower();
+  const float tanTerm = std::tan(static_cast<float>(M_PI_2) * power);
+  const float neper   = (100.0f * std::pow(1.0e-6f / (2.0f * static_cast<float>(M_PI)), power)) / (20.0f * static_cast<float>(M_LOG10E));
+  const bool  alphaIsScalar = mParameters.getAlphaCoeffScalarFlag(), c0IsScalar = mParameters.getC0ScalarFlag();
+  if (alphaIsScalar && c0IsScalar)
   {
-    const float alphaCoeff2 = 2.0f * mParameters.getAlphaCoeffScalar() * alphaNeperCoeff;
-    mParameters.setAbsorbTauScalar((-alphaCoeff2) * std::pow(mParameters.getC0Scalar(), alphaPower - 1));
-    mParameters.setAbsorbEtaScalar(alphaCoeff2 * std::pow(mParameters.getC0Scalar(), alphaPower) * tanPi2AlphaPower);
+    const float a2 = 2.0f * mParameters.getAlphaCoeffScalar() * neper;
+    mParameters.setAbsorbTauScalar((-a2) * std::pow(mParameters.getC0Scalar(), power - 1));
+    mParameters.setAbsorbEtaScalar(a2 * std::pow(mParameters.getC0Scalar(), power) * tanTerm);
     return;
   }
-  float* absorbTau = real(MI::kAbsorbTau).getHostData();
-  float* absorbEta = real(MI::kAbsorbEta).getHostData();
-  const bool   alphaCoeffScalarFlag = mParameters.getAlphaCoeffScalarFlag();
-  const float  alphaCoeffScalar     = alphaCoeffScalarFlag ? mParameters.getAlphaCoeffScalar() : 0.0f;
-  const float* alphaCoeffMatrix     = alphaCoeffScalarFlag ? nullptr : getTemp1RealND().getHostData();
-  const bool   c0ScalarFlag         = mParameters.getC0ScalarFlag();
-  const float  c0Scalar             = c0ScalarFlag ? mParameters.getC0Scalar() : 0.0f;
-  const float* c0Matrix             = c0ScalarFlag ? nullptr : real(MI::kC2).getHostData(); // still holds c0 (:2612)
+  // per voxel as soon as either operand is an array; alpha_coeff was loaded into Temp1, the c2 matrix still holds c0
+  const float* alpha = alphaIsScalar ? nullptr : getTemp1RealND().getHostData();
+  const float* c0    = c0IsScalar ? nullptr : real(MI::kC2).getHostData();
+  const float  alphaScalar = alphaIsScalar ? mParameters.getAlphaCoeffScalar() : 0.0f;
+  const float  c0Scalar    = c0IsScalar ? mParameters.getC0Scalar() : 0.0f;
+  float* tau = real(MI::kAbsorbTau).getHostData();
+  float* eta = real(MI::kAbsorbEta).getHostData();
   const size_t n = mParameters.getFullDimensionSizes().nElements();
 #pragma omp parallel for schedule(static)
   for (size_t i = 0; i < n; i++)
   {
-    const float alphaCoeff2 = 2.0f * alphaNeperCoeff * (alphaCoeffScalarFlag ? alphaCoeffScalar : alphaCoeffMatrix[i]);
-    const float c0          = c0ScalarFlag ? c0Scalar : c0Matrix[i];
-    absorbTau[i] = (-alphaCoeff2) * std::pow(c0, alphaPower - 1.0f);
-    absorbEta[i] = alphaCoeff2 * std::pow(c0, alphaPower) * tanPi2AlphaPower;
+    const float a2 = 2.0f * neper * (alpha ? alpha[i] : alphaScalar);
+    const float c  = c0 ? c0[i] : c0Scalar;
+    tau[i] = (-a2) * std::pow(c, power - 1.0f);
+    eta[i] = a2 * std::pow(c, power) * tanTerm;
   }
 }
 
 void KSpaceFirstOrderSolver::computeC2()
-{ // :2690-2703
-  if (!mParameters.getC0ScalarFlag())
-  {
-    float*       c2   = real(MI::kC2).getHostData();
-    const size_t size = real(MI::kC2).size();
+{ // c0 -> c0^2 in place (heterogeneous sound speed only; the scalar is squared in Parameters)
+  if (mParameters.getC0ScalarFlag()) return;
+  RealMatrix& c = real(MI::kC2);
+  float* v = c.getHostData();
+  const size_t n = c.size();
 #pragma omp parallel for schedule(static)
-    for (size_t i = 0; i < size; i++) c2[i] = c2[i] * c2[i];
-  }
+  for (size_t i = 0; i < n; i++) v[i] *= v[i];
 }
 
 // dt/rho0_sg on a non-uniform grid (KSpaceFirstOrderSolver.cpp:2650-2685 for heterogeneous density).  For a homogeneous

@@ -49,7 +49,8 @@ void Parameters::init(const InputProvider& in, const Options& options)
   in.readScalarValue(kDtName, mDt);
   in.readScalarValue(kDxName, mDx);
   in.readScalarValue(kDyName, mDy);
-  in.readScalarValue(kDzName, mDz);
+  mDz = 0.0f;
+  if (isSimulation3D()) in.readScalarValue(kDzName, mDz); // a 2-D input file has no dz (Parameters.cpp:240-243)
   in.readScalarValue(kCRefName, mCRef);
   const char* const pmlSizeNames[3]  = {"pml_x_size", "pml_y_size", "pml_z_size"};
   const char* const pmlAlphaNames[3] = {"pml_x_alpha", "pml_y_alpha", "pml_z_alpha"};

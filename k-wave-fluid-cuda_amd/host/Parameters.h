@@ -63,7 +63,10 @@ class Parameters
     // The input then describes the LOCAL slab: Nz = nzGlobal/slabRanks planes of every 3-D array, the local slice of
     // pml_z / pml_z_sgz, local (re-based) source / sensor indices; 1-D k-space operators stay global.
     size_t slabRanks = 1, slabRank = 0, nzGlobal = 0;
-    kw_exchange_fn exchangeFn = nullptr; // all-to-all provided by the driver (RCCL through torch.distributed)
+    // the all-to-all: by default the device library's own RCCL path — commUniqueId (KW_COMM_ID_BYTES bytes made by
+    // kw_comm_unique_id on rank 0 and handed to every rank) creates the communicator; exchangeFn overrides it
+    const void*    commUniqueId = nullptr;
+    kw_exchange_fn exchangeFn = nullptr; // all-to-all provided by the driver (e.g. host-staged, ranks sharing a GPU)
     void*  exchangeUser = nullptr;
     kw_exchange_start_fn exchangeStartFn = nullptr; // optional split-phase pair: transposes overlap with compute
     kw_exchange_wait_fn  exchangeWaitFn  = nullptr;
@@ -84,7 +87,10 @@ class Parameters
   DimensionSizes getGlobalDimensionSizes() const { return mGlobalDimensionSizes; }
   size_t getSlabRanks() const { return mOptions.slabRanks; }
   size_t getSlabRank() const { return mOptions.slabRank; }
-  bool   isSlabDecomposed() const { return mOptions.slabRanks > 1 || mOptions.exchangeFn != nullptr; }
+  bool   isSlabDecomposed() const
+  {
+    return mOptions.slabRanks > 1 || mOptions.exchangeFn != nullptr || mOptions.commUniqueId != nullptr;
+  }
   DimensionSizes getReducedDimensionSizes() const { return mReducedDimensionSizes; }
   bool           isSimulation3D() const { return mGlobalDimensionSizes.is3D(); }
   bool           isSimulation2D() const { return mGlobalDimensionSizes.is2D(); }

@@ -36,6 +36,7 @@ Parameters::Options kwh_convert_options(const kwh_options* o)
   opt.slabRanks = o->slab_ranks ? o->slab_ranks : 1;
   opt.slabRank  = o->slab_rank;
   opt.nzGlobal  = o->nz_global;
+  opt.commUniqueId = o->comm_unique_id;
   opt.exchangeFn   = reinterpret_cast<kw_exchange_fn>(o->exchange_fn);
   opt.exchangeUser = o->exchange_user;
   opt.exchangeStartFn = reinterpret_cast<kw_exchange_start_fn>(o->exchange_start_fn);

@@ -41,7 +41,7 @@ class Options(C.Structure):
                 ("exchange_fn", C.c_void_p), ("exchange_user", C.c_void_p),
                 ("exchange_start_fn", C.c_void_p), ("exchange_wait_fn", C.c_void_p), ("scratch", C.c_void_p * 6),
                 ("i_avg", C.c_int32), ("q_term", C.c_int32), ("q_term_c", C.c_int32), ("u_c", C.c_int32),
-                ("frequency", C.c_float), ("reserved_", C.c_int32)]
+                ("frequency", C.c_float), ("reserved_", C.c_int32), ("comm_unique_id", C.c_void_p)]
 
 
 _hlib: Optional[C.CDLL] = None
@@ -140,6 +140,11 @@ class HostSolver:
             if fn is not None:
                 self._keep.append(fn)
                 setattr(o, key, C.cast(fn, C.c_void_p))
+        comm_id = opts.pop("comm_unique_id", None)
+        if comm_id is not None:  # bytes from capi.comm_unique_id(): the library's own RCCL exchange
+            buf = C.create_string_buffer(bytes(comm_id), len(comm_id))
+            self._keep.append(buf)
+            o.comm_unique_id = C.cast(buf, C.c_void_p)
         scratch = opts.pop("scratch", None)
         if scratch is not None:
             for i, ptr in enumerate(scratch):

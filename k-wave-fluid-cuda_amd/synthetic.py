@@ -306,7 +306,8 @@ Z_ONLY_DATASETS = ("ddz_k_shift_pos", "ddz_k_shift_neg", "z_shift_neg_r", "pml_z
 
 
 def as_2d_file(pr: Dict[str, np.ndarray]) -> Dict[str, np.ndarray]:
-    """A problem built with nz == 1, reduced to what a 2-D input file holds (dz is kept: it is a mandatory scalar)."""
+    """A problem built with nz == 1, reduced to what a 2-D input file holds (no z dataset at all, dz included:
+    Parameters/Parameters.cpp:240-259 reads dz, pml_z_size and pml_z_alpha only for 3-D)."""
     if int(np.asarray(pr["Nz"]).ravel()[0]) != 1:
         raise ValueError("as_2d_file needs a problem with Nz == 1")
-    return {k: v for k, v in pr.items() if k not in Z_ONLY_DATASETS or k == "dz"}
+    return {k: v for k, v in pr.items() if k not in Z_ONLY_DATASETS}

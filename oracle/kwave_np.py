@@ -39,6 +39,7 @@ def complete_2d(pr: Dict[str, np.ndarray]) -> Dict[str, np.ndarray]:
     out.setdefault("pml_z", one)
     out.setdefault("pml_z_sgz", one)
     out.setdefault("rho0_sgz", pr["rho0_sgx"])
+    out.setdefault("dz", pr["dx"])  # never used: the only z bin is 0 (the reference sets 1/dz^2 = 0 in 2-D)
     return out
 
 

@@ -456,7 +456,7 @@ static void generate_kappa(kwo_sim* s, int source_variant)
   const kwo_problem* pr = &s->pr;
   const float dx2Rec = 1.0f / (pr->dx * pr->dx);
   const float dy2Rec = 1.0f / (pr->dy * pr->dy);
-  const float dz2Rec = 1.0f / (pr->dz * pr->dz);
+  const float dz2Rec = (s->nz > 1) ? 1.0f / (pr->dz * pr->dz) : 0.0f; /* :2409, :2464: 0 for a 2-D grid */
   const float cRefDtPi = pr->c_ref * pr->dt * (float)M_PI;
   const float nxRec = 1.0f / (float)s->nx;
   const float nyRec = 1.0f / (float)s->ny;
@@ -494,7 +494,7 @@ static void generate_kappa_and_nablas(kwo_sim* s)
   const kwo_problem* pr = &s->pr;
   const float dxSqRec = 1.0f / (pr->dx * pr->dx);
   const float dySqRec = 1.0f / (pr->dy * pr->dy);
-  const float dzSqRec = 1.0f / (pr->dz * pr->dz);
+  const float dzSqRec = (s->nz > 1) ? 1.0f / (pr->dz * pr->dz) : 0.0f; /* :2518 */
   const float cRefDt2 = pr->c_ref * pr->dt * 0.5f;
   const float pi2 = (float)M_PI * 2.0f;
   const float nxRec = 1.0f / (float)s->nx;

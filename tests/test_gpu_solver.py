@@ -1,6 +1,8 @@
 """GPU parity tests proper: the C++ time loop (libkwave_host -> libkwave_hip, HIP kernels + rocFFT) against the CPU
 oracle on the same seeded inputs.  Tolerance: relative L2 <= 1e-5 on pressure (BASELINE.json north_star);
 sensor sampling bit-exact with respect to the sampled field."""
+import os
+
 import numpy as np
 import pytest
 
@@ -51,6 +53,22 @@ def test_preprocessing_operators_match_oracle(orc, syn):
     assert g.scalar("absorb_tau") == pytest.approx(o.scalar("tau"), rel=1e-6)
     assert g.scalar("absorb_eta") == pytest.approx(o.scalar("eta"), rel=1e-6)
     g.close()
+
+
+def test_host_generators_are_bit_identical_to_the_frozen_arrays():
+    """The pre-processing generators were rewritten around per-axis tables (round 2); their output must not move by a
+    bit from what the statement-order round-1 build produced (tests/golden/host_generators.npz, written on an MI355X
+    box by tests/golden/make_host_generators.py with the round-1 libraries)."""
+    import importlib.util
+    here = os.path.dirname(os.path.abspath(__file__))
+    spec = importlib.util.spec_from_file_location("make_host_generators", os.path.join(here, "golden", "make_host_generators.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    frozen = np.load(os.path.join(here, "golden", "host_generators.npz"))
+    now = mod.collect()
+    assert sorted(now) == sorted(frozen.files)
+    for name in frozen.files:
+        assert np.array_equal(now[name], frozen[name]), name
 
 
 def test_non_cubic_non_pow2(orc, syn):
