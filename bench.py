@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py — time-steps/s of the k-space first-order loop on MI355X (BASELINE.json metric).
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--size n] [--no-cpu]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--size n] [--no-cpu] [--no-512] [--weak | --strong]
 
 N=1 workload: BASELINE config 3 — 256^3 heterogeneous (c0, rho0, BonA, alpha_coeff as arrays), power-law absorption +
 nonlinear term, p0 source, p_raw + p_max sampled on one xy plane (the manual's benchmark setup).
@@ -9,13 +9,18 @@ A "step" is one pass of the per-step loop (KSpaceFirstOrderSolver.cpp:885-935) o
 resident in HBM before the timed region.  The C++ host loop (libkwave_host) drives libkwave_hip; there is no CPU
 fallback.  One JSON line is printed by rank 0.
 
-Extra objects: "roofline" (dominant device entry point: algorithmic bytes per launch / HIP-event duration, vs the
-8 TB/s HBM peak; "step" carries the whole-step figure with B_alg of SURVEY.md §8d) and "cpu_baseline" (the CPU oracle
-on the host cores for a bounded number of steps of the same workload).
+N>1 (python -m torch.distributed.run ... bench.py --gpus N): the same 256^3 workload as Z-slabs over N GPUs (strong
+scaling: one curve with the N=1 line), with BASELINE config 4 (512^3: N GPUs vs one) in config.c4_512; see
+run_distributed().
+
+Extra objects: "roofline" (dominant kernel: algorithmic bytes per launch / HIP-event duration, vs the 8 TB/s HBM spec
+peak, with this box's measured copy bandwidth beside it; "step" carries the whole-step figure with B_alg of SURVEY.md
+§8d) and "cpu_baseline" (the CPU oracle on the host cores for a bounded number of steps of the same workload).
 """
 from __future__ import annotations
 
 import argparse
+import ctypes as C
 import json
 import os
 import sys
@@ -99,82 +104,166 @@ def cpu_baseline(pr, n, budget_s=20.0):
     sim.step(steps)
     dt = time.time() - t0
     sim.close()
-    return {"value": steps / dt, "unit": "time-steps/s", "cores": cores, "kind": "port",
+    model = ""
+    try:
+        model = next(l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name"))
+    except (OSError, StopIteration):
+        pass
+    return {"value": steps / dt, "unit": "time-steps/s", "cores": cores, "kind": "port", "cpu_model": model,
+            "host_logical_cpus": os.cpu_count(),
             "sample": f"{steps} steps of the same {n}^3 workload after 2 untimed steps, OpenMP on {cores} threads, "
                       f"in-repo FFT (no FFTW/MKL); manual Table C.3: 224.5 ms/step on 2x12-core Haswell + MKL"}
+
+
+def kernel_source_hash():
+    """sha256 over the device sources: PMC counters committed under profiles/ are only quoted for the build they were
+    collected with"""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, "k-wave-fluid-cuda_amd", "csrc", "*"))):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def pmc_traffic_for_this_build():
+    """newest profiles/r*_pmc_traffic.json whose "kernel_source_hash" is this build's; (None, None) when none matches"""
+    import glob
+    cur = kernel_source_hash()
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")), reverse=True):
+        try:
+            d = json.load(open(f))
+        except (OSError, ValueError):
+            continue
+        if d.get("kernel_source_hash") == cur:
+            return f, d
+    return None, None
 
 
 WEAK_DIMS = {1: (256, 256, 256), 2: (256, 256, 512), 4: (256, 512, 512), 8: (512, 512, 512)}  # 256^3 voxels per GPU
 
 
-def run_distributed(args):
-    """N>1: one process per GPU (torch.distributed.run), Z-slab decomposition, RCCL all-to-all over xGMI.
+def single_gpu_rate(n, K, W):
+    """time-steps/s of the n^3 config-3 workload on this process's GPU alone (non-slab fused path)"""
+    import kwave_amd  # noqa: F401
+    from kwave_amd import synthetic
+    from kwave_amd.solver import HostSolver
+    pr = synthetic.make_problem(n, heterogeneous=True, nonlinear=True, absorbing=True, source="p0", nt=W + K + 8)
+    sim = HostSolver(pr, p_raw=1, p_max=1)
+    del pr
+    sim.run(W)
+    sim.sync()
+    ms = sim.time_steps(K)
+    sim.sync()
+    sim.close()
+    return K / (ms * 1e-3)
 
-    Default = weak scaling: every GPU owns 256^3 voxels (N=2: 256x256x512, N=4: 256x512x512, N=8: 512^3 — the last is
-    BASELINE config 4's grid).  `value` is the whole-job aggregate in the same unit as the N=1 line: time-steps/s of a
-    256^3-voxel block, i.e. N x (time-steps/s of the global grid); the global rate is in config.global_steps_per_s.
-    --strong --size n runs a fixed n^3 grid instead ("scaling": "strong", value = global time-steps/s)."""
+
+def run_distributed(args):
+    """N>1: one process per GPU (torch.distributed.run), Z-slab decomposition, one all-to-all transpose per 3-D FFT.
+
+    Default = strong scaling on the metric's own grid: `value` = time-steps/s of the 256^3 config-3 workload on N GPUs
+    (same grid, unit and workload as the N=1 line, so the per-N values form one curve).  BASELINE config 4 rides along
+    in config.c4_512: time-steps/s of the 512^3 grid on the same N GPUs, on one GPU (rank 0 alone, same run) and their
+    ratio (north_star: >= 3.5x at 8 GPUs).  --weak: every GPU owns 256^3 voxels instead (N=8 is the 512^3 grid),
+    value = N x global time-steps/s.  --strong --size n: one fixed n^3 grid only.
+
+    The data path is the device library's own RCCL exchange (--exchange native: kw_comm_init, ncclSend/ncclRecv groups
+    on a communication stream); the process group (gloo) only carries the communicator id, the barriers and the
+    max-over-ranks of the timings.  --exchange torch: torch.distributed.all_to_all_single as a callback (nccl group)."""
     import torch
     import torch.distributed as dist
     import kwave_amd  # noqa: F401
     from kwave_amd import synthetic
     from kwave_amd.dist import DistSolver, partition_problem, slab_range
 
-    dist.init_process_group(args.backend)
+    backend = "nccl" if args.exchange == "torch" else "gloo"
+    dist.init_process_group(backend)
     rank, world = dist.get_rank(), dist.get_world_size()
-    local_rank = int(os.environ.get("LOCAL_RANK", "0")) if args.backend == "nccl" else 0
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if local_rank >= torch.cuda.device_count():
         local_rank = 0  # the launcher narrowed the visible devices to this rank's GPU
     torch.cuda.set_device(local_rank)
-    if args.strong:
-        n = args.size or 512
-        nx = ny = nz = n
-    else:
+    K, W = args.steps, args.warmup
+
+    def reduce_max(x):
+        t = torch.tensor([x], dtype=torch.float64)
+        if backend == "nccl":
+            t = t.cuda()
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def slab_run(grid, k, w):
+        """k timed steps of the config-3 workload on `grid`, Z-slabs over all ranks; (seconds, exchanges per step)"""
+        nx, ny, nz = grid
+        z0, z1 = slab_range(nz, rank, world)
+        pr = synthetic.make_problem(nx, ny, nz, heterogeneous=True, nonlinear=True, absorbing=True, source="p0",
+                                    nt=w + k + 8, zslab=(z0, z1))
+        loc, _ = partition_problem(pr, rank, world, arrays_are_local=True)
+        del pr
+        sim = DistSolver(loc, rank, world, nz, device_index=local_rank, exchange=args.exchange, p_raw=1, p_max=1)
+        sim.run(w)
+        sim.sync()
+        torch.cuda.synchronize()
+        dist.barrier()
+        t0 = time.perf_counter()
+        sim.run(k)
+        sim.sync()
+        torch.cuda.synchronize()
+        sec = reduce_max(time.perf_counter() - t0)
+        dist.barrier()
+        per_step = sim.exchanges // max(k + w, 1)
+        sim.close()
+        return sec, per_step
+
+    c4 = None
+    if args.weak:
         if world not in WEAK_DIMS:
             raise SystemExit(f"weak-scaling grids are defined for 1/2/4/8 GPUs, not {world}")
-        nx, ny, nz = WEAK_DIMS[world]
-    K, W = args.steps, args.warmup
-    z0, z1 = slab_range(nz, rank, world)
-    pr = synthetic.make_problem(nx, ny, nz, heterogeneous=True, nonlinear=True, absorbing=True, source="p0",
-                                nt=W + K + 8, zslab=(z0, z1))
-    loc, _ = partition_problem(pr, rank, world, arrays_are_local=True)
-    sim = DistSolver(loc, rank, world, nz, device_index=local_rank, p_raw=1, p_max=1)
-    sim.run(W)
-    sim.sync()
-    torch.cuda.synchronize()
-    dist.barrier()
-    t0 = time.perf_counter()
-    sim.run(K)
-    sim.sync()
-    torch.cuda.synchronize()
-    dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
-    if args.backend == "nccl":
-        dt = dt.cuda()
-    dist.all_reduce(dt, op=dist.ReduceOp.MAX)
-    dist.barrier()
-    sec = float(dt.item())
+        grid = WEAK_DIMS[world]
+    elif args.strong:
+        grid = (args.size or 512,) * 3
+    else:
+        grid = (args.size or 256,) * 3
+        if not args.no_512 and world > 1:
+            k5, w5 = max(5, K // 5), max(2, W // 5)
+            one = single_gpu_rate(512, k5, w5) if rank == 0 else 0.0
+            dist.barrier()
+            sec5, ex5 = slab_run((512, 512, 512), k5, w5)
+            c4 = {"grid": [512, 512, 512], "steps": k5, "warmup": w5, "n_gpus": world,
+                  "steps_per_s": round(k5 / sec5, 3), "steps_per_s_1gpu": round(one, 3),
+                  "speedup_vs_1gpu": round((k5 / sec5) / one, 3) if one > 0 else None, "exchanges_per_step": ex5,
+                  "note": "BASELINE config 4 (north_star: >= 3.5x at 8 GPUs vs 1 on 512^3); 1-GPU figure measured by "
+                          "rank 0 alone in this run (non-slab fused path)"}
+    sec, ex = slab_run(grid, K, W)
+    nx, ny, nz = grid
     global_rate = K / sec
     if rank == 0:
         b_step, _ = alg_bytes(256)
         voxels = nx * ny * nz
         b_global = b_step * voxels / 256 ** 3
-        value = global_rate if args.strong else global_rate * world
+        value = global_rate * world if args.weak else global_rate
         out = {"metric": "time-steps/sec on 256^3 heterogeneous grid; achieved HBM GB/s vs roofline",
                "value": round(value, 2), "unit": "time-steps/s", "n_gpus": world, "steps": K, "warmup": W,
                "ms_per_step": round(1e3 * sec / K, 4), "higher_is_better": True,
-               "scaling": "strong" if args.strong else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-               "config": {"workload": f"{nx}x{ny}x{nz} heterogeneous, absorbing + nonlinear, p0 source, Z-slab decomposed "
-                                      f"over {world} GPUs ({voxels // world} voxels per GPU), all-to-all transpose per 3-D FFT",
-                          "grid": [nx, ny, nz], "parallelism": f"zslab{world}", "backend": args.backend,
+               "scaling": "weak" if args.weak else "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+               "config": {"workload": f"{nx}x{ny}x{nz} heterogeneous (c0,rho0,BonA,alpha_coeff arrays), power-law absorption "
+                                      f"+ nonlinear, p0 source, p_raw+p_max on one xy plane; Z-slabs over {world} GPUs "
+                                      f"({voxels // world} voxels per GPU), one all-to-all transpose per 3-D FFT",
+                          "grid": [nx, ny, nz], "parallelism": f"zslab{world}",
+                          "exchange": "RCCL inside libkwave_hip.so (ncclSend/ncclRecv groups on a communication stream)"
+                          if args.exchange == "native" else "torch.distributed.all_to_all_single (RCCL) callback",
                           "global_steps_per_s": round(global_rate, 2),
-                          "value_definition": "global time-steps/s" if args.strong else
-                          "N x global time-steps/s (each GPU owns one 256^3-voxel block)",
-                          "exchanges_per_step": sim.exchange.calls // max(K + W, 1)},
+                          "value_definition": "N x global time-steps/s (each GPU owns one 256^3-voxel block)" if args.weak
+                          else "global time-steps/s of this grid on N GPUs",
+                          "exchanges_per_step": ex},
                "roofline": {"bound": "hbm", "kernel": "step (all ranks)", "peak": HBM_PEAK_GBS * world, "unit": "GB/s",
                             "achieved": round(b_global / (sec / K) / 1e9, 1),
                             "frac": round(b_global / (sec / K) / 1e9 / (HBM_PEAK_GBS * world), 4), "traffic": None}}
+        if c4 is not None:
+            out["config"]["c4_512"] = c4
         print(json.dumps(out))
-    sim.close()
     dist.destroy_process_group()
     return 0
 
@@ -188,8 +277,11 @@ def main():
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--profile-steps", type=int, default=5)
     ap.add_argument("--granular", action="store_true", help="one launch per reference kernel instead of fused kernels")
-    ap.add_argument("--strong", action="store_true", help="N>1: fixed --size^3 grid (default 512) instead of weak scaling")
-    ap.add_argument("--backend", default="nccl", help="N>1: torch.distributed backend (nccl = RCCL; gloo for rehearsal)")
+    ap.add_argument("--strong", action="store_true", help="N>1: one fixed --size^3 grid (default 512) only")
+    ap.add_argument("--weak", action="store_true", help="N>1: 256^3 voxels per GPU (256x256x512 / 256x512x512 / 512^3)")
+    ap.add_argument("--no-512", action="store_true", help="N>1: skip the config-4 (512^3) block of the line")
+    ap.add_argument("--exchange", default=os.environ.get("KW_EXCHANGE", "native"), choices=("native", "torch"),
+                    help="N>1 data path: the device library's own RCCL exchange, or torch.distributed as a callback")
     ap.add_argument("--slab-selftest", action="store_true",
                     help="one rank through the N>1 code path (slab kernels + RCCL all-to-all with itself): rehearsal on a 1-GPU box")
     args = ap.parse_args()
@@ -248,27 +340,39 @@ def main():
         kernels = [k for k in table if per.get(k)]
     dom = max(kernels, key=lambda k: table[k]["ms_per_step"])
     achieved = per[dom] / (table[dom]["avg_ms"] * 1e-3) / 1e9
-    traffic, traffic_src = None, None
-    pmc_file = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-    if n == 256 and not args.granular and os.path.exists(pmc_file):
-        pmc = json.load(open(pmc_file))
+    traffic, traffic_src, step_traffic = None, None, None
+    pmc_file, pmc = pmc_traffic_for_this_build()
+    if n == 256 and not args.granular and pmc is not None:
         traffic = pmc.get("traffic_bytes_per_bench_kernel", {}).get(dom)
-        traffic_src = ("profiles/r01_pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) of this "
-                       "workload, 128-B read requests counted x2 (gfx950 correction, checked on probe kernels of known size)")
+        traffic_src = (f"profiles/{os.path.basename(pmc_file)}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) of "
+                       "this workload with this build of the kernels (source hash checked), 128-B read requests counted x2 "
+                       "(gfx950 correction, checked on probe kernels of known size)")
         step_traffic = pmc.get("traffic_bytes_per_step")
-    else:
-        step_traffic = None
+    # measured copy bandwidth of this box beside the spec peak (1 GiB buffers: four times the Infinity Cache)
+    copy_gbs = C.c_double()
+    capi.check(hip.kw_measure_copy_bandwidth(sim.ctx, 1 << 30, 10, C.byref(copy_gbs)))
     roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                "measured_copy_gbs": round(copy_gbs.value, 1),
+                "frac_of_measured_copy": round(achieved / copy_gbs.value, 4),
                 "traffic_source": traffic_src,
                 "alg_bytes_per_launch": per[dom], "avg_ms": table[dom]["avg_ms"],
                 "step": {"alg_bytes": b_step, "achieved": round(b_step / (ms * 1e-3 / K) / 1e9, 1),
-                         "frac": round(b_step / (ms * 1e-3 / K) / 1e9 / HBM_PEAK_GBS, 4), "traffic": step_traffic},
+                         "frac": round(b_step / (ms * 1e-3 / K) / 1e9 / HBM_PEAK_GBS, 4),
+                         "frac_of_measured_copy": round(b_step / (ms * 1e-3 / K) / 1e9 / copy_gbs.value, 4),
+                         "traffic": step_traffic},
                 "entry_points": {k: v for k, v in table.items() if not k.startswith("k_")},
                 "kernels": {k: v for k, v in table.items() if k.startswith("k_")}}
     info = capi.DeviceInfo()
     capi.check(hip.kw_device_info_get(sim.ctx, info))
     sim.close()
+    del sim
+    c4_one = None
+    if n == 256 and not args.granular and not args.no_512:
+        # BASELINE config 4's single-GPU point (the denominator of the >= 3.5x at 8 GPUs target), same process
+        k5 = max(5, K // 5)
+        c4_one = {"grid": [512, 512, 512], "steps": k5, "n_gpus": 1, "steps_per_s": round(single_gpu_rate(512, k5, 2), 3)}
+        c4_one["frac"] = round(alg_bytes(512)[0] * c4_one["steps_per_s"] / 1e9 / HBM_PEAK_GBS, 4)
 
     out = {"metric": "time-steps/sec on 256^3 heterogeneous grid; achieved HBM GB/s vs roofline",
            "value": round(steps_per_s, 2), "unit": "time-steps/s", "n_gpus": 1, "steps": K, "warmup": W,
@@ -282,6 +386,8 @@ def main():
                       "device": (info.name.decode() or info.arch.decode()), "baseline_ref": "BASELINE.md: 49.72 ms/step, TITAN X, "
                       "kspaceFirstOrder3D-CUDA v1.1 (manual Table C.4)", "input_generation_s": round(t_gen, 1)},
            "roofline": roofline}
+    if c4_one is not None:
+        out["config"]["c4_512"] = c4_one
     if not args.no_cpu:
         out["cpu_baseline"] = cpu_baseline(pr, n)
     print(json.dumps(out))

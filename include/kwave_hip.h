@@ -114,6 +114,10 @@ KW_API kw_status   kw_graph_begin(kw_ctx* ctx);
 KW_API kw_status   kw_graph_end(kw_ctx* ctx, kw_graph** out);
 KW_API kw_status   kw_graph_launch(kw_ctx* ctx, kw_graph* g);
 KW_API kw_status   kw_graph_destroy(kw_ctx* ctx, kw_graph* g);
+/* Measured device-copy bandwidth: a float4 copy kernel over two freshly allocated buffers of `bytes` each (choose
+ * them well above the 256 MB Infinity Cache), reps timed passes after one untimed; GB/s counts read + write.  bench.py
+ * reports it beside the spec peak. */
+KW_API kw_status   kw_measure_copy_bandwidth(kw_ctx* ctx, size_t bytes, int reps, double* out_gbs);
 /* HIP events on the context's stream (bench.py times kernels with these) */
 KW_API kw_status   kw_event_create(kw_ctx* ctx, void** out_event);
 KW_API kw_status   kw_event_record(kw_ctx* ctx, void* event);

@@ -106,10 +106,25 @@ def build_host_h5(force: bool = False) -> str:
     return HOST_H5_LIB
 
 
+SLAB_SELFTEST_BIN = os.path.join(LIB_DIR, "slab_selftest")
+
+
+def build_native_drivers(force: bool = False) -> str:
+    """tests/native/slab_selftest.c: the plain-C driver of the slab path over the library's own RCCL exchange."""
+    src = os.path.join(ROOT, "tests", "native", "slab_selftest.c")
+    if not (os.path.exists(src) and os.path.exists(HOST_H5_LIB)):
+        return ""
+    if force or _newer(SLAB_SELFTEST_BIN, [src, HOST_H5_LIB, HIP_LIB] + glob.glob(os.path.join(INCLUDE, "*.h"))):
+        _run(["gcc", "-O1", "-std=c11", "-Wall", "-I" + INCLUDE, "-o", SLAB_SELFTEST_BIN, src, "-L" + LIB_DIR,
+              "-lkwave_host_h5", "-lkwave_hip", "-Wl,-rpath,$ORIGIN", "-Wl,-rpath,/usr/lib/x86_64-linux-gnu"])
+    return SLAB_SELFTEST_BIN
+
+
 def build_all(force: bool = False, verbose: bool = False):
     build_hip(force, verbose)
     build_host(force)
     build_host_h5(force)
+    build_native_drivers(force)
 
 
 if __name__ == "__main__":

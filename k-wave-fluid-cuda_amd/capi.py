@@ -126,6 +126,11 @@ _SIG: Dict[str, list] = {
     "kw_sum_pressure_nonlinear_lossless": [_P] + [_P] * 7,
     "kw_sum_pressure_linear_lossless": [_P] + [_P] * 5,
     "kw_compute_velocity_shift": [_P, C.c_int, _P, _P],
+    "kw_measure_copy_bandwidth": [_P, C.c_size_t, C.c_int, C.POINTER(C.c_double)],
+    "kw_comm_unique_id": [_P, C.c_size_t],
+    "kw_comm_init": [_P, C.c_uint32, C.c_uint32, _P],
+    "kw_comm_destroy": [_P],
+    "kw_comm_info": [_P, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)],
     "kw_fused_set_slab": [_P, C.c_uint32, C.c_uint32, C.c_uint32, _P, _P],
     "kw_fused_set_slab_async": [_P, _P, _P],
     "kw_fused_scratch_bytes": [_P, C.POINTER(C.c_size_t)],
@@ -283,3 +288,20 @@ class Device:
             self.close()
         except Exception:
             pass
+
+
+COMM_ID_BYTES = 128
+
+
+def comm_unique_id() -> bytes:
+    """ncclGetUniqueId through the device library (kw_comm_unique_id): call on rank 0, hand the bytes to every rank."""
+    buf = C.create_string_buffer(COMM_ID_BYTES)
+    check(load().kw_comm_unique_id(buf, COMM_ID_BYTES))
+    return buf.raw
+
+
+def comm_exchanges(ctx) -> int:
+    """exchanges started so far on the context's communicator (0 without one)"""
+    n = C.c_uint64()
+    check(load().kw_comm_info(ctx, None, None, C.byref(n)))
+    return int(n.value)

@@ -363,6 +363,55 @@ kw_status kw_host_free(kw_ctx* ctx, void* hptr)
   return KW_OK;
 }
 
+// ---- measured device-copy bandwidth (reported beside the 8 TB/s spec peak) ------------------------------
+__global__ __launch_bounds__(256) void k_stream_copy(const float4* __restrict__ src, float4* __restrict__ dst, size_t n4)
+{
+  const size_t stride = static_cast<size_t>(gridDim.x) * blockDim.x;
+  for (size_t e = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x; e < n4; e += stride) dst[e] = src[e];
+}
+
+kw_status kw_measure_copy_bandwidth(kw_ctx* ctx, size_t bytes, int reps, double* out_gbs)
+{
+  KW_CHECK_CTX(ctx);
+  KW_REQUIRE(out_gbs != nullptr && bytes >= (1u << 20) && reps >= 1);
+  KW_HIP(hipSetDevice(ctx->device));
+  const size_t n4 = bytes / sizeof(float4);
+  float4 *src = nullptr, *dst = nullptr;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  kw_status rc = KW_OK;
+  auto cleanup = [&]() {
+    if (src) (void)hipFree(src);
+    if (dst) (void)hipFree(dst);
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+  };
+#define KW_BW(call)                                                                                                    \
+  do {                                                                                                                 \
+    const hipError_t e_ = (call);                                                                                      \
+    if (e_ != hipSuccess) { kw_set_error("GPU error: %s routine name: %s", hipGetErrorString(e_), __func__);            \
+                            cleanup(); return (e_ == hipErrorOutOfMemory) ? KW_ERR_ALLOC : KW_ERR_HIP; }                \
+  } while (0)
+  KW_BW(hipMalloc(reinterpret_cast<void**>(&src), n4 * sizeof(float4)));
+  KW_BW(hipMalloc(reinterpret_cast<void**>(&dst), n4 * sizeof(float4)));
+  KW_BW(hipMemsetAsync(src, 0, n4 * sizeof(float4), ctx->stream));
+  KW_BW(hipMemsetAsync(dst, 0, n4 * sizeof(float4), ctx->stream));
+  KW_BW(hipEventCreate(&e0));
+  KW_BW(hipEventCreate(&e1));
+  const dim3 grid(static_cast<unsigned>(ctx->cu_count) * 16u), block(256);
+  hipLaunchKernelGGL(k_stream_copy, grid, block, 0, ctx->stream, src, dst, n4); // untimed first pass
+  KW_BW(hipEventRecord(e0, ctx->stream));
+  for (int i = 0; i < reps; i++) hipLaunchKernelGGL(k_stream_copy, grid, block, 0, ctx->stream, src, dst, n4);
+  KW_BW(hipGetLastError());
+  KW_BW(hipEventRecord(e1, ctx->stream));
+  KW_BW(hipEventSynchronize(e1));
+  float ms = 0.0f;
+  KW_BW(hipEventElapsedTime(&ms, e0, e1));
+#undef KW_BW
+  *out_gbs = 2.0 * static_cast<double>(n4 * sizeof(float4)) * reps / (static_cast<double>(ms) * 1e-3) / 1e9;
+  cleanup();
+  return rc;
+}
+
 // ---- constants -----------------------------------------------------------------------------------------------------
 kw_status kw_set_constants(kw_ctx* ctx, const kw_constants* k)
 {

@@ -2,9 +2,12 @@
 
 New with this build (the reference is single-GPU, /root/reference/Readme.md:12-13).  Real-space arrays are split into
 Z-slabs; every 3-D FFT of the fused pipeline (csrc/kw_fused.hip) does x- and y-passes locally, one all-to-all transpose,
-the fused z-pass on `Ny/P` rows with all `Nz` planes, and the mirror image on the way back.  The all-to-all is
-`torch.distributed.all_to_all_single` — RCCL over xGMI on a GPU node (`backend="nccl"`), gloo through host staging when
-ranks share one GPU (tests) — handed to the C++ solver as a callback (`kw_exchange_fn`, include/kwave_hip.h).
+the fused z-pass on `Ny/P` rows with all `Nz` planes, and the mirror image on the way back.  Three transports:
+  "native"  the device library's own RCCL path (csrc/kw_comm.hip: ncclSend/ncclRecv groups on a communication stream,
+            events against the compute stream).  Python only hands over the communicator id — nothing of it runs in
+            the step loop.  The default on a GPU node.
+  "torch"   `torch.distributed.all_to_all_single` (backend nccl = RCCL) as a callback (`kw_exchange_fn`).
+  "host"    device -> pinned host -> gloo all-to-all -> device, for ranks that share one GPU (tests).
 
 partition_problem() cuts a global problem dict (HDF5 dataset names) into the slab of one rank:
   * 3-D arrays, pml_z, pml_z_sgz         -> planes z0 <= z < z1
@@ -94,9 +97,9 @@ class SlabExchange:
     """The all-to-all handed to the C++ solver.  nccl (= RCCL): device tensors allocated here double as the pipeline's
     scratch, so the collective runs in place on them.  gloo: device -> pinned host, all-to-all on CPU, host -> device."""
 
-    CB = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t)
-    CB_START = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int)
-    CB_WAIT = C.CFUNCTYPE(None, C.c_void_p, C.c_int)
+    CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t)
+    CB_START = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int)
+    CB_WAIT = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int)
 
     def __init__(self, nranks: int, device_index: int = 0):
         import torch
@@ -110,14 +113,28 @@ class SlabExchange:
         self.stream = None
         self._host: Dict[int, tuple] = {}
         self._view_cache: Dict[tuple, tuple] = {}
-        self.callback = self.CB(self._exchange)
+        self.error: Optional[BaseException] = None  # what a callback raised (ctypes cannot propagate it)
+        self.callback = self.CB(self._guard(self._exchange))
         self.calls = 0
         self.host_seconds = 0.0  # time the launching thread spent inside the split-phase callbacks (diagnostic)
         self.wait_seconds = 0.0  # ... of which in work.wait()
         # split-phase form (RCCL only): the transpose of one array is in flight while other arrays compute
         self.works: Dict[int, object] = {}
-        self.start_callback = self.CB_START(self._start) if self.backend == "nccl" else None
-        self.wait_callback = self.CB_WAIT(self._wait) if self.backend == "nccl" else None
+        self.start_callback = self.CB_START(self._guard(self._start)) if self.backend == "nccl" else None
+        self.wait_callback = self.CB_WAIT(self._guard(self._wait)) if self.backend == "nccl" else None
+
+    def _guard(self, fn):
+        """A callback returns 0 / non-zero to the C++ step loop (which then stops with KW_ERR_COMM instead of running
+        on with stale scratch data); the exception itself is kept for DistSolver to re-raise."""
+        def call(*args):
+            try:
+                fn(*args)
+                return 0
+            except BaseException as e:  # noqa: BLE001 - must not unwind through the C frames
+                if self.error is None:
+                    self.error = e
+                return 1
+        return call
 
     def alloc_scratch(self, nbytes: int):
         """Six device buffers (s[3], t[3]) as torch tensors; returns their addresses (for HostSolver(scratch=...))."""
@@ -172,7 +189,7 @@ class SlabExchange:
         if self.backend == "nccl":
             src, dst = self._views(send, recv, n)
             dist.all_to_all_single(dst, src)
-            return
+            return 0
         # gloo (ranks sharing one GPU, tests): stage through pinned host memory
         hip = capi.load()
         key = n
@@ -187,26 +204,65 @@ class SlabExchange:
 
 
 class DistSolver:
-    """One rank of a slab-decomposed simulation (wraps solver.HostSolver)."""
+    """One rank of a slab-decomposed simulation (wraps solver.HostSolver).
+
+    exchange: "native" | "torch" | "host" (module docstring); None picks "torch" for an nccl process group (kept for
+    the callback path's tests) and "host" otherwise.  "native" needs one GPU per rank (RCCL refuses two ranks on one
+    device) — or a single rank, which then exchanges with itself."""
 
     def __init__(self, pr_local: Dict[str, np.ndarray], rank: int, nranks: int, nz_global: int, device_index: int = 0,
-                 **opts):
+                 exchange: Optional[str] = None, **opts):
         from .solver import HostSolver
         import torch
+        import torch.distributed as dist
         self.rank, self.nranks = rank, nranks
-        self.exchange = SlabExchange(nranks, device_index)
+        backend = dist.get_backend() if (dist.is_available() and dist.is_initialized()) else None
+        if exchange is None:
+            exchange = "torch" if backend == "nccl" else "host"
+        if exchange not in ("native", "torch", "host"):
+            raise ValueError(f"unknown exchange {exchange!r}")
+        if exchange == "torch" and backend != "nccl":
+            raise ValueError("exchange='torch' needs an nccl (= RCCL) process group")
+        self.transport = exchange
         nx, ny, nzl = (_sc(pr_local[k]) for k in ("Nx", "Ny", "Nz"))
+        if exchange == "native":
+            # rank 0 draws the communicator id; it travels through the process group (any backend) as plain bytes
+            box = [capi.comm_unique_id() if rank == 0 else None]
+            if nranks > 1:
+                dist.broadcast_object_list(box, src=0)
+            self.exchange = None
+            self.sim = HostSolver(pr_local, slab_ranks=nranks, slab_rank=rank, nz_global=nz_global, comm_unique_id=box[0],
+                                  device_idx=device_index, **opts)
+            return
+        self.exchange = SlabExchange(nranks, device_index)
         scratch = None
-        if self.exchange.backend == "nccl":
+        if exchange == "torch":
             torch.cuda.set_device(device_index)
             pitch = (nx // 2 + 1 + 15) // 16 * 16
             scratch = self.exchange.alloc_scratch(pitch * ny * nzl * 8)
         self.sim = HostSolver(pr_local, slab_ranks=nranks, slab_rank=rank, nz_global=nz_global,
-                              exchange_fn=self.exchange.callback, exchange_start_fn=self.exchange.start_callback,
-                              exchange_wait_fn=self.exchange.wait_callback, scratch=scratch, device_idx=device_index,
-                              **opts)
-        stream = torch.cuda.Stream(device=device_index) if self.exchange.backend == "nccl" else None
+                              exchange_fn=self.exchange.callback,
+                              exchange_start_fn=self.exchange.start_callback if exchange == "torch" else None,
+                              exchange_wait_fn=self.exchange.wait_callback if exchange == "torch" else None,
+                              scratch=scratch, device_idx=device_index, **opts)
+        stream = torch.cuda.Stream(device=device_index) if exchange == "torch" else None
         self.exchange.bind(self.sim.ctx, stream)
+
+    @property
+    def exchanges(self) -> int:
+        """all-to-all exchanges started so far"""
+        return capi.comm_exchanges(self.sim.ctx) if self.exchange is None else self.exchange.calls
+
+    def run(self, n_steps: int):
+        try:
+            self.sim.run(n_steps)
+        except capi.KWaveError as e:
+            if self.exchange is not None and self.exchange.error is not None:
+                raise RuntimeError(f"slab exchange failed on rank {self.rank}: {self.exchange.error!r}") from e
+            raise
+
+    def step(self, n: int = 1):
+        self.run(n)
 
     def __getattr__(self, name):
         return getattr(self.sim, name)

@@ -97,6 +97,7 @@ class KSpaceFirstOrderSolver
   bool                  mPrepared = false;
   double                mPhaseTime[4] = {0.0, 0.0, 0.0, 0.0};
   bool                  mFused    = false;   // fused pipeline active for this grid
+  bool                  mOwnsComm = false;   // this solver gave the context its RCCL communicator (slab mode)
   bool                  mTermsFused = false; // pressure terms of this step already produced by the density stage
   bool                  mVelocityChained = false; // x-spectra of u handed over by the velocity stage this step
   bool mPressureFused = false;     // lossless: p of this step already produced by the density stage

@@ -23,6 +23,7 @@ def main():
     ap.add_argument("--mode", type=int, default=0)
     ap.add_argument("--backend", default="gloo")
     ap.add_argument("--medium", default="111", help="heterogeneous, nonlinear, absorbing as three 0/1 digits")
+    ap.add_argument("--exchange", default=None, help="native | torch | host (DistSolver's default when omitted)")
     ap.add_argument("--pml", type=int, default=4)
     ap.add_argument("--sensor", default="random")
     ap.add_argument("--per-rank", action="store_true",
@@ -39,14 +40,14 @@ def main():
                                 source_mode=a.mode, source_many=1, nt=a.steps, pml_size=a.pml, sensor=a.sensor, zslab=zslab)
     loc, info = partition_problem(pr, rank, P, arrays_are_local=a.per_rank)
     del pr
-    sim = DistSolver(loc, rank, P, nz, device_index=dev, p_raw=1, p_max=1)
+    sim = DistSolver(loc, rank, P, nz, device_index=dev, exchange=a.exchange, p_raw=1, p_max=1)
     sim.run(a.steps)
     sim.finish()
     fields = {k: sim.field(k) for k in ("p", "ux", "uz", "rhoy")}
     series = sim.stream("p") if info["sensor_positions"].size else np.zeros((a.steps, 0), dtype=np.float32)
     if a.per_rank:
         np.savez(f"{a.out}.rank{rank}.npz", series=series, pos=info["sensor_positions"],
-                 exchanges=np.array([sim.exchange.calls]), **fields)
+                 exchanges=np.array([sim.exchanges]), **fields)
         sim.close()
         dist.barrier()
         dist.destroy_process_group()
@@ -61,7 +62,7 @@ def main():
             if g["pos"].size:
                 full[:, g["pos"]] = g["series"]
         out["series"] = full
-        out["exchanges"] = np.array([sim.exchange.calls])
+        out["exchanges"] = np.array([sim.exchanges])
         np.savez(a.out, **out)
     sim.close()
     dist.barrier()

@@ -14,12 +14,14 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 TOL = 1e-5
 
 
-def run_ranks(world, dims, steps, source, mode, tmp_path, backend="gloo", medium="111"):
+def run_ranks(world, dims, steps, source, mode, tmp_path, backend="gloo", medium="111", exchange=None):
     out = str(tmp_path / f"dist_{world}_{source}_{mode}_{backend}_{medium}.npz")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
            "--master-addr", "127.0.0.1", "--master-port", str(29700 + world + 10 * mode),
            os.path.join(HERE, "dist_worker_gpu.py"), "--dims", *map(str, dims), "--steps", str(steps), "--source", source,
            "--mode", str(mode), "--backend", backend, "--medium", medium, "--out", out]
+    if exchange:
+        cmd += ["--exchange", exchange]
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600,
                        env=dict(os.environ, OMP_NUM_THREADS="4", HSA_ENABLE_IPC_MODE_LEGACY="0"))
     assert r.returncode == 0, r.stdout[-4000:]
@@ -54,12 +56,15 @@ def test_slab_ranks_match_oracle(orc, syn, tmp_path, world, dims, source, mode):
     o.close()
 
 
+@pytest.mark.parametrize("exchange", ["native", "torch"])
 @pytest.mark.parametrize("dims,source,mode", [((32, 32, 32), "p0", 0), ((64, 32, 16), "p_source", 2)])
-def test_slab_path_over_rccl_single_rank(orc, syn, tmp_path, dims, source, mode):
-    """backend nccl (= RCCL) with one rank: the slab code path exchanging with itself — device-resident scratch tensors,
-    all_to_all_single(async_op=True) / work.wait() on the solver's stream, split-phase pipelining — on real RCCL."""
+def test_slab_path_over_rccl_single_rank(orc, syn, tmp_path, dims, source, mode, exchange):
+    """One rank exchanging with itself over real RCCL.  native: the device library's own path (kw_comm_init; ncclSend /
+    ncclRecv groups on the communication stream, events against the compute stream; Python only supplies the id).
+    torch: the callback override — device-resident scratch tensors, all_to_all_single(async_op=True) / work.wait()."""
     steps = 20
-    res = run_ranks(1, dims, steps, source, mode, tmp_path, backend="nccl")
+    res = run_ranks(1, dims, steps, source, mode, tmp_path, backend="nccl" if exchange == "torch" else "gloo",
+                    exchange=exchange)
     nx, ny, nz = dims
     pr = syn.make_problem(nx, ny, nz, heterogeneous=True, nonlinear=True, absorbing=True, source=source,
                           source_mode=mode, source_many=1, nt=steps, pml_size=4, sensor="random")
@@ -160,7 +165,7 @@ def _full_size_reference(syn, orc, dims, steps):
 
 @pytest.mark.parametrize("world,backend,dims", [
     (2, "gloo", (512, 512, 512)),   # 2 ranks share the one GPU (host-staged all-to-all)
-    (1, "nccl", (512, 512, 512)),   # the RCCL path exchanging with itself
+    (1, "native", (512, 512, 512)), # the device library's RCCL path exchanging with itself
     (4, "gloo", (256, 512, 512)),   # 128 ky rows / 128 planes per rank: the 2 x 256 split y / z kernels with 4 peer chunks
 ])
 def test_config4_slab_at_full_size(orc, syn, tmp_path, world, backend, dims):
@@ -173,7 +178,7 @@ def test_config4_slab_at_full_size(orc, syn, tmp_path, world, backend, dims):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
            "--master-addr", "127.0.0.1", "--master-port", str(29790 + world),
            os.path.join(HERE, "dist_worker_gpu.py"), "--dims", *map(str, dims), "--steps", str(steps), "--source", "p0",
-           "--backend", backend, "--pml", "10", "--per-rank", "--out", out]
+           "--backend", "gloo", "--pml", "10", "--per-rank", "--out", out] + (["--exchange", "native"] if backend == "native" else [])
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900,
                        env=dict(os.environ, OMP_NUM_THREADS="4", HSA_ENABLE_IPC_MODE_LEGACY="0"))
     assert r.returncode == 0, r.stdout[-4000:]
@@ -189,3 +194,32 @@ def test_config4_slab_at_full_size(orc, syn, tmp_path, world, backend, dims):
             series[:, q["pos"]] = q["series"]
     assert rel_l2(series, ref["series"]) < TOL
     assert all(int(q["exchanges"][0]) >= 13 * (steps - 1) for q in parts)
+
+
+def test_native_slab_driver_without_interpreter(syn, tmp_path):
+    """tests/native/slab_selftest.c — a C program, no Python in the process: input file -> one rank in Z-slab mode over
+    the device library's own RCCL exchange -> output file; against the single-GPU (non-slab) run of the same file."""
+    import kwave_amd  # noqa: F401
+    from kwave_amd import h5io
+    exe = os.path.join(os.path.dirname(h5io.H5_LIB_PATH), "slab_selftest")
+    if not (os.path.exists(h5io.H5_LIB_PATH) and os.path.exists(exe)):
+        pytest.skip("HDF5 component / native driver not built")
+    nt = 16
+    pr = syn.make_problem(64, 48, 32, heterogeneous=True, nonlinear=True, absorbing=True, source="p_source", source_mode=2,
+                          source_many=1, nt=nt, pml_size=4, sensor="random")
+    path_in, one, slab = (str(tmp_path / n) for n in ("in.h5", "one.h5", "slab.h5"))
+    h5io.write_input_file(pr, path_in)
+    flags = dict(p_raw=1, p_max=1, p_final=1, u_final=1)
+    fs = h5io.FileSolver(path_in, **flags)
+    fs.run(nt)
+    fs.finish()
+    fs.write_output(one)
+    fs.close()
+    r = subprocess.run([exe, path_in, slab], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300,
+                       env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
+    assert r.returncode == 0, r.stdout[-2000:]
+    words = r.stdout.split()
+    assert int(words[words.index("exchanges") + 1]) >= 13 * (nt - 1) and words[-1] == "1", r.stdout
+    for name in ("p", "p_max", "p_final", "ux_final", "uz_final"):
+        a, b = h5io.read_dataset(slab, name), h5io.read_dataset(one, name)
+        assert a.shape == b.shape and rel_l2(a, b) < TOL, name
