@@ -69,6 +69,32 @@ def build_hip(force: bool = False, verbose: bool = False) -> str:
     return HIP_LIB
 
 
+def build_hip_variant(name: str, extra_flags, only_length: int = 256) -> str:
+    """Tuning build of the device library into ab/<name>/libkwave_hip.so (tools/ab.sh compares such builds on one GPU
+    box): the fused pipeline restricted to one line length (compiles in seconds) plus extra compiler flags."""
+    out_dir = os.path.join(ROOT, "ab", name)
+    os.makedirs(out_dir, exist_ok=True)
+    srcs = sorted(glob.glob(os.path.join(CSRC, "*.hip")))
+    units = [(s, tu) for s in srcs for tu in ((0, 1, 2) if os.path.basename(s) == "kw_fused.hip" else (None,))]
+    jobs, objs = [], []
+    for s, tu in units:
+        o = os.path.join(out_dir, os.path.basename(s) + (".o" if not tu else f".tu{tu}.o"))
+        cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-fno-slp-vectorize"]
+        cmd += list(extra_flags) + ([f"-DKW_FUSED_ONLY={only_length}"] if only_length else [])
+        cmd += ([f"-DKW_FUSED_TU={tu}"] if tu else []) + ["-I" + INCLUDE, "-I" + CSRC, "-I" + os.path.join(ROOT, "include"),
+                                                          "-I" + os.path.join(ROCM, "include"), "-c", s, "-o", o]
+        jobs.append(cmd)
+        objs.append(o)
+    with concurrent.futures.ThreadPoolExecutor(max_workers=6) as pool:
+        list(pool.map(_run, jobs))
+    lib = os.path.join(out_dir, "libkwave_hip.so")
+    _run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs +
+         ["-L" + os.path.join(ROCM, "lib"), "-lrocfft", "-Wl,-rpath," + os.path.join(ROCM, "lib")])
+    for o in objs:
+        os.remove(o)
+    return lib
+
+
 def build_host(force: bool = False) -> str:
     srcs = sorted(glob.glob(os.path.join(HOST, "*.cpp")))
     if not srcs:
@@ -128,5 +154,8 @@ def build_all(force: bool = False, verbose: bool = False):
 
 
 if __name__ == "__main__":
+    if len(sys.argv) > 2 and sys.argv[1] == "--variant":  # build.py --variant <name> [flags...]
+        print("built:", build_hip_variant(sys.argv[2], sys.argv[3:]))
+        sys.exit(0)
     build_all(force="--force" in sys.argv, verbose="--verbose" in sys.argv)
     print("built:", HIP_LIB, HOST_LIB if os.path.exists(HOST_LIB) else "")

@@ -103,6 +103,36 @@ __device__ __forceinline__ float  ldop(const float* p) { return *p; }
 #endif
 #define LDOP(p) ldop(p) // reduced real operators (kappa, nabla): one or two reads per step each (+2.6 % measured)
 
+// Reduced operators are stored for the z-pass that consumes them: [ky][kx tile of 16][q][j][c][V] — thread (c, j) of the
+// block owning that tile finds the values of ITS bins (kz = j + R1*k2, k2 = q*V + r; 2 x 256 split lines: kz = 2j + h +
+// 2*R1*k2 with run index 2*k2 + h) as RUN / V vectors of V floats, and the 64 lanes of a wave read one contiguous
+// 64 * V * 4-byte piece per load instruction.  V = 4 when the per-thread run length allows, else 2 or 1 (V = 1 is
+// plain [kz][c] order).  KW_OPVEC=0 forces V = 1 (A/B).
+#ifndef KW_OPVEC
+#define KW_OPVEC 1
+#endif
+constexpr int op_vec(int run) { return !KW_OPVEC ? 1 : (run % 4 == 0) ? 4 : (run % 2 == 0) ? 2 : 1; }
+template<int RUN, int R1> __device__ __forceinline__ void load_op_run(float (&dst)[RUN], const float* __restrict__ op, uint32_t base)
+{ // base: index (in floats) of vector q = 0 of this thread; consecutive q are R1 * 16 vectors apart
+  constexpr int V = op_vec(RUN);
+  typedef float vf __attribute__((ext_vector_type(V)));
+#pragma unroll
+  for (int q = 0; q < RUN / V; q++)
+  {
+    if constexpr (V == 1) dst[q] = LDOP(op + base + static_cast<uint32_t>(q * R1 * NLMAX));
+    else
+    {
+#ifndef KW_TEMPORAL_STATE
+      const vf t = __builtin_nontemporal_load(reinterpret_cast<const vf*>(op + base + static_cast<uint32_t>(q * R1 * NLMAX * V)));
+#else
+      const vf t = *reinterpret_cast<const vf*>(op + base + static_cast<uint32_t>(q * R1 * NLMAX * V));
+#endif
+#pragma unroll
+      for (int r = 0; r < V; r++) dst[q * V + r] = t[r];
+    }
+  }
+}
+
 
 // ---- register-level steps -------------------------------------------------------------------------------------------
 // Fill the block's twiddle table from the global one (tw[m] = exp(-2*pi*i*m/L)); the caller's next lds_barrier()
@@ -152,7 +182,7 @@ struct PassArgs
   float2*       out[3];
   const float2* tw;
   uint32_t      nxc, P;
-  uint32_t      PX;   // row pitch of the packed (exchange) side: rows travel without their padding
+  uint32_t      PX;   // row pitch of the packed (exchange) side (= P unless rows travel without their padding)
   uint32_t      narr; // arrays per block (grid.z * narr arrays in the launch)
   uint32_t      z0;   // first plane of this launch (chunked plane-local passes)
   const float2* mul[3]; // per array: optional factor mul[ky] applied to the line before its transform (ddy of the gradient)
@@ -266,13 +296,24 @@ struct ZArgs
 };
 
 // inverse along the line, started from the step-B register layout (thread (c,k1) holds X[k1 + R1*k2]); result:
-// thread (c,q1) holds x[q1 + R2*q2], q2 < R1 — returned in v
-template<int L>
+// thread (c,q1) holds x[q1 + R2*q2], q2 < R1 — returned in v.
+// The exchange runs the forward one backwards over the same cells: in the forward transform thread n2 writes the cells
+// (k1, n2) for all k1 ("its column") and thread k1 reads (k1, n2) for all n2 ("its row"); here thread k1 writes its row
+// — cells nobody else has read — and thread q1 reads its column.  A thread therefore only ever overwrites what it read
+// last itself: no barrier is needed between the forward read and this write, nor between this read and the next
+// forward write (KW_ZSYM=0 restores the q1-major layout with its two extra barriers, for A/B).
+#ifndef KW_ZSYM
+#define KW_ZSYM 1
+#endif
+// COLWRITE (square factorisations only, used by the 2 x 256 split kernels): the transposed cell assignment — thread k1
+// writes its column and thread q1 reads its row — for an exchange that follows one whose read was by columns.
+template<int L, bool COLWRITE = false>
 __device__ __forceinline__ void inverse_from_regs(float2 (&w)[Fac<L>::R2], float2 (&v)[Fac<L>::R1], float2* lds, int c,
                                                   int j, const float2* twl)
 {
   using G = Geo<L>;
   constexpr int R1 = G::R1, R2 = G::R2;
+  static_assert(!COLWRITE || R1 == R2, "transposed exchange needs a square factorisation");
   if (ACT(R1, j))
   {
     Dft<R2, kInv>::run(w);
@@ -280,14 +321,17 @@ __device__ __forceinline__ void inverse_from_regs(float2 (&w)[Fac<L>::R2], float
     for (int q1 = 0; q1 < R2; q1++)
     {
       const float2 t = (q1 == 0) ? w[0] : apply_tw<kInv>(w[q1], twl[j * G::TP + q1]);
-      lds[q1 * G::SI + j * G::NL + c] = t;
+      if (COLWRITE) lds[q1 * G::SF + j * G::NL + c] = t;
+      else if (KW_ZSYM) lds[j * G::SF + q1 * G::NL + c] = t;
+      else lds[q1 * G::SI + j * G::NL + c] = t;
     }
   }
   lds_barrier();
   if (ACT(R2, j))
   {
 #pragma unroll
-    for (int k1 = 0; k1 < R1; k1++) v[k1] = lds[j * G::SI + k1 * G::NL + c];
+    for (int k1 = 0; k1 < R1; k1++)
+      v[k1] = COLWRITE ? lds[j * G::SF + k1 * G::NL + c] : KW_ZSYM ? lds[k1 * G::SF + j * G::NL + c] : lds[j * G::SI + k1 * G::NL + c];
     Dft<R1, kInv>::run(v);
   }
 }
@@ -314,7 +358,8 @@ template<int L, int MODE> __global__ __launch_bounds__(Geo<L>::THREADS) void k_z
   const uint32_t basel  = ky * bstr + kxl;
   // operators live in a tile-blocked layout [ky][kx tile][kz][16]: the 16 x nz values of this block's tile are one
   // contiguous run (k_import_reduced), instead of 64-B pieces a whole plane apart
-  const uint32_t opbase = ((ky * (a.Pop / NLMAX) + kxl / NLMAX) * a.nz) * NLMAX + kxl % NLMAX, opzstr = NLMAX;
+  constexpr int  OPV    = op_vec(R2);
+  const uint32_t opbase = (((ky * (a.Pop / NLMAX) + kxl / NLMAX) * (R2 / OPV) * R1 + j) * NLMAX + kxl % NLMAX) * OPV;
   constexpr bool MULTI  = (MODE == Z_VGRAD || MODE == Z_ABSORB);
   const uint32_t arr0   = MULTI ? a.arr0 : 0;
   const uint32_t narr   = MULTI ? a.narr : 1;
@@ -333,9 +378,7 @@ template<int L, int MODE> __global__ __launch_bounds__(Geo<L>::THREADS) void k_z
   float kap[R2];
   if (MODE != Z_SHIFT && ACT(R1, j))
   {
-    const float* __restrict__ op = a.op[(MODE == Z_ABSORB) ? arr0 : 0];
-#pragma unroll
-    for (int k2 = 0; k2 < R2; k2++) kap[k2] = LDOP(op + opbase + static_cast<uint32_t>(j + R1 * k2) * opzstr);
+    load_op_run<R2, R1>(kap, a.op[(MODE == Z_ABSORB) ? arr0 : 0], opbase);
   }
   lds_barrier(); // twiddle table visible (the loads above stay in flight across it)
 
@@ -386,14 +429,12 @@ template<int L, int MODE> __global__ __launch_bounds__(Geo<L>::THREADS) void k_z
       }
       if (MODE == Z_ABSORB && ia + 1 < narr)
       {
-        const float* __restrict__ op = a.op[arr + 1];
-        uint32_t lb = opbase + static_cast<uint32_t>(j) * opzstr;
+        uint32_t lb = opbase;
         asm volatile("" : "+v"(lb));
-#pragma unroll
-        for (int k2 = 0; k2 < R2; k2++) kap[k2] = LDOP(op + lb + static_cast<uint32_t>(R1 * k2) * opzstr);
+        load_op_run<R2, R1>(kap, a.op[arr + 1], lb);
       }
     }
-    lds_barrier(); // forward exchange buffer is free again
+    if (!KW_ZSYM) lds_barrier(); // forward exchange buffer is free again
 
 #pragma unroll 1
     for (int o = 0; o < NOUT; o++)
@@ -439,7 +480,9 @@ template<int L, int MODE> __global__ __launch_bounds__(Geo<L>::THREADS) void k_z
 #pragma unroll
         for (int q2 = 0; q2 < R1; q2++) out[ob + static_cast<uint32_t>(R2 * q2) * zstr] = r[q2];
       }
-      if (o + 1 < NOUT || ia + 1 < narr) lds_barrier(); // exchange buffer reused by the next output / array
+      // the next output's inverse writes rows while other threads may still read their columns: barrier; the next
+      // array's forward transform writes the column this thread has just read: none
+      if (o + 1 < NOUT || (!KW_ZSYM && ia + 1 < narr)) lds_barrier();
     }
   }
 }
@@ -466,18 +509,22 @@ template<int L> __device__ __forceinline__ void load_twiddles_split(float2* twl,
 }
 
 // H-point transform of the step-A registers v (thread (c, n2 = j) holds x[n1*R2 + j]); thread (c, k1 = j) ends with
-// X[j + R1*k2] in w.  The exchange buffer must be free on entry; the caller puts a barrier before its next use.
-template<int H, int DIR>
+// X[j + R1*k2] in w.  Default cell assignment: the thread writes its column of the exchange buffer and reads its row;
+// ROWWRITE: the transposed one (writes its row, reads its column) — for a transform that follows an exchange whose
+// read was by rows, so that every thread overwrites only what it read itself and no barrier is needed in between
+// (see inverse_from_regs).  Otherwise the buffer must be free on entry.
+template<int H, int DIR, bool ROWWRITE = false>
 __device__ __forceinline__ void line_fft(float2 (&v)[Fac<H>::R1], float2 (&w)[Fac<H>::R2], float2* lds, int c, int j,
                                          const float2* twl)
 {
   using G = Geo<H>;
+  static_assert(!ROWWRITE || G::R1 == G::R2, "transposed exchange needs a square factorisation");
   step_a<H, DIR>(v, j, twl);
 #pragma unroll
-  for (int k1 = 0; k1 < G::R1; k1++) lds[k1 * G::SF + j * G::NL + c] = v[k1];
+  for (int k1 = 0; k1 < G::R1; k1++) lds[ROWWRITE ? j * G::SF + k1 * G::NL + c : k1 * G::SF + j * G::NL + c] = v[k1];
   lds_barrier();
 #pragma unroll
-  for (int n2 = 0; n2 < G::R2; n2++) w[n2] = lds[j * G::SF + n2 * G::NL + c];
+  for (int n2 = 0; n2 < G::R2; n2++) w[n2] = lds[ROWWRITE ? n2 * G::SF + j * G::NL + c : j * G::SF + n2 * G::NL + c];
   Dft<G::R2, DIR>::run(w);
 }
 
@@ -534,8 +581,8 @@ __global__ __launch_bounds__(Geo<L / 2>::THREADS) void k_ypass_split(PassArgs a)
   }
   float2 wa[R2], wb[R2];
   line_fft<H, DIR>(va, wa, lds, c, j, twl);
-  lds_barrier();
-  line_fft<H, DIR>(vb, wb, lds, c, j, twl);
+  if (!KW_ZSYM) lds_barrier();
+  line_fft<H, DIR, KW_ZSYM != 0>(vb, wb, lds, c, j, twl); // writes the rows the first transform just read: no barrier
   if (valid)
   {
     if (POUT)
@@ -583,7 +630,8 @@ template<int L, int MODE> __global__ __launch_bounds__(Geo<L / 2>::THREADS) void
   const uint32_t basel  = ky * a.P + kxl;
   // operators live in a tile-blocked layout [ky][kx tile][kz][16]: the 16 x nz values of this block's tile are one
   // contiguous run (k_import_reduced), instead of 64-B pieces a whole plane apart
-  const uint32_t opbase = ((ky * (a.Pop / NLMAX) + kxl / NLMAX) * a.nz) * NLMAX + kxl % NLMAX, opzstr = NLMAX;
+  constexpr int  OPV    = op_vec(2 * R2); // run of this thread: bins 2*(j + R1*k2) + h at run index 2*k2 + h
+  const uint32_t opbase = (((ky * (a.Pop / NLMAX) + kxl / NLMAX) * (2 * R2 / OPV) * R1 + j) * NLMAX + kxl % NLMAX) * OPV;
   constexpr bool MULTI  = (MODE == Z_VGRAD || MODE == Z_ABSORB);
   const uint32_t arr    = MULTI ? a.arr0 + blockIdx.z : 0;
   // PGRAD: the x- and y-gradients share one z-inverse — ddx(kx), ddy(ky) do not depend on kz, so they are applied after
@@ -609,19 +657,21 @@ template<int L, int MODE> __global__ __launch_bounds__(Geo<L / 2>::THREADS) void
       va[n1] = cadd(lo, hi);
       vb[n1] = apply_tw<kFwd>(csub(lo, hi), tw2[n1 * R2 + j]);
     }
+    // four exchanges per line and output (two forward, two inverse halves), each writing exactly the cells its thread
+    // read in the one before (column / row / column / row ...): the only barriers left are the ones inside them
     line_fft<H, kFwd>(va, Xa, lds, c, j, twl);
-    lds_barrier();
-    line_fft<H, kFwd>(vb, Xb, lds, c, j, twl);
-    lds_barrier(); // exchange buffer free for the inverse transforms
+    if (!KW_ZSYM) lds_barrier();
+    line_fft<H, kFwd, KW_ZSYM != 0>(vb, Xb, lds, c, j, twl);
+    if (!KW_ZSYM) lds_barrier(); // exchange buffer free for the inverse transforms
   }
   { // spectral operator (see k_zfused for the reference lines), kz = 2*(j + R1*k2) (+1)
-    const float* __restrict__ op = a.op[(MODE == Z_ABSORB) ? arr : 0];
-    const uint32_t lb = opbase + static_cast<uint32_t>(2 * j) * opzstr;
+    float run[2 * R2];
+    load_op_run<2 * R2, R1>(run, a.op[(MODE == Z_ABSORB) ? arr : 0], opbase);
 #pragma unroll
     for (int k2 = 0; k2 < R2; k2++)
     {
-      float sa = LDOP(op + lb + static_cast<uint32_t>(2 * R1 * k2) * opzstr);
-      float sb = LDOP(op + lb + static_cast<uint32_t>(2 * R1 * k2 + 1) * opzstr);
+      float sa = run[2 * k2];
+      float sb = run[2 * k2 + 1];
       if (MODE == Z_VGRAD || MODE == Z_SOURCE) { sa *= a.divider; sb *= a.divider; }
       Xa[k2] = make_float2(Xa[k2].x * sa, Xa[k2].y * sa);
       Xb[k2] = make_float2(Xb[k2].x * sb, Xb[k2].y * sb);
@@ -662,9 +712,9 @@ template<int L, int MODE> __global__ __launch_bounds__(Geo<L / 2>::THREADS) void
 #pragma unroll
         for (int k2 = 0; k2 < R2; k2++) w[k2] = half ? Xb[k2] : Xa[k2];
       }
-      if (half == 0) inverse_from_regs<H>(w, ra, lds, c, j, twl);
-      else inverse_from_regs<H>(w, rb, lds, c, j, twl);
-      if (half == 0 || o + 1 < NOUT) lds_barrier(); // exchange buffer reused by the next half / output
+      if (half == 0) inverse_from_regs<H, KW_ZSYM != 0>(w, ra, lds, c, j, twl); // after a read by columns: write columns
+      else inverse_from_regs<H>(w, rb, lds, c, j, twl);                          // after a read by rows: write rows
+      if (!KW_ZSYM && (half == 0 || o + 1 < NOUT)) lds_barrier(); // exchange buffer reused by the next half / output
     }
     if (valid)
     {
@@ -1279,21 +1329,25 @@ template<int L> __global__ __launch_bounds__(Geo<L>::THREADS) void k_xshift(Xshi
   }
 }
 
-// import of a reduced real operator into the pipeline's tile-blocked layout: dst[ky][kx tile][kz][16] <- src[kz][ky][nxc]
+// import of a reduced real operator into the layout the z-pass reads (see load_op_run):
+// dst[ky][kx tile][q][j][c][V] <- src[kz][ky][nxc], kz = j + r1*(q*V + r)  (split lines: 2j + h + 2*r1*k2, run index 2*k2 + h)
 // (rows = nyl local ky, nzg planes: the transposed operators of slab mode have the same form)
 __global__ void k_import_reduced(float* __restrict__ dst, const float* __restrict__ src, uint32_t nxc, uint32_t P,
-                                 uint32_t nyl, uint32_t nzg, size_t total)
+                                 uint32_t nyl, uint32_t nzg, size_t total, uint32_t r1, uint32_t vec, uint32_t split)
 {
-  const uint32_t nt = P / NLMAX;
+  const uint32_t nt = P / NLMAX, nq = nzg / (r1 * vec);
   for (size_t e = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x; e < total;
        e += static_cast<size_t>(gridDim.x) * blockDim.x)
   {
-    const uint32_t c  = static_cast<uint32_t>(e % NLMAX);
-    size_t         r  = e / NLMAX;
-    const uint32_t kz = static_cast<uint32_t>(r % nzg);
-    r /= nzg;
+    size_t         r  = e;
+    const uint32_t r4 = static_cast<uint32_t>(r % vec); r /= vec;
+    const uint32_t c  = static_cast<uint32_t>(r % NLMAX); r /= NLMAX;
+    const uint32_t j  = static_cast<uint32_t>(r % r1); r /= r1;
+    const uint32_t q  = static_cast<uint32_t>(r % nq); r /= nq;
     const uint32_t t  = static_cast<uint32_t>(r % nt);
     const uint32_t ky = static_cast<uint32_t>(r / nt);
+    const uint32_t ri = q * vec + r4; // position in the thread's run
+    const uint32_t kz = split ? 2u * j + (ri & 1u) + 2u * r1 * (ri >> 1) : j + r1 * ri;
     const uint32_t kx = t * NLMAX + c;
     dst[e] = (kx < nxc) ? src[(static_cast<size_t>(kz) * nyl + ky) * nxc + kx] : 0.f;
   }
@@ -1436,9 +1490,13 @@ template<int L> __global__ __launch_bounds__(Geo<L>::THREADS) void k_probe_xinv(
 // ---- host side ------------------------------------------------------------------------------------------------------
 // line lengths with a two-factor register decomposition L = R1 * R2, R1, R2 in {4 ... 32} with at most one odd prime
 // power (3, 9, 27, 5, 25) each: 2^m, 3 * 2^m, 9 * 2^m, 27 * 2^m, 81 * 4, 5 * 2^m, 15 * 2^m, 25 * 2^m, 75 * 2^m, 125 * 4
+#ifdef KW_FUSED_ONLY /* tuning builds: one line length only (-DKW_FUSED_ONLY=256), compiles in seconds */
+#define KW_FUSED_LENGTHS(X) X(KW_FUSED_ONLY)
+#else
 #define KW_FUSED_LENGTHS(X) X(16) X(32) X(48) X(64) X(72) X(80) X(96) X(100) X(108) X(120) X(128) X(144) X(160) X(192)  \
   X(200) X(216) X(240) X(256) X(288) X(300) X(320) X(324) X(384) X(400) X(432) X(480) X(500) X(512) X(576) X(600) X(640) \
   X(648) X(768) X(1024)
+#endif
 bool supported_len(uint32_t n)
 {
 #define X(LEN) if (n == LEN) return true;
@@ -1557,7 +1615,7 @@ template<int MODE> kw_status launch_zfused(kw_ctx* ctx, int narr, ZArgs a)
   a.tw      = f.tw[2];
   a.divider = c.fft_divider;
   a.nxc     = c.nx_complex;
-  a.P       = f.slab ? f.PX : f.P; // slab mode: the z-pass works on the exchanged (unpadded) rows in place
+  a.P       = f.slab ? f.PX : f.P; // slab mode: the z-pass works on the exchanged rows in place
   a.Pop     = f.P;
   a.ny      = f.nyl;
   a.nz      = f.nz_global;
@@ -1781,7 +1839,15 @@ kw_status create_impl(kw_ctx* ctx, void* const s[3], void* const t[3])
   f.nz_global = (f.slab) ? slab.nz_global : c.nz;
   f.nyl       = c.ny / f.nranks;
   f.P         = (c.nx_complex + NLMAX - 1) / NLMAX * NLMAX;
-  f.PX        = f.slab ? c.nx_complex : f.P; // exchange buffers carry rows without their padding (-10 % wire bytes)
+  // Exchange-side row pitch.  Default: the padded pitch — every 16-column tile segment of the packed y-passes and of the
+  // transposed z-pass is one aligned 128-B line.  KW_SLAB_UNPADDED=1 sends rows without their padding (nx/2+1 complex:
+  // -10 % wire bytes at 256, -5.5 % at 512) at the price of tile segments that straddle two lines: measured on one
+  // rank at 256^3 the z-pass then takes 67 us per array instead of 30 and the packed y-passes 35-42 us instead of 23-27
+  // (profiles/r02_statsslab_*), i.e. +0.45 ms of local time per step for 0.2 ms less on the wire at 8 GPUs / 512^3.
+  {
+    const char* e = getenv("KW_SLAB_UNPADDED");
+    f.PX = (f.slab && e != nullptr && e[0] != '0') ? c.nx_complex : f.P;
+  }
   KW_TRY(alloc_scratch(ctx, s, t));
   const uint32_t lens[3] = { c.nx, c.ny, f.nz_global };
   for (int i = 0; i < 3; i++)
@@ -1958,8 +2024,20 @@ kw_status kw_fused_import_reduced(kw_ctx* ctx, float* dst_padded, const float* s
   KW_REQUIRE(dst_padded && src);
   const kw_constants& c = ctx->c;
   const size_t total = static_cast<size_t>(c.ny) * c.nz * ctx->fused.P;
+  // factorisation of the z lines, as the z-pass kernels are instantiated
+  const bool split = (ctx->fused.nz_global == 512 && ctx->fused.split512);
+  uint32_t r1 = Fac<256>::R1, r2 = Fac<256>::R2; // the split lines are built on the 256-point transform
+  if (!split)
+    switch (ctx->fused.nz_global)
+    {
+#define X(LEN) case LEN: r1 = Fac<LEN>::R1; r2 = Fac<LEN>::R2; break;
+      KW_FUSED_LENGTHS(X)
+#undef X
+      default: kw_set_error("kw_fused_import_reduced: unsupported length %u", ctx->fused.nz_global); return KW_ERR_INVALID;
+    }
+  const uint32_t vec = static_cast<uint32_t>(op_vec(static_cast<int>(split ? 2 * r2 : r2)));
   LAUNCH(k_import_reduced, dim3(ctx->cu_count * 8), dim3(256), dst_padded, src, c.nx_complex, ctx->fused.P,
-         ctx->fused.nyl, ctx->fused.nz_global, total);
+         ctx->fused.nyl, ctx->fused.nz_global, total, r1, vec, split ? 1u : 0u);
   return KW_OK;
 }
 

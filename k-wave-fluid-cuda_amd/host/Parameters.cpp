@@ -46,6 +46,10 @@ void Parameters::init(const InputProvider& in, const Options& options)
 
   in.readScalarValue(kNtName, mNt);
   if (mOptions.benchmarkTimeStepCount > 0) mNt = mOptions.benchmarkTimeStepCount; // Parameters.cpp:130-133
+  // Parameters.cpp:135-139: sampling must start inside the run ("-s 0" arrives here as 0 - 1, i.e. wrapped around)
+  if (mOptions.samplingStartTimeIndex > mNt)
+    throw std::invalid_argument("Error: The beginning of data sampling is out of the simulation time span <1, " +
+                                std::to_string(mNt) + ">.");
   in.readScalarValue(kDtName, mDt);
   in.readScalarValue(kDxName, mDx);
   in.readScalarValue(kDyName, mDy);

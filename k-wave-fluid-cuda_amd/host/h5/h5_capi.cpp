@@ -182,8 +182,11 @@ void kwh_checkpoint_write_impl(kwh_solver* s, const std::string& path)
 {
   const Parameters& params = Parameters::getInstance();
   s->solver->prepare();
+  // written beside the target and renamed over it once complete: a run killed while checkpointing (the situation
+  // --checkpoint_interval exists for) keeps its previous restart point instead of a truncated file
+  const std::string partial = path + ".partial";
   Hdf5File f;
-  f.create(path);
+  f.create(partial);
   f.writeHeader("checkpoint", "k-Wave checkpoint written by kspaceFirstOrder-HIP");
   const DimensionSizes dims = params.getFullDimensionSizes();
   f.writeScalarValue(kTimeIndexName, params.getTimeIndex());
@@ -207,6 +210,8 @@ void kwh_checkpoint_write_impl(kwh_solver* s, const std::string& path)
       f.writeMatrix("stream_" + name, DimensionSizes(state.size(), 1, 1), state.data(), Hdf5File::MatrixDomainType::kReal);
   }
   f.close();
+  if (std::rename(partial.c_str(), path.c_str()) != 0)
+    throw std::runtime_error("cannot move the finished checkpoint " + partial + " to " + path);
 }
 
 void kwh_checkpoint_read_impl(kwh_solver* s, const std::string& path)
@@ -234,7 +239,10 @@ void kwh_checkpoint_read_impl(kwh_solver* s, const std::string& path)
   for (const std::string& name : streams.names(true))
   {
     size_t steps = 0;
-    f.readCompleteDataset("stream_" + name + "_steps", 1, &steps);
+    if (!f.datasetExists("stream_" + name + "_steps"))
+      throw std::invalid_argument(path + " holds no state for the output stream \"" + name + "\": checkpoints of this build carry "
+                                  "their streams inside the checkpoint file (datasets stream_<name>), the reference's "
+                                  "kspaceFirstOrder-CUDA keeps them in the output file - the two cannot resume each other's runs");
     std::vector<float> state;
     if (f.datasetExists("stream_" + name))
     {

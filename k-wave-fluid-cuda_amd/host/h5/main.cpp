@@ -2,6 +2,7 @@
 // Mirrors the sequence of the reference's main() (main.cpp:840-966) and the subset of its flags that select what
 // the loop computes and stores (CommandLineParameters.cpp:264-292); cosmetics (usage box, progress table) are out of scope.
 #include <algorithm>
+#include <cerrno>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -31,6 +32,33 @@ static void usage()
               "      --block_size <n>.  Not available: --post, --40-bit_complex\n");
 }
 
+// numeric command-line values: anything but a plain non-negative number is an error (the reference's getopt loop
+// rejects them the same way, CommandLineParameters.cpp:300-420)
+static unsigned long long parseCount(const char* flag, const char* text)
+{
+  char* end = nullptr;
+  errno = 0;
+  const unsigned long long v = std::strtoull(text, &end, 10);
+  if (text[0] == '-' || text[0] == '\0' || end == text || *end != '\0' || errno != 0)
+  {
+    std::fprintf(stderr, "Error: %s needs a non-negative integer, got \"%s\"\n", flag, text);
+    std::exit(EXIT_FAILURE);
+  }
+  return v;
+}
+static double parseReal(const char* flag, const char* text)
+{
+  char* end = nullptr;
+  errno = 0;
+  const double v = std::strtod(text, &end);
+  if (text[0] == '\0' || end == text || *end != '\0' || errno != 0 || !(v >= 0.0))
+  {
+    std::fprintf(stderr, "Error: %s needs a non-negative number, got \"%s\"\n", flag, text);
+    std::exit(EXIT_FAILURE);
+  }
+  return v;
+}
+
 int main(int argc, char** argv)
 {
   std::string in, out, ckpt;
@@ -48,9 +76,14 @@ int main(int argc, char** argv)
     auto next = [&]() -> const char* { if (i + 1 >= argc) { usage(); std::exit(EXIT_FAILURE); } return argv[++i]; };
     if (a == "-i") in = next();
     else if (a == "-o") out = next();
-    else if (a == "-g") o.device_idx = std::atoi(next());
-    else if (a == "-s") o.sampling_start_time_index = std::strtoull(next(), nullptr, 10) - 1; // 1-based on the CLI (:416-425)
-    else if (a == "--benchmark") o.benchmark_time_steps = std::strtoull(next(), nullptr, 10);
+    else if (a == "-g") o.device_idx = static_cast<int32_t>(parseCount("-g", next()));
+    else if (a == "-s")
+    { // 1-based on the CLI (:416-425); 0 is rejected here, a start beyond Nt by Parameters::init once Nt is known
+      const unsigned long long v = parseCount("-s", next());
+      if (v < 1) { std::fprintf(stderr, "Error: The beginning of data sampling is out of the simulation time span <1, Nt>.\n"); return EXIT_FAILURE; }
+      o.sampling_start_time_index = v - 1;
+    }
+    else if (a == "--benchmark") o.benchmark_time_steps = parseCount("--benchmark", next());
     else if (a == "-p" || a == "--p_raw") o.p_raw = 1;
     else if (a == "--p_rms") o.p_rms = 1;
     else if (a == "--p_max") o.p_max = 1;
@@ -71,19 +104,19 @@ int main(int argc, char** argv)
     else if (a == "--I_avg_c") o.i_avg_c = 1;
     else if (a == "--I_avg") o.i_avg = 1;
     else if (a == "--u_c") o.u_c = 1;
-    else if (a == "--frequency") o.frequency = std::strtof(next(), nullptr);
+    else if (a == "--frequency") o.frequency = static_cast<float>(parseReal("--frequency", next()));
     else if (a == "--Q_term") o.q_term = 1;
     else if (a == "--Q_term_c") o.q_term_c = 1;
-    else if (a == "--period") o.period = std::strtof(next(), nullptr);
-    else if (a == "--mos") o.mos = std::strtoull(next(), nullptr, 10);
-    else if (a == "--harmonics") o.harmonics = std::strtoull(next(), nullptr, 10);
+    else if (a == "--period") o.period = static_cast<float>(parseReal("--period", next()));
+    else if (a == "--mos") o.mos = parseCount("--mos", next());
+    else if (a == "--harmonics") o.harmonics = parseCount("--harmonics", next());
     else if (a == "--no_overlap") o.no_overlap = 1;
     else if (a == "--granular") o.fused_kernels = 0;
-    else if (a == "-c") compressionLevel = static_cast<unsigned>(std::strtoul(next(), nullptr, 10));
+    else if (a == "-c") compressionLevel = static_cast<unsigned>(parseCount("-c", next()));
     else if (a == "--copy_sensor_mask") copySensorMask = true;
     else if (a == "--checkpoint_file") ckpt = next();
-    else if (a == "--checkpoint_timesteps") ckptSteps = std::strtoull(next(), nullptr, 10);
-    else if (a == "--checkpoint_interval") ckptSeconds = std::strtod(next(), nullptr);
+    else if (a == "--checkpoint_timesteps") ckptSteps = parseCount("--checkpoint_timesteps", next());
+    else if (a == "--checkpoint_interval") ckptSeconds = parseReal("--checkpoint_interval", next());
     else if (a == "--version") { std::printf("%s\n", KSpaceFirstOrderSolver().getCodeName().c_str()); return EXIT_SUCCESS; }
     else if (a == "-r" || a == "-t" || a == "--verbose" || a == "--block_size") (void)next(); // progress / threads / log level / host block: nothing to set here
     else if (a == "--post" || a == "--40-bit_complex")

@@ -61,6 +61,8 @@ def main(argv=None) -> int:
         raise SystemExit("run_slab: corner (cuboid) sensor masks are not supported in slab mode")
     loc, info = partition_problem(pr, rank, world, arrays_are_local=True)
     opts = {f: 1 for f in STREAM_FLAGS if getattr(a, f)}
+    if a.start < 1:
+        raise SystemExit("Error: The beginning of data sampling is out of the simulation time span <1, Nt>.")
     sim = DistSolver(loc, rank, world, nz, device_index=dev, sampling_start=a.start - 1, benchmark_steps=a.benchmark, **opts)
     nt = a.benchmark or int(np.asarray(pr["Nt"]).ravel()[0])
     sim.run(nt)

@@ -229,3 +229,47 @@ def closed_form_pressure(pr: Dict[str, np.ndarray], n_steps: int) -> np.ndarray:
     p0 = np.asarray(pr["p0_source_input"], dtype=np.float64)
     spec = np.fft.rfftn(p0, axes=(0, 1, 2)) * np.cos(c * k * n_steps * dt)
     return np.fft.irfftn(spec, s=(nz, ny, nx), axes=(0, 1, 2))
+
+
+def absorbing_mode_recurrence(pr: Dict[str, np.ndarray], n_steps: int):
+    """K8: homogeneous *absorbing* linear medium (scalar c0, rho0, alpha_coeff), PML == 1 (periodic box), p0 source only.
+
+    Every operator of the step is then diagonal in k-space, so the whole scheme closes per Fourier mode on three
+    scalars — p^, R^ = sum_i rho_i^ and S^ = sum_i ddk_i^- kappa u_i^ — independently of any FFT code, field kernel or
+    generator loop of the restatements:
+        S <- S + (dt/rho0) kappa^2 |k|^2 p          (A2-A4 then A6-A7: sum_i ddk_i^+ ddk_i^- = -|k|^2 by construction)
+        R <- R - dt rho0 S                           (A9, linear)
+        p <- c^2 ( R (1 - eta nabla2) + tau nabla1 rho0 S )          (A11 absorbing linear, SolverCudaKernels.cu:1978)
+    starting after step 0 from  p = p0^, R = p0^/c^2, S = -(dt / 2 rho0) kappa^2 |k|^2 p0^   (A12: u = +dt/(2 rho0) grad p0).
+    kappa = sinc(c_ref dt |k| / 2), nabla1 = |k|^(y-2), nabla2 = |k|^(y-1) (0 at k = 0), tau = -2 a c0^(y-1),
+    eta = 2 a c0^y tan(pi y / 2), a = alpha_coeff * 100 (1e-6 / 2 pi)^y / (20 log10 e)  (KSpaceFirstOrderSolver.cpp:2514-2643).
+    Returns (p, ux) in fp64 after step n_steps; ux from u_x^ <- u_x^ - (dt/rho0) ddx^+ kappa p^ alongside.
+    """
+    nx, ny, nz = (int(_sc(pr[k])) for k in ("Nx", "Ny", "Nz"))
+    dx, dy, dz = (_sc(pr[k]) for k in ("dx", "dy", "dz"))
+    c0, rho0, dt, c_ref = _sc(pr["c0"]), _sc(pr["rho0"]), _sc(pr["dt"]), _sc(pr["c_ref"])
+    y, alpha = _sc(pr["alpha_power"]), _sc(pr["alpha_coeff"])
+    kx = 2.0 * math.pi * np.fft.rfftfreq(nx, dx)
+    ky = 2.0 * math.pi * np.fft.fftfreq(ny, dy)
+    kz = 2.0 * math.pi * np.fft.fftfreq(nz, dz)
+    k2 = (kz ** 2).reshape(-1, 1, 1) + (ky ** 2).reshape(1, -1, 1) + (kx ** 2).reshape(1, 1, -1)
+    k = np.sqrt(k2)
+    kappa = np.sinc(c_ref * dt * k / 2.0 / math.pi)  # np.sinc(x) = sin(pi x) / (pi x)
+    with np.errstate(divide="ignore"):
+        nabla1 = np.where(k > 0, k ** (y - 2.0), 0.0)
+    nabla2 = np.where(k > 0, k ** (y - 1.0), 0.0)
+    a_np = alpha * 100.0 * (1.0e-6 / (2.0 * math.pi)) ** y / (20.0 * math.log10(math.e))
+    tau = -2.0 * a_np * c0 ** (y - 1.0)
+    eta = 2.0 * a_np * c0 ** y * math.tan(math.pi * y / 2.0)
+    ddx_pos = (1j * kx * np.exp(1j * kx * dx / 2.0)).reshape(1, 1, -1)
+    p0 = np.fft.rfftn(np.asarray(pr["p0_source_input"], dtype=np.float64), axes=(0, 1, 2))
+    g = (dt / rho0) * kappa ** 2 * k2
+    p, R, S = p0.copy(), p0 / c0 ** 2, -0.5 * g * p0
+    ux = 0.5 * (dt / rho0) * ddx_pos * kappa * p0
+    for _ in range(n_steps):
+        ux = ux - (dt / rho0) * ddx_pos * kappa * p
+        S = S + g * p
+        R = R - dt * rho0 * S
+        p = c0 ** 2 * (R * (1.0 - eta * nabla2) + tau * nabla1 * rho0 * S)
+    back = lambda a: np.fft.irfftn(a, s=(nz, ny, nx), axes=(0, 1, 2))
+    return back(p), back(ux)

@@ -198,6 +198,19 @@ def test_k1_closed_form_on_gpu(syn):
     g.close()
 
 
+def test_k8_absorbing_mode_recurrence_on_gpu(syn):
+    """K8 on the GPU: the homogeneous absorbing linear medium against the fp64 per-mode recurrence (oracle-free pin of
+    kappa / nabla1 / nabla2 / tau / eta and of the absorbing pressure sum), fused pipeline and rocFFT path."""
+    from oracle.kwave_np import absorbing_mode_recurrence
+    pr = syn.make_problem(64, heterogeneous=False, nonlinear=False, absorbing=True, pml_off=True, source="p0", nt=110)
+    p, ux = absorbing_mode_recurrence(pr, 100)
+    for fused in (True, False):
+        g = make_gpu(pr, fused_kernels=fused)
+        g.run(101)
+        assert rel_l2(g.field("p"), p) < TOL and rel_l2(g.field("ux"), ux) < TOL, fused
+        g.close()
+
+
 def test_sensor_streams_bit_exact_and_delayed_flush(orc, syn):
     """p_raw / p_max / p_min / p_rms streams: raw samples equal the field at the mask bit-for-bit; aggregates equal the
     oracle's reduce operators applied to the GPU's own raw series bit-for-bit."""

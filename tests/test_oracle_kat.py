@@ -27,6 +27,27 @@ def test_k1_closed_form_config1(orc, k1):
     o.close()
 
 
+def test_k8_absorbing_mode_recurrence(orc, syn):
+    """K8: homogeneous absorbing linear medium in a periodic box — the scheme closes per Fourier mode on (p^, sum rho^,
+    div u^), iterated in fp64 without any of the restatements' FFT / kernel / generator code: pins kappa, nabla1,
+    nabla2, tau, eta and the absorbing branch of the pressure sum (SolverCudaKernels.cu:1724-1742, 1812-1820,
+    1966-1980; generators KSpaceFirstOrderSolver.cpp:2514-2643).  The absorption itself moves p by 1.6e-2 here."""
+    from oracle.kwave_np import absorbing_mode_recurrence
+    pr = syn.make_problem(64, heterogeneous=False, nonlinear=False, absorbing=True, pml_off=True, source="p0", nt=110)
+    o = orc.OracleSim(pr)
+    o.step(1)
+    for n in (10, 100):
+        o.step(n - (o.t - 1))
+        p, ux = absorbing_mode_recurrence(pr, n)
+        assert rel_l2(o.field("p"), p) < 1e-5 and rel_l2(o.field("ux"), ux) < 1e-5, n
+    assert rel_l2(p, closed_form_pressure(pr, 100)) > 1e-3  # a lossless run would not pass
+    s = NumpySim(syn.make_problem(32, heterogeneous=False, nonlinear=False, absorbing=True, pml_off=True, source="p0"))
+    for _ in range(41):
+        s.step()
+    assert rel_l2(s.p, absorbing_mode_recurrence(s.pr, 40)[0]) < 1e-6
+    o.close()
+
+
 def test_k1_numpy_fp64_closed_form(k1, syn):
     pr = syn.make_problem(32, heterogeneous=False, nonlinear=False, absorbing=False, pml_off=True, source="p0")
     s = NumpySim(pr)

@@ -1,0 +1,18 @@
+#!/bin/bash
+# tools/abk.sh [bench args]: per-kernel A/B of the device-library builds in ab/<name>/ (build.py --variant) on ONE GPU
+# box, two interleaved repetitions; prints steps/s and the kernel table (ms per launch) of every run.
+L=k-wave-fluid-cuda_amd/lib
+cp $L/libkwave_hip.so /tmp/libkwave_hip.keep
+for rep in 1 2; do
+  for d in ab/*/; do
+    v=$(basename $d)
+    cp ab/$v/libkwave_hip.so $L/
+    python bench.py --no-cpu --no-512 "$@" > gpurun_out/abk_${v}_${rep}.json 2> gpurun_out/abk_${v}_${rep}.err || { echo "$v FAILED"; tail -3 gpurun_out/abk_${v}_${rep}.err; continue; }
+    python - <<PY
+import json
+d=json.load(open("gpurun_out/abk_${v}_${rep}.json"))
+print("$v", "$rep", d["value"], {k.replace("k_",""): round(1e3*x["avg_ms"],1) for k,x in sorted(d["roofline"]["kernels"].items())})
+PY
+  done
+done
+cp /tmp/libkwave_hip.keep $L/libkwave_hip.so
