@@ -116,6 +116,7 @@ def build_host_h5(force: bool = False) -> str:
     if not os.path.exists(os.path.join(HDF5_ROOT, "include", "hdf5.h")):
         return ""
     srcs = sorted(glob.glob(os.path.join(HOST, "*.cpp"))) + [os.path.join(HOST, "h5", "Hdf5File.cpp"),
+                                                               os.path.join(HOST, "h5", "SeriesWriter.cpp"),
                                                                os.path.join(HOST, "h5", "h5_capi.cpp")]
     deps = srcs + glob.glob(os.path.join(HOST, "*.h")) + glob.glob(os.path.join(HOST, "h5", "*"))
     common = ["-O2", "-std=c++17", "-fPIC", "-fopenmp", "-I" + INCLUDE, "-I" + HOST, "-I" + os.path.join(HDF5_ROOT, "include")]

@@ -10,7 +10,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
-from typing import Dict
+from typing import Dict, Optional
 
 import numpy as np
 
@@ -54,6 +54,14 @@ def _h5check(rc: int):
         raise capi.KWaveError(load_h5().kwh_last_error().decode(errors="replace"))
 
 
+VECTOR_AXIS = {"ddx_k_shift_pos_r": "x", "ddx_k_shift_neg_r": "x", "x_shift_neg_r": "x", "pml_x": "x", "pml_x_sgx": "x",
+               "dxudxn": "x", "dxudxn_sgx": "x",
+               "ddy_k_shift_pos": "y", "ddy_k_shift_neg": "y", "y_shift_neg_r": "y", "pml_y": "y", "pml_y_sgy": "y",
+               "dyudyn": "y", "dyudyn_sgy": "y",
+               "ddz_k_shift_pos": "z", "ddz_k_shift_neg": "z", "z_shift_neg_r": "z", "pml_z": "z", "pml_z_sgz": "z",
+               "dzudzn": "z", "dzudzn_sgz": "z"}
+
+
 def write_input_file(pr: Dict[str, np.ndarray], path: str) -> None:
     """Write a problem dict (HDF5 dataset names, 1-based indices) as a k-Wave input file."""
     L = load_h5()
@@ -65,8 +73,12 @@ def write_input_file(pr: Dict[str, np.ndarray], path: str) -> None:
         keep.append(arr)
         is_c = name in COMPLEX_DATASETS
         shp = list(arr.shape)
-        if is_c:  # (n, 2) pairs -> (x = 2n, 1, 1) / (2, n) like the file format's doubled fastest dimension
-            shp = [shp[0] * 2] if name.startswith(("ddx", "x_shift")) else [shp[0], 2]
+        # 1-D operators / PML / grid-derivative vectors keep their axis in the file, as k-Wave writes them: an x vector is
+        # (n,1,1), a y vector (1,n,1), a z vector (1,1,n) in (x,y,z) order; complex ones double the fastest (x) dimension
+        axis = VECTOR_AXIS.get(name)
+        if axis is not None:
+            n = arr.size // (2 if is_c else 1)
+            shp = {"x": [1, 1, n * (2 if is_c else 1)], "y": [1, n, 2 if is_c else 1], "z": [n, 1, 2 if is_c else 1]}[axis]
         shp = shp[::-1]
         while len(shp) < 3:
             shp.append(1)
@@ -188,9 +200,14 @@ def read_numeric_attribute(path: str, dataset: str, attr: str) -> float:
 
 
 class FileSolver(HostSolver):
-    """HostSolver created from a k-Wave HDF5 input file instead of in-memory datasets."""
+    """HostSolver created from a k-Wave HDF5 input file instead of in-memory datasets.
 
-    def __init__(self, path: str, **opts):
+    output=path opens the output file before the first step: every stored time series is appended to it step by step
+    (the reference's per-step hyperslab writes) instead of being kept in host memory; write_output(path) completes it.
+    reopen_output=True continues the output file of a checkpointed run (then call read_checkpoint)."""
+
+    def __init__(self, path: str, output: Optional[str] = None, compression_level: int = 0, reopen_output: bool = False,
+                 **opts):
         L = load_h5()
         self._keep = []
         o = Options()
@@ -219,6 +236,10 @@ class FileSolver(HostSolver):
         L.kwh_stream_read.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_uint64]
         for fn in ("kwh_destroy", "kwh_finish", "kwh_sync"):
             getattr(L, fn).argtypes = [C.c_void_p]
+        self.output = output
+        if output is not None:
+            L.kwh_open_output_file.argtypes = [C.c_void_p, C.c_char_p, C.c_uint32, C.c_int32]
+            _h5check(L.kwh_open_output_file(self._h, output.encode(), compression_level, int(reopen_output)))
 
     def write_output(self, path: str, compression_level: int = 0, copy_sensor_mask: bool = False):
         _h5check(self.L.kwh_write_output_file_ex(self._h, path.encode(), compression_level, int(copy_sensor_mask)))

@@ -13,6 +13,10 @@ struct kwh_solver
   MemoryInput                             input;       // datasets handed over in memory (kwh_create)
   std::unique_ptr<InputProvider>          file_input;  // or an input file (kwh_create_from_file)
   std::unique_ptr<KSpaceFirstOrderSolver> solver;
+  // HDF5 component: the writer behind kwh_open_output_file (h5/SeriesWriter.h), kept type-erased because this header is
+  // shared with the HDF5-free library; must go before the solver (its sinks live in the solver's streams)
+  std::shared_ptr<void>                   series_writer;
+  ~kwh_solver() { series_writer.reset(); }
 };
 
 void kwh_set_error(const std::string& e);

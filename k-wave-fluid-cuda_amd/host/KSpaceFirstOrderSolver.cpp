@@ -331,6 +331,7 @@ void KSpaceFirstOrderSolver::computeAverageIntensities()
   if (ps == nullptr) throw std::runtime_error("computeAverageIntensities: the raw pressure stream is missing");
   const size_t steps = ps->sampledSteps(), points = ps->size();
   if (steps < 2 || points == 0) return; // nothing stored (sampling never started): the intensities stay zero
+  ps->loadSeries(); // series streamed to the output file come back from there (the reference re-reads its datasets too, :1331-1370)
 
   // phase factors of the half-step shift (:1253-1260)
   using FloatComplex = std::complex<float>;
@@ -363,12 +364,16 @@ void KSpaceFirstOrderSolver::computeAverageIntensities()
       BaseOutputStream* us = mOutputStreamContainer.get(ui[a]);
       auto* is = dynamic_cast<PostProcessedOutputStream*>(mOutputStreamContainer.get(ii[a]));
       if (us == nullptr || is == nullptr) throw std::runtime_error("computeAverageIntensities: stream missing");
+      if (first == 0) us->loadSeries();
       upload(us->dataset(), first, n, dU.f());
       kwCheck(kw_time_shift_series(ctx, dU.f(), dShift.f(), steps, n));
       kwCheck(kw_intensity_avg(ctx, dI.f(), dP.f(), dU.f(), steps, n));
       kwCheck(kw_memcpy_d2h(ctx, is->data().data() + first, dI.f(), n * sizeof(float)));
     }
   }
+  ps->releaseSeries();
+  for (int a = 0; a < 3; a++)
+    if (BaseOutputStream* us = mOutputStreamContainer.get(ui[a])) us->releaseSeries();
 }
 
 void KSpaceFirstOrderSolver::computeQTerm(OutputStreamContainer::OutputStreamIdx intensityX,

@@ -107,6 +107,19 @@ void BaseOutputStream::freeMemory()
   }
 }
 
+void BaseOutputStream::storeRow(const float* row)
+{
+  if (mSink) mSink->append(row, mSize);
+  else mDataset.insert(mDataset.end(), row, row + mSize);
+}
+
+void BaseOutputStream::loadSeries()
+{
+  if (!mSink || !isSeries()) return;
+  mSink->flush();
+  mSink->read(mDataset, mFlushedSteps);
+}
+
 void BaseOutputStream::copyAggregateFromDevice()
 {
   mDataset.resize(mSize);
@@ -131,7 +144,8 @@ void BaseOutputStream::checkpointState(std::vector<float>& state, size_t& sample
   if (mReduceOp == ReduceOperator::kNone)
   {
     while (mFlushedSteps < mSampledSteps) flushRaw(); // the step sampled last is still in its pinned buffer
-    state = mDataset;
+    if (mSink) { mSink->flush(); state.clear(); }     // the series is in the output file (as in the reference)
+    else state = mDataset;
   }
   else
   { // accumulator as it stands (RMS: sum of squares, scaled only in postProcess)
@@ -147,8 +161,16 @@ void BaseOutputStream::restoreState(const float* state, size_t n, size_t sampled
     throw std::runtime_error("checkpointing of compression streams (" + mName + ") is not implemented");
   if (mReduceOp == ReduceOperator::kNone)
   {
-    if (n != sampledSteps * mSize) throw std::invalid_argument("checkpoint of stream " + mName + " has the wrong size");
-    mDataset.assign(state, state + n);
+    if (mSink)
+    { // rows 0 .. sampledSteps-1 are in the re-opened output file
+      if (n != 0) throw std::invalid_argument("checkpoint of stream " + mName + " carries a series but the output file is streamed");
+      mSink->setRows(sampledSteps);
+    }
+    else
+    {
+      if (n != sampledSteps * mSize) throw std::invalid_argument("checkpoint of stream " + mName + " has the wrong size");
+      mDataset.assign(state, state + n);
+    }
     mSampledSteps = mFlushedSteps = sampledSteps;
   }
   else
@@ -199,7 +221,7 @@ void IndexOutputStream::flushRaw()
   if (mReduceOp != ReduceOperator::kNone || mFlushedSteps >= mSampledSteps) return;
   const int b = mFlushedSteps & 1;
   kwCheck(kw_event_synchronize(ctx(), mEvent[b])); // IndexOutputStream.cpp:354
-  mDataset.insert(mDataset.end(), mPinned[b], mPinned[b] + mSize);
+  storeRow(mPinned[b]);
   mFlushedSteps++;
 }
 
@@ -252,7 +274,7 @@ void CompressedIndexOutputStream::postSample2()
 {
   if (mCurrent == nullptr) return;
   kwCheck(kw_memcpy_d2h(ctx(), mFrameHost.data(), mCurrent, mSize * sizeof(float)));
-  mDataset.insert(mDataset.end(), mFrameHost.begin(), mFrameHost.end());
+  storeRow(mFrameHost.data());
   mFlushedSteps++;
   mCompressedTimeStep++;
   if (mSavingFlag) kwCheck(kw_memset(ctx(), mCurrent, 0, mSize * sizeof(float))); // BaseOutputStream.cpp:117-132
@@ -261,7 +283,8 @@ void CompressedIndexOutputStream::postSample2()
 
 void CompressedIndexOutputStream::checkpointState(std::vector<float>& state, size_t& sampledSteps)
 { // taken between steps: the frame finished by the last sampled step has already been emitted (postSample2)
-  state = mDataset;
+  if (mSink) { mSink->flush(); state.clear(); } // frames so far are in the output file
+  else state = mDataset;
   const size_t frames = state.size();
   const int    nacc   = (mC2 == mC1) ? 1 : 2;
   state.resize(frames + nacc * mSize);
@@ -275,8 +298,17 @@ void CompressedIndexOutputStream::restoreState(const float* state, size_t n, siz
   if (n < nacc * mSize || (n - nacc * mSize) % mSize != 0)
     throw std::invalid_argument("checkpoint of stream " + mName + " has the wrong size");
   const size_t frames = n - nacc * mSize;
-  mDataset.assign(state, state + frames);
-  mCompressedTimeStep = mFlushedSteps = frames / mSize;
+  if (mSink)
+  { // the number of frames in the re-opened output file follows from the sampled steps (one per oSize steps)
+    if (frames != 0) throw std::invalid_argument("checkpoint of stream " + mName + " carries frames but the output file is streamed");
+    mCompressedTimeStep = mFlushedSteps = sampledSteps / CompressHelper::getInstance().getOSize();
+    mSink->setRows(mCompressedTimeStep);
+  }
+  else
+  {
+    mDataset.assign(state, state + frames);
+    mCompressedTimeStep = mFlushedSteps = frames / mSize;
+  }
   kwCheck(kw_memcpy_h2d(ctx(), mC1, state + frames, mSize * sizeof(float)));
   if (nacc == 2) kwCheck(kw_memcpy_h2d(ctx(), mC2, state + frames + mSize, mSize * sizeof(float)));
   mSampledSteps = sampledSteps;
@@ -346,7 +378,7 @@ void CuboidOutputStream::flushRaw()
   if (mReduceOp != ReduceOperator::kNone || mFlushedSteps >= mSampledSteps) return;
   const int b = mFlushedSteps & 1;
   kwCheck(kw_event_synchronize(ctx(), mEvent[b]));
-  mDataset.insert(mDataset.end(), mPinned[b], mPinned[b] + mSize);
+  storeRow(mPinned[b]);
   mFlushedSteps++;
 }
 

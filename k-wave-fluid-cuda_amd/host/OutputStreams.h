@@ -28,6 +28,19 @@ void sampleAll(ReduceOperator op, float* samplingBuffer, const float* sourceData
 void postProcessingRms(float* samplingBuffer, float scalingCoeff, size_t nSamples);
 } // namespace OutputStreamsHipKernels
 
+/// Where the rows of a stored time series go.  Without a sink a series stream keeps its rows in memory (dataset());
+/// the HDF5 component installs sinks that append every row to the output file as it is flushed (h5/SeriesWriter.h),
+/// which is what the reference's streams do with their own dataset (IndexOutputStream.cpp:348-372).
+class SeriesSink
+{
+ public:
+  virtual ~SeriesSink() = default;
+  virtual void append(const float* row, size_t floats) = 0;       ///< next row; may return before it is on disk
+  virtual void flush() = 0;                                        ///< every appended row is in the file on return
+  virtual void read(std::vector<float>& out, size_t rows) = 0;    ///< rows [0, rows) back from the file
+  virtual void setRows(size_t rows) = 0;                           ///< restart: `rows` rows are in the file already
+};
+
 class BaseOutputStream
 {
  public:
@@ -42,8 +55,14 @@ class BaseOutputStream
   virtual void close() {}
   const std::string& name() const { return mName; }
   ReduceOperator     reduceOp() const { return mReduceOp; }
-  /// stored dataset: raw = [sampledSteps][mSize]; aggregated = [mSize] (valid after postProcess)
+  /// stored dataset: raw = [sampledSteps][mSize]; aggregated = [mSize] (valid after postProcess).  A series that goes
+  /// to a sink is not held here: loadSeries() reads it back for the few users that need all of it (I_avg, stream_read)
   const std::vector<float>& dataset() const { return mDataset; }
+  bool isSeries() const { return mReduceOp == ReduceOperator::kNone || mReduceOp == ReduceOperator::kC; }
+  void attachSink(std::unique_ptr<SeriesSink> sink) { mSink = std::move(sink); std::vector<float>().swap(mDataset); }
+  bool hasSink() const { return static_cast<bool>(mSink); }
+  void loadSeries();
+  void releaseSeries() { if (mSink) std::vector<float>().swap(mDataset); }
   size_t size() const { return mSize; }
   size_t sampledSteps() const { return mFlushedSteps; }
   /// stream that only feeds another one (the reference's doNotSaveFlag, e.g. I_avg behind --Q_term): not listed, not written
@@ -58,6 +77,7 @@ class BaseOutputStream
  protected:
   void allocateMemory();
   void freeMemory();
+  void storeRow(const float* row); ///< one flushed row of a series: to the sink, else appended to the in-memory dataset
   void copyAggregateFromDevice();
   OutputStreamsHipKernels::ReduceOperator kernelOp() const;
 
@@ -72,6 +92,7 @@ class BaseOutputStream
   void*             mEvent[2]     = {nullptr, nullptr};
   size_t            mSampledSteps = 0, mFlushedSteps = 0;
   std::vector<float> mDataset;
+  std::unique_ptr<SeriesSink> mSink;
 };
 
 class IndexOutputStream : public BaseOutputStream

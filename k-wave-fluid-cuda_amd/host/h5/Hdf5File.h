@@ -30,6 +30,7 @@ class Hdf5File
   void create(const std::string& fileName);                       // Hdf5File.cpp:97-118 (truncate)
   void open(const std::string& fileName, bool readOnly = true);   // :126-146
   bool isOpen() const { return mFile >= 0; }
+  hid_t handle() const { return mFile; }
   void close();
   bool datasetExists(const std::string& name) const;
   DimensionSizes getDatasetDimensionSizes(const std::string& name) const; // returned as (x,y,z) = HDF5 dims reversed

@@ -14,6 +14,7 @@
 #include "../HostSolverHandle.h"
 #include "../MatrixNames.h"
 #include "Hdf5File.h"
+#include "SeriesWriter.h"
 
 #define KWH_TRY try {
 #define KWH_CATCH                                                                                                      \
@@ -23,12 +24,93 @@
   catch (...) { kwh_set_error("unknown exception"); return 1; }                                                        \
   return 0;
 
+static Hdf5SeriesWriter* seriesWriter(kwh_solver* s) { return static_cast<Hdf5SeriesWriter*>(s->series_writer.get()); }
+
+// what a reader needs to expand compression coefficients again (IndexOutputStream.cpp:146-157)
+static void writeCompressionAttributes(Hdf5File& out, const std::string& name, const CompressedIndexOutputStream& cs)
+{
+  const CompressHelper& ch = CompressHelper::getInstance();
+  out.writeLongLongAttribute(name, "c_harmonics", static_cast<long long>(ch.getHarmonics()));
+  out.writeStringAttribute(name, "c_type", "c");
+  out.writeFloatAttribute(name, "c_period", ch.getPeriod());
+  out.writeLongLongAttribute(name, "c_mos", static_cast<long long>(ch.getMos()));
+  out.writeLongLongAttribute(name, "c_shift", cs.shiftedBasis() ? 1 : 0);
+  out.writeFloatAttribute(name, "c_complex_size", 2.0f);
+  out.writeLongLongAttribute(name, "c_max_exp", cs.shiftedBasis() ? CompressHelper::kMaxExpU : CompressHelper::kMaxExpP);
+}
+
+// Per-step output (IndexOutputStream.cpp:87-160 create, :348-372 flushRaw; CuboidOutputStream.cpp:95-140, :656-722): the
+// output file exists from the start of the run, every stored series owns its dataset(s) in it and appends a hyperslab
+// per sampled step (compression streams: per finished frame) through the writer thread of h5/SeriesWriter.h.
+// reopen: continue the output file of a checkpointed run (BaseOutputStream::reopen, e.g. IndexOutputStream.cpp:170-215)
+void kwh_open_output(kwh_solver* s, const std::string& path, unsigned compressionLevel, bool reopen)
+{
+  if (s->series_writer) throw std::runtime_error("the output file is open already");
+  const Parameters& params = Parameters::getInstance();
+  if (params.getTimeIndex() != 0 && !reopen) throw std::runtime_error("kwh_open_output_file: call it before the first time step");
+  auto writer = std::make_shared<Hdf5SeriesWriter>(path, compressionLevel, !reopen);
+  OutputStreamContainer& streams = s->solver->getOutputStreamContainer();
+  MatrixContainer& mc = s->solver->getMatrixContainer();
+  const bool cornersMask = mc.has(MatrixContainer::MatrixIdx::kSensorMaskCorners);
+  const size_t steps = (params.getNt() > params.getSamplingStartTimeIndex()) ? params.getNt() - params.getSamplingStartTimeIndex() : 0;
+  for (const std::string& name : streams.names())
+  {
+    BaseOutputStream* st = streams.find(name);
+    if (!st->isSeries()) continue;
+    auto* cs = dynamic_cast<CompressedIndexOutputStream*>(st);
+    // rows of the dataset: every sampled step, or every finished frame (IndexOutputStream.cpp:108-117)
+    const size_t rows = cs ? std::max<size_t>(steps / CompressHelper::getInstance().getOSize(), 1) : steps;
+    std::vector<Hdf5SeriesWriter::Part> parts;
+    if (cornersMask && cs == nullptr)
+    {
+      const IndexMatrix& corners = mc.getMatrix<IndexMatrix>(MatrixContainer::MatrixIdx::kSensorMaskCorners);
+      writer->drain();
+      if (!reopen) writer->file().createGroup(name);
+      size_t offset = 0;
+      for (size_t c = 0; c < corners.getDimensionSizes().ny; c++)
+      {
+        const DimensionSizes a = corners.getTopLeftCorner(c), b = corners.getBottomRightCorner(c);
+        Hdf5SeriesWriter::Part p;
+        p.name   = name + "/" + std::to_string(c + 1);
+        p.dims   = DimensionSizes(b.nx - a.nx + 1, b.ny - a.ny + 1, b.nz - a.nz + 1, rows);
+        p.offset = offset;
+        p.n      = corners.getSizeOfCuboid(c);
+        offset += p.n;
+        parts.push_back(p);
+      }
+    }
+    else
+    {
+      Hdf5SeriesWriter::Part p;
+      p.name = name;
+      p.dims = DimensionSizes(st->size(), rows, 1);
+      p.n    = st->size();
+      parts.push_back(p);
+    }
+    if (rows == 0) continue; // sampling never starts: nothing to store
+    st->attachSink(writer->makeSink(parts, st->size(), rows));
+    if (cs && !reopen) writeCompressionAttributes(writer->file(), name, *cs);
+  }
+  s->series_writer = writer;
+}
+
 void kwh_write_output(kwh_solver* s, const std::string& path, unsigned compressionLevel, bool copySensorMask)
 {
   const Parameters& params = Parameters::getInstance();
-  Hdf5File out;
-  out.create(path);
-  out.setOutputLayout(true, compressionLevel); // chunked like the reference's output; -c N deflate level
+  Hdf5File fresh;
+  Hdf5SeriesWriter* writer = seriesWriter(s);
+  if (writer != nullptr)
+  { // the file has been open since the start of the run and holds the series already: complete it
+    if (writer->path() != path) throw std::invalid_argument("the output is being streamed to " + writer->path() + ", it cannot be written to " + path);
+    writer->finish();
+    compressionLevel = writer->compressionLevel();
+  }
+  else
+  {
+    fresh.create(path);
+    fresh.setOutputLayout(true, compressionLevel); // chunked like the reference's output; -c N deflate level
+  }
+  Hdf5File& out = writer ? writer->file() : fresh;
   out.writeHeader("output", "k-Wave output written by kspaceFirstOrder-HIP");
   { // the rest of the output header (Hdf5FileHeader.cpp:78-87, :340-384): host, cores, memory, phase times as strings
     char host[256] = "unknown";
@@ -102,6 +184,7 @@ void kwh_write_output(kwh_solver* s, const std::string& path, unsigned compressi
     BaseOutputStream* st = streams.find(name);
     const bool series = st->reduceOp() == BaseOutputStream::ReduceOperator::kNone ||
                         st->reduceOp() == BaseOutputStream::ReduceOperator::kC;
+    if (series && st->hasSink()) continue; // streamed: in the file since the step it was sampled at
     DimensionSizes d(st->size(), series ? st->sampledSteps() : 1, 1);
     if (!series && st->size() == dims.nElements()) d = dims;
     if (st->dataset().size() != d.nElements()) continue; // nothing sampled yet
@@ -128,17 +211,7 @@ void kwh_write_output(kwh_solver* s, const std::string& path, unsigned compressi
       continue;
     }
     out.writeMatrix(name, d, st->dataset().data(), Hdf5File::MatrixDomainType::kReal);
-    if (auto* cs = dynamic_cast<CompressedIndexOutputStream*>(st))
-    { // what a reader needs to expand the coefficients again (IndexOutputStream.cpp:146-157)
-      const CompressHelper& ch = CompressHelper::getInstance();
-      out.writeLongLongAttribute(name, "c_harmonics", static_cast<long long>(ch.getHarmonics()));
-      out.writeStringAttribute(name, "c_type", "c");
-      out.writeFloatAttribute(name, "c_period", ch.getPeriod());
-      out.writeLongLongAttribute(name, "c_mos", static_cast<long long>(ch.getMos()));
-      out.writeLongLongAttribute(name, "c_shift", cs->shiftedBasis() ? 1 : 0);
-      out.writeFloatAttribute(name, "c_complex_size", 2.0f);
-      out.writeLongLongAttribute(name, "c_max_exp", cs->shiftedBasis() ? CompressHelper::kMaxExpU : CompressHelper::kMaxExpP);
-    }
+    if (auto* cs = dynamic_cast<CompressedIndexOutputStream*>(st)) writeCompressionAttributes(out, name, *cs);
   }
   auto writeFinal = [&](MatrixContainer::MatrixIdx idx, const std::string& name) {
     RealMatrix& m = s->solver->getMatrixContainer().getMatrix<RealMatrix>(idx);
@@ -169,6 +242,7 @@ void kwh_write_output(kwh_solver* s, const std::string& path, unsigned compressi
     }
   }
   out.close();
+  s->series_writer.reset();
 }
 void kwh_write_output(kwh_solver* s, const std::string& path) { kwh_write_output(s, path, 0, false); }
 
@@ -384,6 +458,17 @@ KWH_API int kwh_write_output_file_ex(kwh_solver* s, const char* path, uint32_t c
   if (!s || !path) throw std::invalid_argument("kwh_write_output_file_ex: NULL argument");
   if (compression_level > 9) throw std::invalid_argument("compression level must be 0..9");
   kwh_write_output(s, path, compression_level, copy_sensor_mask != 0);
+  KWH_CATCH
+}
+
+/* Open the output file before the first step: every stored time series (raw and compressed streams) is then appended
+ * to it step by step instead of being held in host memory until the end; kwh_write_output_file(_ex) on the same path
+ * completes the file.  reopen != 0 continues the output file of a checkpointed run (call before kwh_checkpoint_read). */
+KWH_API int kwh_open_output_file(kwh_solver* s, const char* path, uint32_t compression_level, int32_t reopen)
+{
+  KWH_TRY
+  if (!s || !path) throw std::invalid_argument("kwh_open_output_file: NULL argument");
+  kwh_open_output(s, path, compression_level, reopen != 0);
   KWH_CATCH
 }
 

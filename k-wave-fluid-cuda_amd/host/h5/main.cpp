@@ -14,6 +14,7 @@
 #include "Hdf5File.h"
 
 void kwh_write_output(kwh_solver* s, const std::string& path, unsigned compressionLevel, bool copySensorMask);
+void kwh_open_output(kwh_solver* s, const std::string& path, unsigned compressionLevel, bool reopen);
 void kwh_checkpoint_write_impl(kwh_solver* s, const std::string& path);
 void kwh_checkpoint_read_impl(kwh_solver* s, const std::string& path);
 
@@ -135,11 +136,15 @@ int main(int argc, char** argv)
                 Parameters::getInstance().getHipParameters().getDeviceName().c_str());
     Parameters& params = Parameters::getInstance();
     const bool checkpointing = !ckpt.empty() && (ckptSteps > 0 || ckptSeconds > 0.0);
+    bool resuming = false;
+    if (checkpointing)
+      if (FILE* f = std::fopen(ckpt.c_str(), "rb")) { std::fclose(f); resuming = true; }
+    // the output file is open for the whole run: sampled series go to it step by step (OutputStreamContainer.cpp:380-403)
+    kwh_open_output(&s, out, compressionLevel, resuming);
     if (checkpointing)
     { // recover if a checkpoint exists (KSpaceFirstOrderSolver.cpp:186-228), run one leg, stop with a new checkpoint
-      if (FILE* f = std::fopen(ckpt.c_str(), "rb"))
+      if (resuming)
       {
-        std::fclose(f);
         kwh_checkpoint_read_impl(&s, ckpt);
         std::printf("recovered from %s at time step %zu\n", ckpt.c_str(), params.getTimeIndex());
       }

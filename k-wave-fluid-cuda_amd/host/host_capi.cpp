@@ -99,6 +99,7 @@ int kwh_destroy(kwh_solver* s)
   if (s)
   {
     if (s->solver) kw_sync(Parameters::getInstance().getHipParameters().getContext());
+    s->series_writer.reset(); // drains and closes the streamed output datasets while the streams still exist
     s->solver.reset();
     delete s;
   }
@@ -203,8 +204,10 @@ int kwh_stream_read(kwh_solver* s, const char* name, float* dst, uint64_t n)
   KWH_TRY
   BaseOutputStream* st = s->solver->getOutputStreamContainer().find(name);
   if (!st) throw std::invalid_argument(std::string("no output stream named ") + name);
+  st->loadSeries(); // a series streamed to the output file is read back from there
   if (st->dataset().size() != n) throw std::invalid_argument(std::string("size mismatch for stream ") + name);
   std::memcpy(dst, st->dataset().data(), n * sizeof(float));
+  st->releaseSeries();
   KWH_CATCH
 }
 

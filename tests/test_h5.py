@@ -210,3 +210,145 @@ def test_compression_datasets_carry_their_parameters(h5io, syn, tmp_path):
         assert h5io.read_numeric_attribute(path_out, name, "c_max_exp") == e
         assert h5io.read_numeric_attribute(path_out, name, "c_complex_size") == 2.0
         assert h5io.read_numeric_attribute(path_out, name, "c_period") == pytest.approx(period, rel=1e-6)
+
+
+# ---- independent look at the files (h5dump, not this repo's reader) ------------------------------------------------------
+def _h5dump():
+    import h5dump_util
+    if not h5dump_util.available():
+        pytest.skip("h5dump not found")
+    return h5dump_util
+
+
+def test_input_file_as_h5dump_sees_it(h5io, syn, tmp_path):
+    """What the reference's reader relies on (Hdf5File.cpp:59-68, 345-352, 767-815, 898-915, 1023-1034;
+    Hdf5FileHeader.cpp:62-87), checked with HDF5's own tool: F32LE / U64LE element types, 3-D dataspaces in (z, y, x)
+    order, scalars as (1,1,1), complex data with a doubled fastest dimension, fixed-length NUL-terminated ASCII string
+    attributes data_type / domain_type on every dataset and the six header attributes on the root group."""
+    u = _h5dump()
+    pr = syn.make_problem(16, 12, 8, nt=6, pml_size=2, source="p_source", source_many=1, sensor="random")
+    path = str(tmp_path / "in.h5")
+    h5io.write_input_file(pr, path)
+    d = u.describe(path)
+    assert u.check_kwave_conventions(d, "input") == []
+    ds = d["datasets"]
+    assert ds["/c0"]["dims"] == (8, 12, 16) and ds["/c0"]["datatype"] == "H5T_IEEE_F32LE"
+    assert ds["/Nx"]["dims"] == (1, 1, 1) and ds["/Nx"]["datatype"] == "H5T_STD_U64LE"
+    assert ds["/ddx_k_shift_pos_r"]["dims"] == (1, 1, 18) and ds["/ddx_k_shift_pos_r"]["attrs"]["domain_type"]["value"] == "complex"
+    assert ds["/ddz_k_shift_neg"]["dims"] == (8, 1, 2)
+    assert ds["/sensor_mask_index"]["attrs"]["data_type"]["value"] == "long"
+    assert ds["/p_source_input"]["dims"][0] == 1  # (1, Nt_src, Nsrc): time-major series of a many-series source
+    assert set(name.lstrip("/") for name in ds) == set(pr)
+
+
+@pytest.mark.gpu
+def test_output_and_checkpoint_files_as_h5dump_sees_them(h5io, syn, tmp_path):
+    """Output file (in-memory and streamed variants) and checkpoint file through h5dump: same conventions; output
+    datasets chunked like the reference's — series one time step per chunk (IndexOutputStream.cpp:119-126), grid-sized
+    arrays one z-plane per chunk (RealMatrix.cpp:88-121), deflate at the -c level; scalars contiguous."""
+    u = _h5dump()
+    nt = 12
+    pr = syn.make_problem(32, 24, 16, heterogeneous=True, nonlinear=True, absorbing=True, source="p_source", source_mode=1,
+                          nt=nt, pml_size=4, sensor="random")
+    nsens = pr["sensor_mask_index"].size
+    path_in = str(tmp_path / "in.h5")
+    h5io.write_input_file(pr, path_in)
+    flags = dict(p_raw=1, p_max=1, p_final=1, u_raw=1, p_max_all=1)
+    for streamed in (False, True):
+        out = str(tmp_path / f"out{int(streamed)}.h5")
+        fs = h5io.FileSolver(path_in, output=out if streamed else None, compression_level=4, **flags)
+        fs.run(nt // 2)
+        ckpt = str(tmp_path / f"ckpt{int(streamed)}.h5")
+        fs.write_checkpoint(ckpt)
+        fs.run(nt - nt // 2)
+        fs.finish()
+        fs.write_output(out, compression_level=4)
+        fs.close()
+        d = u.describe(out)
+        assert u.check_kwave_conventions(d, "output") == [], streamed
+        ds = d["datasets"]
+        assert ds["/p"]["dims"] == (1, nt, nsens) and ds["/ux"]["dims"] == (1, nt, nsens)
+        if streamed:
+            assert ds["/p"]["chunk"] == (1, 1, nsens) and ds["/p"]["deflate"] == 4
+        assert ds["/p_max"]["dims"] == (1, 1, nsens)
+        assert ds["/p_final"]["dims"] == (16, 24, 32) and ds["/p_final"]["chunk"] == (1, 24, 32) and ds["/p_final"]["deflate"] == 4
+        assert ds["/p_max_all"]["dims"] == (16, 24, 32)
+        assert ds["/Nx"]["dims"] == (1, 1, 1) and ds["/Nx"]["chunk"] is None and ds["/t_index"]["datatype"] == "H5T_STD_U64LE"
+        for attr in ("host_names", "number_of_cpu_cores", "total_execution_time", "simulation_phase_execution_time"):
+            assert d["attrs"][attr]["string"] and d["attrs"][attr]["nullterm"], attr
+        c = u.describe(ckpt)
+        assert u.check_kwave_conventions(c, "checkpoint") == []
+        for name in ("p", "rhox", "rhoy", "rhoz", "ux_sgx", "uy_sgy", "uz_sgz"):
+            assert c["datasets"]["/" + name]["dims"] == (16, 24, 32), name
+        assert c["datasets"]["/t_index"]["dims"] == (1, 1, 1)
+
+
+@pytest.mark.gpu
+def test_streamed_output_equals_the_output_written_at_the_end(h5io, syn, tmp_path):
+    """Per-step output (IndexOutputStream.cpp:348-372, OutputStreamContainer.cpp:380-403): with the output file open
+    from the start every series row is appended as its step is flushed; the finished file holds the same bits as the one
+    written from memory at the end — raw and compressed series, aggregates, intensities computed from the re-read series."""
+    nt = 40
+    pr = syn.make_problem(32, heterogeneous=True, nonlinear=False, absorbing=False, source="p_source", source_mode=1,
+                          nt=nt, pml_size=4, sensor="random")
+    dt = float(pr["dt"].ravel()[0])
+    path_in = str(tmp_path / "in.h5")
+    h5io.write_input_file(pr, path_in)
+    flags = dict(p_raw=1, p_max=1, u_non_staggered_raw=1, p_c=1, u_non_staggered_c=1, i_avg_c=1, i_avg=1,
+                 period=1.0 / (1.0e6 * dt) / 2.0, harmonics=2, sampling_start=3)
+    outs = []
+    for streamed in (False, True):
+        out = str(tmp_path / f"o{int(streamed)}.h5")
+        fs = h5io.FileSolver(path_in, output=out if streamed else None, **flags)
+        fs.run(nt)
+        if streamed:  # a stream can still be read back through the API (from the file)
+            series = fs.stream("p")
+        fs.finish()
+        fs.write_output(out)
+        fs.close()
+        outs.append(out)
+    names = ("p", "p_max", "ux_non_staggered", "uz_non_staggered", "p_c", "uy_non_staggered_c", "Ix_avg_c", "Ix_avg", "Iz_avg")
+    for name in names:
+        assert h5io.dataset_info(outs[1], name) == h5io.dataset_info(outs[0], name), name
+        a, b = h5io.read_dataset(outs[1], name), h5io.read_dataset(outs[0], name)
+        assert a.size > 0 and np.array_equal(a, b), name
+    assert np.array_equal(series.reshape(-1), h5io.read_dataset(outs[0], "p").reshape(-1)[: series.size])
+    assert h5io.read_numeric_attribute(outs[1], "p_c", "c_harmonics") == 2
+
+
+@pytest.mark.gpu
+def test_streamed_output_survives_and_continues_after_a_checkpoint(h5io, syn, tmp_path):
+    """A streamed run that stops with a checkpoint leaves the rows sampled so far in the output file (no series in the
+    checkpoint); a new process re-opens the file, recovers and completes it — identical to the uninterrupted output.
+    Cuboid sensor mask: one 4-D dataset per cuboid, one time step per hyperslab (CuboidOutputStream.cpp:439-470)."""
+    nt, split = 20, 9
+    pr = syn.make_problem(32, 24, 20, heterogeneous=True, nonlinear=True, absorbing=True, source="p0", nt=nt, pml_size=4)
+    corners = np.array([[3, 4, 5, 10, 9, 8], [12, 2, 1, 20, 20, 6]], dtype=np.uint64)  # 1-based x1 y1 z1 x2 y2 z2
+    pr.pop("sensor_mask_index")
+    pr["sensor_mask_type"] = np.array([[[1]]], dtype=np.uint64)
+    pr["sensor_mask_corners"] = corners.reshape(1, 2, 6)
+    path_in, whole, legs, ckpt = (str(tmp_path / n) for n in ("in.h5", "whole.h5", "legs.h5", "ckpt.h5"))
+    h5io.write_input_file(pr, path_in)
+    flags = dict(p_raw=1, p_rms=1, u_raw=1, p_final=1)
+    fs = h5io.FileSolver(path_in, output=whole, **flags)
+    fs.run(nt)
+    fs.finish()
+    fs.write_output(whole)
+    fs.close()
+    a = h5io.FileSolver(path_in, output=legs, **flags)
+    a.run(split)
+    a.write_checkpoint(ckpt)
+    a.close()  # no write_output: the process "dies" here
+    assert not h5io.dataset_exists(ckpt, "stream_p")  # the series lives in the output file, not in the checkpoint
+    first = h5io.read_dataset(legs, "p/1")
+    assert first.shape[0] == nt and np.array_equal(first[:split], h5io.read_dataset(whole, "p/1")[:split])
+    assert not first[split:].any()
+    b = h5io.FileSolver(path_in, output=legs, reopen_output=True, **flags)
+    b.read_checkpoint(ckpt)
+    assert b.t == split
+    b.run(nt)
+    b.finish()
+    b.write_output(legs)
+    b.close()
+    for name in ("p/1", "p/2", "ux/2", "p_rms/1", "p_final"):
+        assert np.array_equal(h5io.read_dataset(legs, name), h5io.read_dataset(whole, name)), name
