@@ -134,6 +134,71 @@ template<int RUN, int R1> __device__ __forceinline__ void load_op_run(float (&ds
 }
 
 
+// Element e of a lane plus a wave-uniform element offset: "SGPR base + 32-bit lane offset" addressing.  The uniform part
+// (array base + n * line stride) is 64-bit scalar arithmetic, the lane part one VGPR holding a byte offset — written
+// this way the loads / stores of a tile cost no vector ALU work at all (as  p[lane + n * stride]  every access pays a
+// v_add_u32 and a 64-bit v_lshl_add_u64: a sixth of the vector instructions of a z-pass, whose VALU is ~75 % busy).
+// KW_SADDR=0 restores the indexed form (A/B).
+#ifndef KW_SADDR
+#define KW_SADDR 1
+#endif
+// (the empty asm pins the uniform part to an SGPR pair: left alone, the compiler re-associates it into a chain of 64-bit
+// vector adds)
+__device__ __forceinline__ float2 ld_uni(const float2* __restrict__ p, uint64_t uniform_elems, uint32_t lane_bytes)
+{
+  typedef float v2 __attribute__((ext_vector_type(2)));
+  typedef const __attribute__((address_space(1))) char* gptr; // global address space survives the asm (else: flat loads)
+  gptr b = (gptr)(p + uniform_elems);
+  asm volatile("" : "+s"(b));
+  const v2 t = *(const __attribute__((address_space(1))) v2*)(b + lane_bytes);
+  return make_float2(t.x, t.y);
+}
+__device__ __forceinline__ void st_uni(float2* __restrict__ p, uint64_t uniform_elems, uint32_t lane_bytes, const float2& v)
+{
+  typedef float v2 __attribute__((ext_vector_type(2)));
+  typedef __attribute__((address_space(1))) char* gptr;
+  gptr b = (gptr)(p + uniform_elems);
+  asm volatile("" : "+s"(b));
+  *(__attribute__((address_space(1))) v2*)(b + lane_bytes) = v2{ v.x, v.y };
+}
+
+// Tile coordinates of a block of a y- or z-pass.  Regular tiles: NL consecutive columns kx at one line position (the
+// plane z of a y-pass, the row ky of a z-pass; blockIdx.y).  Column tile: a half-spectrum row of nxc = NL*m + 1 bins —
+// every Nx that is a multiple of 32: the extra bin is the x-Nyquist column — leaves a last tile with ONE valid lane in
+// NL.  The blocks of that tile instead take the single column at NL line positions each (lane c <-> position
+// NL * blockIdx.y + c) and the blocks left over exit at once: the same cache lines are touched as before, by 1/NL of the
+// blocks — 2064 instead of 2304 blocks per pass at 256^3.  MEASURED SLOWER and therefore off unless KW_FUSED_COLT=1: every
+// wave-level access of a column-tile block touches 64 different cache lines (one 8-B element per row) instead of four
+// whole ones, and those 16 blocks become the critical path of the launch (256^3: y-passes +12 %, z-passes 0 .. +12 %,
+// step -4 %; gpurun_out/r02_abk3.txt).  What would help is the Nyquist column stored apart as a compact [z][ky] array.
+struct TileCoord
+{
+  uint32_t kx, kxl, pos;
+  bool     valid, dead;
+};
+template<int NL> __device__ __forceinline__ TileCoord tile_coord(uint32_t nxc, uint32_t colt, uint32_t npos, int c)
+{
+  TileCoord t;
+  const uint32_t ct = (nxc - 1u) / NL; // the tile holding the last column (tiles past it are row padding only)
+  if (colt != 0 && blockIdx.x >= ct)
+  {
+    const uint32_t p = blockIdx.y * NL + c;
+    t.dead  = blockIdx.x > ct || blockIdx.y * NL >= npos;
+    t.kx    = t.kxl = nxc - 1u;
+    t.valid = p < npos;
+    t.pos   = min(p, npos - 1u); // lanes past the last position re-read it; their results are never stored
+  }
+  else
+  {
+    t.kx    = blockIdx.x * NL + c;
+    t.kxl   = min(t.kx, nxc - 1u); // pad lanes re-read the last column (no branch, no extra sector); never stored
+    t.valid = t.kx < nxc;
+    t.pos   = blockIdx.y;
+    t.dead  = false;
+  }
+  return t;
+}
+
 // ---- register-level steps -------------------------------------------------------------------------------------------
 // Fill the block's twiddle table from the global one (tw[m] = exp(-2*pi*i*m/L)); the caller's next lds_barrier()
 // publishes it.  Every use below is "one VGPR base + compile-time offset", so twiddles cost neither address registers
@@ -185,6 +250,7 @@ struct PassArgs
   uint32_t      PX;   // row pitch of the packed (exchange) side (= P unless rows travel without their padding)
   uint32_t      narr; // arrays per block (grid.z * narr arrays in the launch)
   uint32_t      z0;   // first plane of this launch (chunked plane-local passes)
+  uint32_t      colt; // the last tile of a row is a column tile (see tile_coord)
   const float2* mul[3]; // per array: optional factor mul[ky] applied to the line before its transform (ddy of the gradient)
   RowAddr       ain, aout;
 };
@@ -201,10 +267,12 @@ __global__ __launch_bounds__(Geo<L>::THREADS) void k_ypass(PassArgs a)
   load_twiddles<L>(twl, a.tw);
   const int      c     = threadIdx.x % G::NL;
   const int      j     = threadIdx.x / G::NL;
-  const uint32_t kx    = blockIdx.x * G::NL + c;
-  const bool     valid = kx < a.nxc;
-  const uint32_t kxl   = min(kx, a.nxc - 1u); // pad lanes re-read the last column (no branch, no extra sector); never stored
-  const uint32_t z     = blockIdx.y + a.z0;
+  const TileCoord tc   = tile_coord<G::NL>(a.nxc, a.colt, gridDim.y, c);
+  if (tc.dead) return;
+  const uint32_t kx    = tc.kx;
+  const bool     valid = tc.valid;
+  const uint32_t kxl   = tc.kxl;
+  const uint32_t z     = tc.pos + a.z0;
   const uint32_t arr0  = blockIdx.z * a.narr; // each block takes a.narr arrays back to back (next one's lines prefetched)
 
   auto load_lines = [&](float2 (&v)[R1], const float2* __restrict__ Sin) {
@@ -219,7 +287,8 @@ __global__ __launch_bounds__(Geo<L>::THREADS) void k_ypass(PassArgs a)
       asm volatile("" : "+v"(b));
       const uint32_t step = R2 * a.ain.estride * a.P;
 #pragma unroll
-      for (int n1 = 0; n1 < R1; n1++) v[n1] = Sin[b + n1 * step];
+      for (int n1 = 0; n1 < R1; n1++)
+        v[n1] = KW_SADDR ? ld_uni(Sin, static_cast<uint64_t>(n1) * step, b * static_cast<uint32_t>(sizeof(float2))) : Sin[b + n1 * step];
     }
   };
 
@@ -263,7 +332,11 @@ __global__ __launch_bounds__(Geo<L>::THREADS) void k_ypass(PassArgs a)
           asm volatile("" : "+v"(b));
           const uint32_t step = R1 * a.aout.estride * a.P;
 #pragma unroll
-          for (int k2 = 0; k2 < R2; k2++) Sout[b + k2 * step] = w[k2];
+          for (int k2 = 0; k2 < R2; k2++)
+          {
+            if (KW_SADDR) st_uni(Sout, static_cast<uint64_t>(k2) * step, b * static_cast<uint32_t>(sizeof(float2)), w[k2]);
+            else Sout[b + k2 * step] = w[k2];
+          }
         }
       }
     }
@@ -293,6 +366,7 @@ struct ZArgs
   uint32_t      narr; // arrays processed back to back by each block (VGRAD / ABSORB)
   uint32_t      ky0;  // global ky of local row 0 (slab mode: rank * ny/nranks); ny above = number of LOCAL rows
   uint32_t      lstride, bstride; // Z_SHIFT: element stride along a line, offset per blockIdx.y (both in complex units)
+  uint32_t      colt; // the last tile of a row is a column tile (see tile_coord)
 };
 
 // inverse along the line, started from the step-B register layout (thread (c,k1) holds X[k1 + R1*k2]); result:
@@ -348,13 +422,15 @@ template<int L, int MODE> __global__ __launch_bounds__(Geo<L>::THREADS) void k_z
   load_twiddles<L>(twl, a.tw);
   const int      c      = threadIdx.x % G::NL;
   const int      j      = threadIdx.x / G::NL;
-  const uint32_t kx     = blockIdx.x * G::NL + c;
-  const uint32_t ky     = blockIdx.y;
-  const bool     valid  = kx < a.nxc;
+  const TileCoord tc    = tile_coord<G::NL>(a.nxc, (MODE == Z_SHIFT) ? 0u : a.colt, gridDim.y, c);
+  if (tc.dead) return;
+  const uint32_t kx     = tc.kx;
+  const uint32_t ky     = tc.pos;
+  const bool     valid  = tc.valid;
   const uint32_t zstr   = (MODE == Z_SHIFT) ? a.lstride : a.ny * a.P;
   const uint32_t bstr   = (MODE == Z_SHIFT) ? a.bstride : a.P;
   const uint32_t base   = ky * bstr + kx;
-  const uint32_t kxl    = min(kx, a.nxc - 1u); // pad lanes re-read the last column; their results are never stored
+  const uint32_t kxl    = tc.kxl;
   const uint32_t basel  = ky * bstr + kxl;
   // operators live in a tile-blocked layout [ky][kx tile][kz][16]: the 16 x nz values of this block's tile are one
   // contiguous run (k_import_reduced), instead of 64-B pieces a whole plane apart
@@ -371,8 +447,10 @@ template<int L, int MODE> __global__ __launch_bounds__(Geo<L>::THREADS) void k_z
   if (ACT(R2, j))
   {
     const float2* __restrict__ in = a.in[arr0];
+    const uint32_t lb = (basel + static_cast<uint32_t>(j) * zstr) * static_cast<uint32_t>(sizeof(float2));
 #pragma unroll
-    for (int n1 = 0; n1 < R1; n1++) v[n1] = in[basel + static_cast<uint32_t>(n1 * R2 + j) * zstr];
+    for (int n1 = 0; n1 < R1; n1++)
+      v[n1] = KW_SADDR ? ld_uni(in, static_cast<uint64_t>(n1 * R2) * zstr, lb) : in[basel + static_cast<uint32_t>(n1 * R2 + j) * zstr];
   }
   // spectral operator of the elements this thread will hold after the forward transform (kz = j + R1*k2)
   float kap[R2];
@@ -399,7 +477,9 @@ template<int L, int MODE> __global__ __launch_bounds__(Geo<L>::THREADS) void k_z
       uint32_t lb = basel + static_cast<uint32_t>(j) * zstr;
       asm volatile("" : "+v"(lb)); // per-iteration address arithmetic instead of 16 loop-invariant address registers
 #pragma unroll
-      for (int n1 = 0; n1 < R1; n1++) v[n1] = in[lb + static_cast<uint32_t>(n1 * R2) * zstr];
+      for (int n1 = 0; n1 < R1; n1++)
+        v[n1] = KW_SADDR ? ld_uni(in, static_cast<uint64_t>(n1 * R2) * zstr, lb * static_cast<uint32_t>(sizeof(float2)))
+                         : in[lb + static_cast<uint32_t>(n1 * R2) * zstr];
     }
     lds_barrier();
     float2 X[R2];
@@ -478,7 +558,11 @@ template<int L, int MODE> __global__ __launch_bounds__(Geo<L>::THREADS) void k_z
         uint32_t ob = base + static_cast<uint32_t>(j) * zstr;
         asm volatile("" : "+v"(ob)); // recomputed per output: 16 hoisted 64-bit addresses cost an occupancy step
 #pragma unroll
-        for (int q2 = 0; q2 < R1; q2++) out[ob + static_cast<uint32_t>(R2 * q2) * zstr] = r[q2];
+        for (int q2 = 0; q2 < R1; q2++)
+        {
+          if (KW_SADDR) st_uni(out, static_cast<uint64_t>(R2 * q2) * zstr, ob * static_cast<uint32_t>(sizeof(float2)), r[q2]);
+          else out[ob + static_cast<uint32_t>(R2 * q2) * zstr] = r[q2];
+        }
       }
       // the next output's inverse writes rows while other threads may still read their columns: barrier; the next
       // array's forward transform writes the column this thread has just read: none
@@ -541,10 +625,12 @@ __global__ __launch_bounds__(Geo<L / 2>::THREADS) void k_ypass_split(PassArgs a)
   load_twiddles_split<L>(twl, tw2, a.tw);
   const int      c     = threadIdx.x % G::NL;
   const int      j     = threadIdx.x / G::NL;
-  const uint32_t kx    = blockIdx.x * G::NL + c;
-  const bool     valid = kx < a.nxc;
-  const uint32_t kxl   = min(kx, a.nxc - 1u);
-  const uint32_t z     = blockIdx.y + a.z0;
+  const TileCoord tc   = tile_coord<G::NL>(a.nxc, a.colt, gridDim.y, c);
+  if (tc.dead) return;
+  const uint32_t kx    = tc.kx;
+  const bool     valid = tc.valid;
+  const uint32_t kxl   = tc.kxl;
+  const uint32_t z     = tc.pos + a.z0;
   const float2* __restrict__ Sin = a.in[blockIdx.z];
   float2* __restrict__ Sout      = a.out[blockIdx.z];
 
@@ -565,8 +651,8 @@ __global__ __launch_bounds__(Geo<L / 2>::THREADS) void k_ypass_split(PassArgs a)
 #pragma unroll
     for (int n1 = 0; n1 < R1; n1++)
     {
-      va[n1] = Sin[b + n1 * step];
-      vb[n1] = Sin[b + (R1 + n1) * step];
+      va[n1] = KW_SADDR ? ld_uni(Sin, static_cast<uint64_t>(n1) * step, b * static_cast<uint32_t>(sizeof(float2))) : Sin[b + n1 * step];
+      vb[n1] = KW_SADDR ? ld_uni(Sin, static_cast<uint64_t>(R1 + n1) * step, b * static_cast<uint32_t>(sizeof(float2))) : Sin[b + (R1 + n1) * step];
     }
   }
   lds_barrier(); // twiddle tables visible (the line loads stay in flight across it)
@@ -602,8 +688,16 @@ __global__ __launch_bounds__(Geo<L / 2>::THREADS) void k_ypass_split(PassArgs a)
 #pragma unroll
       for (int k2 = 0; k2 < R2; k2++)
       {
-        Sout[b + k2 * step]       = wa[k2];
-        Sout[b + one + k2 * step] = wb[k2];
+        if (KW_SADDR)
+        {
+          st_uni(Sout, static_cast<uint64_t>(k2) * step, b * static_cast<uint32_t>(sizeof(float2)), wa[k2]);
+          st_uni(Sout, static_cast<uint64_t>(k2) * step + one, b * static_cast<uint32_t>(sizeof(float2)), wb[k2]);
+        }
+        else
+        {
+          Sout[b + k2 * step]       = wa[k2];
+          Sout[b + one + k2 * step] = wb[k2];
+        }
       }
     }
   }
@@ -621,12 +715,14 @@ template<int L, int MODE> __global__ __launch_bounds__(Geo<L / 2>::THREADS) void
   load_twiddles_split<L>(twl, tw2, a.tw);
   const int      c      = threadIdx.x % G::NL;
   const int      j      = threadIdx.x / G::NL;
-  const uint32_t kx     = blockIdx.x * G::NL + c;
-  const uint32_t ky     = blockIdx.y;
-  const bool     valid  = kx < a.nxc;
+  const TileCoord tc    = tile_coord<G::NL>(a.nxc, a.colt, gridDim.y, c);
+  if (tc.dead) return;
+  const uint32_t kx     = tc.kx;
+  const uint32_t ky     = tc.pos;
+  const bool     valid  = tc.valid;
   const uint32_t zstr   = a.ny * a.P;
   const uint32_t base   = ky * a.P + kx;
-  const uint32_t kxl    = min(kx, a.nxc - 1u);
+  const uint32_t kxl    = tc.kxl;
   const uint32_t basel  = ky * a.P + kxl;
   // operators live in a tile-blocked layout [ky][kx tile][kz][16]: the 16 x nz values of this block's tile are one
   // contiguous run (k_import_reduced), instead of 64-B pieces a whole plane apart
@@ -646,8 +742,10 @@ template<int L, int MODE> __global__ __launch_bounds__(Geo<L / 2>::THREADS) void
 #pragma unroll
     for (int n1 = 0; n1 < R1; n1++)
     {
-      va[n1] = in[lb + static_cast<uint32_t>(n1 * R2) * zstr];
-      vb[n1] = in[lb + static_cast<uint32_t>(H + n1 * R2) * zstr];
+      va[n1] = KW_SADDR ? ld_uni(in, static_cast<uint64_t>(n1 * R2) * zstr, lb * static_cast<uint32_t>(sizeof(float2)))
+                        : in[lb + static_cast<uint32_t>(n1 * R2) * zstr];
+      vb[n1] = KW_SADDR ? ld_uni(in, static_cast<uint64_t>(H + n1 * R2) * zstr, lb * static_cast<uint32_t>(sizeof(float2)))
+                        : in[lb + static_cast<uint32_t>(H + n1 * R2) * zstr];
     }
     lds_barrier(); // twiddle tables visible
 #pragma unroll
@@ -725,8 +823,16 @@ template<int L, int MODE> __global__ __launch_bounds__(Geo<L / 2>::THREADS) void
       for (int q2 = 0; q2 < R1; q2++)
       { // n = j + R2*q2
         const float2 t = apply_tw<kInv>(rb[q2], tw2[j + R2 * q2]);
-        out[ob + static_cast<uint32_t>(R2 * q2) * zstr]     = cadd(ra[q2], t);
-        out[ob + static_cast<uint32_t>(H + R2 * q2) * zstr] = csub(ra[q2], t);
+        if (KW_SADDR)
+        {
+          st_uni(out, static_cast<uint64_t>(R2 * q2) * zstr, ob * static_cast<uint32_t>(sizeof(float2)), cadd(ra[q2], t));
+          st_uni(out, static_cast<uint64_t>(H + R2 * q2) * zstr, ob * static_cast<uint32_t>(sizeof(float2)), csub(ra[q2], t));
+        }
+        else
+        {
+          out[ob + static_cast<uint32_t>(R2 * q2) * zstr]     = cadd(ra[q2], t);
+          out[ob + static_cast<uint32_t>(H + R2 * q2) * zstr] = csub(ra[q2], t);
+        }
       }
     }
   }
@@ -741,14 +847,20 @@ struct XfwdArgs
   float2*       out[3];
   const float2* tw;
   uint32_t      nx, P;
+  uint32_t      nrows, tile0; // rows of the grid (ny * nz); first tile of this launch
 };
+
+// The x kernels work on tiles of 2 * NL rows.  A grid whose row count ny * nz is not a whole number of tiles ends in a
+// partial tile: that one tile is launched on its own with TAIL = true — row loads clamp to the last row, every store is
+// predicated on the row — so the full tiles keep their unmasked kernels.
 
 // forward line FFT of this block's 16 complex lines (= 32 real rows) from the step-A registers v (valid for f < R2),
 // split into the two half-spectra and stored to rows tile_row0.. of `out`.  Called by every thread of the block; the
 // exchange buffer must be free on entry and is free again on exit (trailing barrier).
-template<int L>
+template<int L, bool TAIL = false>
 __device__ __forceinline__ void xfwd_tail(float2 (&v)[Fac<L>::R1], float2* lds, int c, int f,
-                                          const float2* tw, float2* __restrict__ out, uint32_t P, uint32_t tile)
+                                          const float2* tw, float2* __restrict__ out, uint32_t P, uint32_t tile,
+                                          uint32_t nrows = 0)
 {
   using G = Geo<L>;
   constexpr int R1 = G::R1, R2 = G::R2, HALF = L / 2 + 1;
@@ -783,13 +895,13 @@ __device__ __forceinline__ void xfwd_tail(float2 (&v)[Fac<L>::R1], float2* lds, 
     const float2 xa = make_float2(0.5f * (zk.x + zn.x), 0.5f * (zk.y - zn.y));
     const float2 xb = make_float2(0.5f * (zk.y + zn.y), 0.5f * (zn.x - zk.x));
     const uint32_t r = tile_row0 + 2 * cc;
-    out[r * P + k]       = xa;
-    out[(r + 1) * P + k] = xb;
+    if (!TAIL || r < nrows) out[r * P + k] = xa;
+    if (!TAIL || r + 1 < nrows) out[(r + 1) * P + k] = xb;
   }
   lds_barrier();
 }
 
-template<int L> __global__ __launch_bounds__(Geo<L>::THREADS) void k_xfwd(XfwdArgs a)
+template<int L, bool TAIL = false> __global__ __launch_bounds__(Geo<L>::THREADS) void k_xfwd(XfwdArgs a)
 {
   using G = Geo<L>;
   constexpr int R1 = G::R1, R2 = G::R2;
@@ -799,17 +911,18 @@ template<int L> __global__ __launch_bounds__(Geo<L>::THREADS) void k_xfwd(XfwdAr
   const int    f   = threadIdx.x % G::TPL;
   const int    c   = threadIdx.x / G::TPL;
   const float* __restrict__ in = a.in[blockIdx.y];
-  const uint32_t row0 = (blockIdx.x * G::NL + c) * 2;
+  const uint32_t tile = blockIdx.x + a.tile0;
+  const uint32_t row0 = (tile * G::NL + c) * 2;
   float2 v[R1];
   if (ACT(R2, f))
   {
-    const float* __restrict__ ra = in + row0 * L;
-    const float* __restrict__ rb = ra + L;
+    const float* __restrict__ ra = in + (TAIL ? min(row0, a.nrows - 1u) : row0) * L;
+    const float* __restrict__ rb = TAIL ? in + min(row0 + 1u, a.nrows - 1u) * L : ra + L;
 #pragma unroll
     for (int n1 = 0; n1 < R1; n1++) v[n1] = make_float2(ra[n1 * R2 + f], rb[n1 * R2 + f]);
   }
   lds_barrier(); // twiddle table visible
-  xfwd_tail<L>(v, lds, c, f, twl, a.out[blockIdx.y], a.P, blockIdx.x);
+  xfwd_tail<L, TAIL>(v, lds, c, f, twl, a.out[blockIdx.y], a.P, tile, a.nrows);
 }
 
 // =====================================================================================================================
@@ -838,13 +951,14 @@ struct XinvArgs
   uint32_t      tile0;   // first 2*NL-row tile of this launch (chunked plane-local passes)
   const float2* mulx[3]; // per component: optional factor mulx[kx] applied to the rows before the inverse (ddx of the gradient)
   uint32_t      descending; // tiles (and components) are taken from the last to the first (experiment: KW_FUSED_XINV_DESC)
+  uint32_t      nrows;      // rows of the grid (ny * nz): bounds the partial last tile (TAIL kernels)
 };
 
 // standalone inverse of one array for this block's 32 rows; thread (c, f<R1) ends with x[f + R1*k2] of rows (2c, 2c+1)
-template<int L, int NGRP = 1>
+template<int L, int NGRP = 1, bool TAIL = false>
 __device__ __forceinline__ void xinv_lines(const float2* __restrict__ src, uint32_t P, float2* lds, int c, int f,
                                            const float2* tw, float2 (&w)[Fac<L>::R2], uint32_t tile,
-                                           const float2* __restrict__ mulx = nullptr)
+                                           const float2* __restrict__ mulx = nullptr, uint32_t nrows = 0)
 {
   using G = Geo<L>;
   constexpr int R1 = G::R1, R2 = G::R2, HALF = L / 2 + 1;
@@ -864,8 +978,8 @@ __device__ __forceinline__ void xinv_lines(const float2* __restrict__ src, uint3
       const int cc = e / HALF;
       const int k  = e - cc * HALF;
       const uint32_t r = tile_row0 + 2 * cc;
-      A[it] = src[r * P + k];
-      B[it] = src[(r + 1) * P + k];
+      A[it] = src[(TAIL ? min(r, nrows - 1u) : r) * P + k];
+      B[it] = src[(TAIL ? min(r + 1u, nrows - 1u) : r + 1u) * P + k];
     }
 #pragma unroll
     for (int it = 0; it < NG; it++)
@@ -919,7 +1033,7 @@ __device__ __forceinline__ void   f4put(float4& v, int k, float s)
 // epilogue access to the state / medium arrays is a 16-B-per-lane coalesced access.
 // (the 256-point density epilogue sits two registers above the 3-waves-per-SIMD step: ask the allocator for that step)
 // TERMS: compile-time value of a.terms for the density epilogue (one specialised kernel per pressure-term mode)
-template<int L, int EPI, bool CHAIN, int TERMS = 0>
+template<int L, int EPI, bool CHAIN, int TERMS = 0, bool TAIL = false>
 __global__ __launch_bounds__(Geo<L>::THREADS, (EPI == EPI_DENSITY && L == 256) ? 3 : 1) void k_xinv(XinvArgs a)
 {
   constexpr int terms = TERMS;
@@ -949,7 +1063,8 @@ __global__ __launch_bounds__(Geo<L>::THREADS, (EPI == EPI_DENSITY && L == 256) ?
   for (int i = 0; i < NA; i++)
   {
     float2 w[R2];
-    xinv_lines<L, (EPI == EPI_DENSITY) ? 2 : 1>(a.in[(NA == 1) ? comp : i], a.P, lds, c, f, twl, w, tile, (NA == 1) ? a.mulx[comp] : nullptr); // ends with a barrier
+    xinv_lines<L, (EPI == EPI_DENSITY) ? 2 : 1, TAIL>(a.in[(NA == 1) ? comp : i], a.P, lds, c, f, twl, w, tile,
+                                                       (NA == 1) ? a.mulx[comp] : nullptr, a.nrows); // ends with a barrier
     if (ACT(R1, f))
     {
 #pragma unroll
@@ -997,7 +1112,7 @@ __global__ __launch_bounds__(Geo<L>::THREADS, (EPI == EPI_DENSITY && L == 256) ?
     for (int g = 0; g < GQ; g++)
     {
       const int      e   = threadIdx.x + (q0 + g) * G::THREADS;
-      const uint32_t r   = tile_row0 + e / Q4;
+      const uint32_t r   = TAIL ? min(tile_row0 + e / Q4, a.nrows - 1u) : tile_row0 + e / Q4; // operands of a masked row: the last row's
       const uint32_t z   = r / k.ny;
       const uint32_t y   = r - z * k.ny;
       const uint32_t x   = XFIX ? xfix : 4u * (e % Q4);
@@ -1041,10 +1156,11 @@ __global__ __launch_bounds__(Geo<L>::THREADS, (EPI == EPI_DENSITY && L == 256) ?
       const uint32_t r = tile_row0 + e / Q4;
       const uint32_t x = XFIX ? xfix : 4u * (e % Q4);
       const uint32_t i = r * L + x;
+      const bool     row_ok = !TAIL || r < a.nrows; // every store below is predicated on it
       const float4   pmx = XFIX ? pmlx4 : opx[g];
       if (EPI == EPI_STORE)
       {
-        st4(a.out[comp] + i, res[0][q]);
+        if (row_ok) st4(a.out[comp] + i, res[0][q]);
       }
       else if (EPI == EPI_VELOCITY)
       { // SolverCudaKernels.cu:199-212 (heterogeneous) / :287-305 (homogeneous)
@@ -1073,7 +1189,7 @@ __global__ __launch_bounds__(Geo<L>::THREADS, (EPI == EPI_DENSITY && L == 256) ?
             f4put(vu, t, (f4get(vu, t) * pm - divider * f4get(gr, t)) * pm);
           }
         }
-        st4(a.out[comp] + i, vu);
+        if (row_ok) st4(a.out[comp] + i, vu);
         if constexpr (CHAIN) fw[0][q] = vu;
       }
       else if (EPI == EPI_INITVEL)
@@ -1092,7 +1208,7 @@ __global__ __launch_bounds__(Geo<L>::THREADS, (EPI == EPI_DENSITY && L == 256) ?
 #pragma unroll
           for (int t = 0; t < 4; t++) f4put(o, t, f4get(gr, t) * (k.fft_divider * 0.5f * dtr));
         }
-        st4(a.out[comp] + i, o);
+        if (row_ok) st4(a.out[comp] + i, o);
       }
       else if (EPI == EPI_DENSITY)
       { // :1368-1392 (nonlinear) / :1480-1496 (linear); du already carries fftDivider (applied in k-space, :1220)
@@ -1122,14 +1238,14 @@ __global__ __launch_bounds__(Geo<L>::THREADS, (EPI == EPI_DENSITY && L == 256) ?
             f4put(nrz, t, pz * (pz * erz - dtRho0 * f4get(duz, t)));
           }
         }
-        st4(a.out[0] + i, nrx);
-        st4(a.out[1] + i, nry);
-        st4(a.out[2] + i, nrz);
+        if (row_ok) st4(a.out[0] + i, nrx);
+        if (row_ok) st4(a.out[1] + i, nry);
+        if (row_ok) st4(a.out[2] + i, nrz);
         if (a.aux[0] != nullptr)
         {
-          st4(a.aux[0] + i, dux);
-          st4(a.aux[1] + i, duy);
-          st4(a.aux[2] + i, duz);
+          if (row_ok) st4(a.aux[0] + i, dux);
+          if (row_ok) st4(a.aux[1] + i, duy);
+          if (row_ok) st4(a.aux[2] + i, duz);
         }
         if (terms == 2)
         { // :1588-1601 with the updated densities
@@ -1146,9 +1262,9 @@ __global__ __launch_bounds__(Geo<L>::THREADS, (EPI == EPI_DENSITY && L == 256) ?
             f4put(o1, t, ((eBonA * eRhoSum * eRhoSum) / (2.0f * r0)) + eRhoSum);
             f4put(o2, t, r0 * eDuSum);
           }
-          st4(a.t[1] + i, o1); // the nonlinear term is read again by the pressure sum (a stage later: cached or not, same time)
+          if (row_ok) st4(a.t[1] + i, o1); // the nonlinear term is read again by the pressure sum (a stage later: cached or not, same time)
           if constexpr (CHAIN) { *reinterpret_cast<float4*>(&ldsr[(e / Q4) * RP + x]) = o2; fw[0][q] = o0; }
-          else { st4(a.t[0] + i, o0); st4(a.t[2] + i, o2); }
+          else { if (row_ok) st4(a.t[0] + i, o0); if (row_ok) st4(a.t[2] + i, o2); }
         }
         else if (terms == 3)
         { // lossless equation of state on the updated densities: sumPressureNonlinearLossless (:2067-2084) /
@@ -1163,7 +1279,7 @@ __global__ __launch_bounds__(Geo<L>::THREADS, (EPI == EPI_DENSITY && L == 256) ?
             if (a.nonlinear) f4put(pn, t, f4get(c24, t) * (rhoSum + (f4get(b4, t) * (rhoSum * rhoSum) / (2.0f * f4get(r04, t)))));
             else f4put(pn, t, f4get(c24, t) * rhoSum);
           }
-          st4(a.t[0] + i, pn);
+          if (row_ok) st4(a.t[0] + i, pn);
           if constexpr (CHAIN) *reinterpret_cast<float4*>(&ldsr[(e / Q4) * RP + x]) = pn;
         }
         else if (terms == 1)
@@ -1176,9 +1292,9 @@ __global__ __launch_bounds__(Geo<L>::THREADS, (EPI == EPI_DENSITY && L == 256) ?
             const float duSum = f4get(dux, t) + f4get(duy, t) + f4get(duz, t);
             f4put(o1, t, f4get(r04, t) * duSum);
           }
-          st4(a.t[0] + i, o0); // the density sum is read again by the pressure sum
+          if (row_ok) st4(a.t[0] + i, o0); // the density sum is read again by the pressure sum
           if constexpr (CHAIN) { *reinterpret_cast<float4*>(&ldsr[(e / Q4) * RP + x]) = o1; fw[0][q] = o0; }
-          else st4(a.t[1] + i, o1);
+          else if (row_ok) st4(a.t[1] + i, o1);
         }
       }
       else if (EPI == EPI_PSUM)
@@ -1192,7 +1308,7 @@ __global__ __launch_bounds__(Geo<L>::THREADS, (EPI == EPI_DENSITY && L == 256) ?
 #pragma unroll
         for (int t = 0; t < 4; t++)
           f4put(o, t, f4get(c24, t) * (f4get(fi, t) + (k.fft_divider * ((f4get(tt, t) * f4get(tau4, t)) - (f4get(et, t) * f4get(eta4, t))))));
-        st4(a.out[0] + i, o);
+        if (row_ok) st4(a.out[0] + i, o);
         if constexpr (CHAIN) fw[0][q] = o;
       }
     }
@@ -1227,7 +1343,7 @@ __global__ __launch_bounds__(Geo<L>::THREADS, (EPI == EPI_DENSITY && L == 256) ?
           v[n1] = make_float2(ldsr[(2 * c) * RP + n1 * R2c + f], ldsr[(2 * c + 1) * RP + n1 * R2c + f]);
       }
       lds_barrier(); // the real tile aliases the exchange buffer
-      xfwd_tail<L>(v, lds, c, f, twl, a.fout[(NA == 1) ? comp : jf], a.P, tile);
+      xfwd_tail<L, TAIL>(v, lds, c, f, twl, a.fout[(NA == 1) ? comp : jf], a.P, tile, a.nrows);
     }
   }
 }
@@ -1242,9 +1358,10 @@ struct XshiftArgs
   float*        out;
   const float2* tw;
   const float2* H; // L complex: shift[k] / L on 0 < k < L/2, conjugate above, real parts at k = 0 and L/2
+  uint32_t      nrows, tile0;
 };
 
-template<int L> __global__ __launch_bounds__(Geo<L>::THREADS) void k_xshift(XshiftArgs a)
+template<int L, bool TAIL = false> __global__ __launch_bounds__(Geo<L>::THREADS) void k_xshift(XshiftArgs a)
 {
   using G = Geo<L>;
   constexpr int R1 = G::R1, R2 = G::R2;
@@ -1256,12 +1373,13 @@ template<int L> __global__ __launch_bounds__(Geo<L>::THREADS) void k_xshift(Xshi
   float* ldsr = reinterpret_cast<float*>(lds);
   const int f = threadIdx.x % G::TPL;
   const int c = threadIdx.x / G::TPL;
-  const uint32_t tile_row0 = blockIdx.x * G::NL * 2;
+  const uint32_t tile_row0 = (blockIdx.x + a.tile0) * G::NL * 2;
   float2 v[R1];
   if (ACT(R2, f))
   {
-    const float* __restrict__ ra = a.in + (tile_row0 + 2 * c) * L;
-    const float* __restrict__ rb = ra + L;
+    const uint32_t row0 = tile_row0 + 2 * c;
+    const float* __restrict__ ra = a.in + (TAIL ? min(row0, a.nrows - 1u) : row0) * L;
+    const float* __restrict__ rb = TAIL ? a.in + min(row0 + 1u, a.nrows - 1u) * L : ra + L;
 #pragma unroll
     for (int n1 = 0; n1 < R1; n1++) v[n1] = make_float2(ra[n1 * R2 + f], rb[n1 * R2 + f]);
   }
@@ -1325,7 +1443,8 @@ template<int L> __global__ __launch_bounds__(Geo<L>::THREADS) void k_xshift(Xshi
     const int e   = threadIdx.x + q * G::THREADS;
     const int row = e / Q4;
     const int x4  = e - row * Q4;
-    st4(a.out + (tile_row0 + row) * L + 4 * x4, *reinterpret_cast<const float4*>(&ldsr[row * RP + 4 * x4]));
+    if (!TAIL || tile_row0 + row < a.nrows)
+      st4(a.out + (tile_row0 + row) * L + 4 * x4, *reinterpret_cast<const float4*>(&ldsr[row * RP + 4 * x4]));
   }
 }
 
@@ -1543,10 +1662,23 @@ kw_status launch_xfwd(kw_ctx* ctx, int narr, const float* const* in, float2* con
   a.tw = ctx->fused.tw[0];
   a.nx = c.nx;
   a.P  = ctx->fused.P;
-  const dim3 grid(c.ny * c.nz / (2 * nl_of(c.nx)), narr, 1);
-#define M(LEN) LAUNCH((k_xfwd<LEN>), grid, dim3(Geo<LEN>::THREADS), a)
-  KW_LEN_SWITCH(c.nx, M)
+  a.nrows = c.ny * c.nz;
+  const uint32_t rows_per_tile = 2u * static_cast<uint32_t>(nl_of(c.nx)), full = a.nrows / rows_per_tile;
+  if (full > 0)
+  {
+    const dim3 grid(full, narr, 1);
+#define M(LEN) LAUNCH((k_xfwd<LEN, false>), grid, dim3(Geo<LEN>::THREADS), a)
+    KW_LEN_SWITCH(c.nx, M)
 #undef M
+  }
+  if (a.nrows % rows_per_tile != 0)
+  { // the partial last tile, masked
+    a.tile0 = full;
+    const dim3 grid(1, narr, 1);
+#define M(LEN) LAUNCH((k_xfwd<LEN, true>), grid, dim3(Geo<LEN>::THREADS), a)
+    KW_LEN_SWITCH(c.nx, M)
+#undef M
+  }
   return KW_OK;
 }
 
@@ -1580,6 +1712,7 @@ kw_status launch_ypass(kw_ctx* ctx, int dir, int narr, float2* const* in, float2
   a.aout = pack_out ? packed : natural;
   a.narr = f.ypass_loop ? narr : 1;
   a.z0   = z0;
+  a.colt = (f.colt && c.nx_complex % static_cast<uint32_t>((c.ny == 512 && f.split512) ? NLMAX : nl_of(c.ny)) == 1u) ? 1u : 0u;
   if (c.ny == 512 && f.split512)
   { // 2 x 256 lines: 16-column tiles, one array per block
     a.narr = 1;
@@ -1621,6 +1754,7 @@ template<int MODE> kw_status launch_zfused(kw_ctx* ctx, int narr, ZArgs a)
   a.nz      = f.nz_global;
   a.ky0     = f.rank * f.nyl;
   a.narr    = narr;
+  a.colt    = (f.colt && c.nx_complex % static_cast<uint32_t>((f.nz_global == 512 && f.split512) ? NLMAX : nl_of(f.nz_global)) == 1u) ? 1u : 0u;
   if (f.nz_global == 512 && f.split512)
   {
     LAUNCH((k_zfused_split<512, MODE>), dim3(f.P / NLMAX, f.nyl, narr), dim3(Geo<256>::THREADS), a);
@@ -1652,12 +1786,27 @@ kw_status launch_xinv_impl(kw_ctx* ctx, int ncomp, XinvArgs a, uint32_t z0, uint
   a.tw = ctx->fused.tw[0];
   a.c  = c;
   a.P  = ctx->fused.P;
-  a.tile0 = z0 * c.ny / (2 * nl_of(c.nx));
+  a.nrows = c.ny * c.nz;
   a.descending = ctx->fused.xinv_desc ? 1u : 0u;
-  const dim3 grid(c.ny * (nzc ? nzc : c.nz) / (2 * nl_of(c.nx)), ncomp, 1);
-#define M(LEN) LAUNCH((k_xinv<LEN, EPI, CHAIN, TERMS>), grid, dim3(Geo<LEN>::THREADS), a)
-  KW_LEN_SWITCH(c.nx, M)
+  const uint32_t rows_per_tile = 2u * static_cast<uint32_t>(nl_of(c.nx));
+  const uint32_t rows = c.ny * (nzc ? nzc : c.nz), full = rows / rows_per_tile;
+  a.tile0 = z0 * c.ny / rows_per_tile; // chunked launches start on tile boundaries (plane_local_tail)
+  if (full > 0)
+  {
+    const dim3 grid(full, ncomp, 1);
+#define M(LEN) LAUNCH((k_xinv<LEN, EPI, CHAIN, TERMS, false>), grid, dim3(Geo<LEN>::THREADS), a)
+    KW_LEN_SWITCH(c.nx, M)
 #undef M
+  }
+  if (rows % rows_per_tile != 0)
+  { // the partial last tile of the grid, masked (only ever the last chunk: chunks are whole tiles otherwise)
+    a.tile0 += full;
+    a.descending = 0u;
+    const dim3 grid(1, ncomp, 1);
+#define M(LEN) LAUNCH((k_xinv<LEN, EPI, CHAIN, TERMS, true>), grid, dim3(Geo<LEN>::THREADS), a)
+    KW_LEN_SWITCH(c.nx, M)
+#undef M
+  }
   return KW_OK;
 }
 #endif
@@ -1873,6 +2022,8 @@ kw_status create_impl(kw_ctx* ctx, void* const s[3], void* const t[3])
     f.split512    = (e == nullptr) || (e[0] != '0');
     e             = getenv("KW_FUSED_YPASS_LOOP");
     f.ypass_loop  = (e == nullptr) || (e[0] != '0');
+    e             = getenv("KW_FUSED_COLT");
+    f.colt        = (e != nullptr) && (e[0] != '0');
   }
   f.ready = true;
   return KW_OK;
@@ -1961,9 +2112,8 @@ kw_status kw_fused_supported(kw_ctx* ctx, int* out)
   const kw_constants& c = ctx->c;
   const auto& f         = ctx->fused;
   const uint32_t nzg    = (f.slab) ? f.nz_global : c.nz;
-  // the x kernels work on tiles of 2 * NL rows (32; 16 from Nx = 400 on): Ny * Nz (local) must be a whole number of tiles
-  bool ok = supported_len(c.nx) && supported_len(c.ny) && supported_len(nzg) &&
-            ((c.ny * c.nz) % (2u * static_cast<uint32_t>(nl_of(static_cast<int>(c.nx)))) == 0);
+  // (the x kernels work on tiles of 2 * NL rows; a row count Ny * Nz that is no whole number of tiles ends in one masked tile)
+  bool ok = supported_len(c.nx) && supported_len(c.ny) && supported_len(nzg);
   if (f.slab) ok = ok && (nzg == c.nz * f.nranks) && (c.ny % f.nranks == 0);
   const uint64_t P64 = (c.nx_complex + NLMAX - 1) / NLMAX * NLMAX;
   ok = ok && (P64 * c.ny * c.nz < (1ull << 32)) && (static_cast<uint64_t>(c.nx) * c.ny * c.nz < (1ull << 32));
@@ -2241,11 +2391,22 @@ kw_status kw_fused_shift_velocity(kw_ctx* ctx, int axis, const float* in, float*
   KW_PROF(ctx, names[axis]);
   if (axis == 0)
   {
-    XshiftArgs a{ in, out, f.tw[0], reinterpret_cast<const float2*>(filter) };
-    const dim3 grid(c.ny * c.nz / (2 * nl_of(c.nx)), 1, 1);
-#define M(LEN) LAUNCH((k_xshift<LEN>), grid, dim3(Geo<LEN>::THREADS), a)
-    KW_LEN_SWITCH(c.nx, M)
+    XshiftArgs a{ in, out, f.tw[0], reinterpret_cast<const float2*>(filter), c.ny * c.nz, 0u };
+    const uint32_t rows_per_tile = 2u * static_cast<uint32_t>(nl_of(c.nx)), full = a.nrows / rows_per_tile;
+    if (full > 0)
+    {
+      const dim3 grid(full, 1, 1);
+#define M(LEN) LAUNCH((k_xshift<LEN, false>), grid, dim3(Geo<LEN>::THREADS), a)
+      KW_LEN_SWITCH(c.nx, M)
 #undef M
+    }
+    if (a.nrows % rows_per_tile != 0)
+    {
+      a.tile0 = full;
+#define M(LEN) LAUNCH((k_xshift<LEN, true>), dim3(1, 1, 1), dim3(Geo<LEN>::THREADS), a)
+      KW_LEN_SWITCH(c.nx, M)
+#undef M
+    }
     return KW_OK;
   }
   // y / z: the real array is read as nx/2 complex columns; lines run along the axis with the matching stride

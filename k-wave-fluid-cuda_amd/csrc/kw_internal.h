@@ -45,6 +45,7 @@ struct kw_ctx
     bool     per_array = false;                    // launch order: chain per array instead of batched (A/B knob; batched is faster)
     bool     ypass_loop = true;                    // y-pass blocks walk the arrays of a launch (prefetching) instead of one array per block
     bool     split512 = true;                      // 512-point y / z lines as 2 x 256 (A/B knob against the 16 x 32 kernels)
+    bool     colt = false;                         // x-Nyquist column handled by column tiles in the y / z passes (KW_FUSED_COLT=1; measured slower)
     bool     xinv_desc = false;                    // x-inverse kernels take their tiles last-to-first (KW_FUSED_XINV_DESC)
     uint32_t zchunks = 1;                          // plane-local passes (y^-1, x^-1 + epilogue, chained x, y) run per chunk of planes
     int      y_done  = 0;                          // chained spectra in s[0..y_done) already carry their forward y-pass

@@ -65,16 +65,22 @@ def test_sampling_starts_at_the_last_step_and_zero_length_legs(orc, syn):
     o.close()
 
 
-def test_sampling_start_beyond_the_run_stores_nothing(syn):
+def test_sampling_start_at_the_end_stores_nothing_and_beyond_is_refused(syn):
+    """-s Nt + 1 (0-based index Nt) is the last start the reference accepts (Parameters.cpp:135-139: index > Nt is
+    "out of the simulation time span"); nothing is sampled then.  Anything later — or -s 0, which wraps around — is an error."""
+    from kwave_amd import capi
     nt = 6
     pr = syn.make_problem(16, heterogeneous=False, nonlinear=False, absorbing=False, source="p0", nt=nt, pml_size=2,
                           sensor="random")
-    g = gpu(pr, p_raw=1, p_max=1, i_avg=1, sampling_start=nt + 3)
+    g = gpu(pr, p_raw=1, p_max=1, i_avg=1, sampling_start=nt)
     g.run(nt)
     g.finish()
     assert g.stream("p").size == 0
     assert not g.stream("Ix_avg").any()
     g.close()
+    for bad in (nt + 1, 2 ** 64 - 1):
+        with pytest.raises(capi.KWaveError, match="beginning of data sampling"):
+            gpu(pr, p_raw=1, sampling_start=bad)
 
 
 @pytest.mark.parametrize("mode", [0, 1, 2])

@@ -167,14 +167,29 @@ def test_fused_line_lengths_mixed_radix(orc, syn, dims):
         assert max(errs.values()) < TOL, (dims, kw, errs)
 
 
-def test_grids_without_whole_x_tiles_take_the_rocfft_path(orc, syn):
-    """Ny * Nz = 100 * 100 is not a multiple of the 32-row x tile of Nx = 300: the solver falls back (same results)."""
-    pr = syn.make_problem(300, 100, 100, heterogeneous=True, nonlinear=True, absorbing=True, source="p0", pml_size=4)
-    g, o = make_gpu(pr, fused_kernels=True), orc.OracleSim(pr)
+@pytest.mark.parametrize("dims,opts", [
+    ((300, 100, 100), {}),                                  # Ny * Nz = 10 000 = 312 tiles of 32 rows + 16 rows
+    ((100, 100, 100), dict(u_non_staggered_raw=1)),         # cube of round 1's rocFFT-path list; the x-shift kernel too
+    ((108, 100, 108), dict(source="p_source", source_mode=2)),  # 10 800 rows; k-space corrected source (EPI_STORE tail)
+    ((64, 100, 300), {}),                                   # power-of-two x lines over a 4 * 25 by 4 * 75 plane
+])
+def test_grids_without_whole_x_tiles_stay_on_the_fused_pipeline(orc, syn, dims, opts):
+    """The x kernels take tiles of 32 (16) rows; a row count Ny * Nz that is no whole number of tiles ends in one masked
+    tile (TAIL kernels) instead of sending the whole grid to the rocFFT path."""
+    opts = dict(opts)
+    source, mode = opts.pop("source", "p0"), opts.pop("source_mode", 0)
+    ny, nz = dims[1], dims[2]
+    pr = syn.make_problem(*dims, heterogeneous=True, nonlinear=True, absorbing=True, source=source, source_mode=mode,
+                          pml_size=4 if min(dims) >= 20 else 2, sensor="random", nt=12)
+    assert (ny * nz) % 32 == 16  # (the fused line lengths are multiples of 4: a partial tile is always half a tile)
+    g, o = make_gpu(pr, fused_kernels=True, p_raw=1, **opts), orc.OracleSim(pr)
     g.run(10)
-    assert g.scalar("fused_pipeline") == 0.0
+    assert g.scalar("fused_pipeline") == 1.0
     o.step(10)
-    assert rel_l2(g.field("p"), o.field("p")) < TOL
+    for f in ("p", "ux", "uz", "rhoy"):
+        assert rel_l2(g.field(f), o.field(f)) < TOL, f
+    if "u_non_staggered_raw" in opts:
+        assert rel_l2(g.field("ux_shifted"), orc.shifted_velocity(g.field("ux"), pr["x_shift_neg_r"], 0)) < TOL
     g.close()
     o.close()
 
