@@ -366,6 +366,12 @@ KW_API kw_status kw_fused_density(kw_ctx* ctx, int nonlinear, const float* ux_sg
                                   float* t2, int flags);
 /* absorbing branch of computePressure{Nonlinear,Linear} after the terms (KSpaceFirstOrderSolver.cpp:2196-2204,
  * 2231-2239; .cu:1812-1820,1865-1879,1966-1980): first = nonlinear term or density sum */
+/* computeVelocityGradient alone (KSpaceFirstOrderSolver.cpp:2126-2143, SolverCudaKernels.cu:1210-1239): the three
+ * gradients as arrays, for loops that put a step between them and the density update (non-uniform grids, :2145-2149) */
+KW_API kw_status kw_fused_velocity_gradient(kw_ctx* ctx, const float* ux_sgx, const float* uy_sgy, const float* uz_sgz,
+                                            float* duxdx, float* duydy, float* duzdz, const float* kappa_padded,
+                                            const float* ddx_k_shift_neg_r, const float* ddy_k_shift_neg,
+                                            const float* ddz_k_shift_neg, int flags /* KW_FUSED_U_IN_SCRATCH */);
 KW_API kw_status kw_fused_absorption_pressure(kw_ctx* ctx, float* p, const float* velocity_gradient_term,
                                               const float* density_sum, const float* first,
                                               const float* nabla1_padded, const float* nabla2_padded, const float* c2,
@@ -410,6 +416,15 @@ KW_API kw_status kw_sample_index_compress(kw_ctx* ctx, float* c1, float* c2, con
                                           const uint64_t* sensor_data, uint64_t n_samples, uint32_t harmonics,
                                           const float* bE, const float* bE_1, uint32_t b_size, uint32_t step_local,
                                           int mirror_first_half_frame);
+/* --40-bit_complex (IndexOutputStream.cpp:410-436; codec Compression/CompressHelper.cpp:224-389): the accumulators are
+ * [n_samples][harmonics] 5-byte packed complex numbers, decoded, updated and re-encoded at every sampled step; max_exp =
+ * 138 (pressure) / 114 (velocity).  no_overlap: one buffer (c2 unused), c1 += bE*x + bE_1*x. */
+KW_API kw_status kw_sample_index_compress_40b(kw_ctx* ctx, void* c1, void* c2, const float* source_data,
+                                              const uint64_t* sensor_data, uint64_t n_samples, uint32_t harmonics,
+                                              const float* bE, const float* bE_1, uint32_t b_size, uint32_t step_local,
+                                              int mirror_first_half_frame, int no_overlap, int max_exp);
+KW_API kw_status kw_intensity_avg_c_accumulate_40b(kw_ctx* ctx, float* iavg, const void* frame_p, const void* frame_u,
+                                                   uint64_t n_samples, uint32_t harmonics, int max_exp_p, int max_exp_u);
 /* IndexOutputStream::postSample for kIAvgC (IndexOutputStream.cpp:299-342): iavg[i] += sum_h Re(P[i,h]*conj(U[i,h]))/2 */
 KW_API kw_status kw_intensity_avg_c_accumulate(kw_ctx* ctx, float* iavg, const float* frame_p, const float* frame_u,
                                                uint64_t n_samples, uint32_t harmonics);

@@ -59,11 +59,15 @@ typedef struct kwh_options
   int32_t  i_avg, q_term, q_term_c;
   int32_t  u_c;        /* --u_c: compression coefficients of the staggered velocities (OutputStreamContainer.cpp:133-142) */
   float    frequency;  /* --frequency [Hz]: period = 1 / (frequency * dt) (Parameters.cpp:468-480); not together with period */
-  int32_t  reserved_;
+  int32_t  only_post_processing; /* --post: no time loop; I_avg / I_avg_c / Q_term / Q_term_c from the series stored in an
+                                    existing output file (KSpaceFirstOrderSolver.cpp:373-415; kwh_post_process_output_file) */
   /* slab runs over the library's own RCCL path (the default multi-GPU exchange): KW_COMM_ID_BYTES bytes from
    * kw_comm_unique_id() on rank 0, the same on every rank; exchange_fn / exchange_start_fn must then be NULL.
    * With slab_ranks == 1 the rank exchanges with itself (rehearsal of the multi-GPU path on one GPU). */
   const void* comm_unique_id;
+  int32_t  complex_40bit; /* --40-bit_complex: compression coefficients kept and stored as 5-byte complex numbers
+                             (CompressHelper.cpp:224-389; BaseOutputStream.cpp:98-101: c_complex_size 1.25) */
+  int32_t  reserved_;
 } kwh_options;
 
 KWH_API const char* kwh_last_error(void);

@@ -144,6 +144,7 @@ _SIG: Dict[str, list] = {
     "kw_fused_velocity": [_P] + [_P] * 14 + [C.c_int],
     "kw_fused_initial_velocity": [_P] + [_P] * 11,
     "kw_fused_density": [_P, C.c_int] + [_P] * 14 + [_P] * 3 + [C.c_int, _P, _P, _P, _P, C.c_int],
+    "kw_fused_velocity_gradient": [_P] + [_P] * 10 + [C.c_int],
     "kw_fused_absorption_pressure": [_P] + [_P] * 9 + [C.c_int],
     "kw_fused_scale_source": [_P, _P, _P],
     "kw_fused_probe": [_P, C.c_int, _P],
@@ -153,6 +154,8 @@ _SIG: Dict[str, list] = {
     "kw_sample_all": [_P, C.c_int, _P, _P, _U64],
     "kw_post_processing_rms": [_P, _P, C.c_float, _U64],
     "kw_sample_index_compress": [_P, _P, _P, _P, _P, _U64, C.c_uint32, _P, _P, C.c_uint32, C.c_uint32, C.c_int],
+    "kw_sample_index_compress_40b": [_P, _P, _P, _P, _P, _U64, C.c_uint32, _P, _P, C.c_uint32, C.c_uint32, C.c_int, C.c_int, C.c_int],
+    "kw_intensity_avg_c_accumulate_40b": [_P, _P, _P, _P, _U64, C.c_uint32, C.c_int, C.c_int],
     "kw_intensity_avg_c_accumulate": [_P, _P, _P, _P, _U64, C.c_uint32],
     "kw_time_shift_series": [_P, _P, _P, _U64, _U64],
     "kw_intensity_avg": [_P, _P, _P, _P, _U64, _U64],

@@ -1815,15 +1815,19 @@ kw_status launch_xinv_impl(kw_ctx* ctx, int ncomp, XinvArgs a, uint32_t z0, uint
 
 // split-phase exchange of scratch array `slot`: start is ordered after the work enqueued so far; wait orders later
 // work after its completion.  Without asynchronous callbacks, start is the blocking exchange and wait a no-op.
-kw_status xstart(kw_ctx* ctx, int slot, float2* send, float2* recv)
+kw_status xstart_bytes(kw_ctx* ctx, int slot, void* send, void* recv, size_t bytes_per_peer)
 {
   const auto& f = ctx->fused;
-  const size_t bytes_per_peer = static_cast<size_t>(ctx->c.nz) * f.nyl * f.PX * sizeof(float2);
   if (f.exchange_start == nullptr && f.exchange == nullptr) return kw_comm_exchange_start(ctx, slot, send, recv, bytes_per_peer);
   const int rc = (f.exchange_start != nullptr) ? f.exchange_start(f.exchange_user, send, recv, bytes_per_peer, slot)
                                                : f.exchange(f.exchange_user, send, recv, bytes_per_peer);
   if (rc != 0) { kw_set_error("slab exchange: the caller's exchange callback failed (status %d)", rc); return KW_ERR_COMM; }
   return KW_OK;
+}
+kw_status xstart(kw_ctx* ctx, int slot, float2* send, float2* recv)
+{ // one spectral scratch array: nz local planes x nyl rows per peer
+  const auto& f = ctx->fused;
+  return xstart_bytes(ctx, slot, send, recv, static_cast<size_t>(ctx->c.nz) * f.nyl * f.PX * sizeof(float2));
 }
 kw_status xwait(kw_ctx* ctx, int slot)
 {
@@ -2325,6 +2329,35 @@ kw_status kw_fused_density(kw_ctx* ctx, int nonlinear, const float* ux, const fl
   return KW_OK;
 }
 
+// A6-A8 only: du_i/dx_i = ifftn(ddk_i_neg * kappa * fftn(u_i)) / N stored as arrays — for callers that put something
+// between the gradient and the density update (non-uniform grids: duxdx *= dxudxn, SolverCudaKernels.cu:1285-1301)
+kw_status kw_fused_velocity_gradient(kw_ctx* ctx, const float* ux, const float* uy, const float* uz, float* duxdx,
+                                     float* duydy, float* duzdz, const float* kappa_padded, const float* ddx, const float* ddy,
+                                     const float* ddz, int flags)
+{
+  KW_FUSED_READY(ctx);
+  KW_PROF(ctx, "fused_velocity_gradient");
+  KW_REQUIRE(ux && uy && uz && duxdx && duydy && duzdz && kappa_padded && ddx && ddy && ddz);
+  const bool u_in_scratch = (flags & KW_FUSED_U_IN_SCRATCH) != 0;
+  float2** S = ctx->fused.s;
+  const float* in3[3] = { ux, uy, uz };
+  ZArgs z{};
+  for (int i = 0; i < 3; i++) { z.in[i] = S[i]; z.out[i] = S[i]; }
+  z.op[0] = kappa_padded;
+  z.dd[0] = (const float2*)ddx; z.dd[1] = (const float2*)ddy; z.dd[2] = (const float2*)ddz;
+  if (ctx->fused.slab) KW_TRY(slab_chain<Z_VGRAD>(ctx, 3, u_in_scratch ? nullptr : in3, z));
+  else
+  {
+    KW_TRY(forward_xy(ctx, 3, u_in_scratch ? nullptr : in3));
+    KW_TRY(launch_zfused<Z_VGRAD>(ctx, 3, z));
+    KW_TRY(inverse_y(ctx, 3));
+  }
+  XinvArgs x{};
+  float* du[3] = { duxdx, duydy, duzdz };
+  for (int i = 0; i < 3; i++) { x.in[i] = S[i]; x.out[i] = du[i]; }
+  return launch_xinv<EPI_STORE>(ctx, 3, x);
+}
+
 // A11 absorbing branch after the terms: p = c2*(first + d*(tau*ifftn(nabla1*fftn(vel_grad_term)) - eta*ifftn(nabla2*fftn(density_sum))))
 kw_status kw_fused_absorption_pressure(kw_ctx* ctx, float* p, const float* vel_grad_term, const float* density_sum,
                                        const float* first, const float* nabla1_padded, const float* nabla2_padded,
@@ -2386,9 +2419,47 @@ kw_status kw_fused_shift_velocity(kw_ctx* ctx, int axis, const float* in, float*
   KW_FUSED_READY(ctx);
   auto& f = ctx->fused;
   const kw_constants& c = ctx->c;
-  KW_REQUIRE(!f.slab && axis >= 0 && axis <= 2 && in != nullptr && out != nullptr && filter != nullptr);
+  KW_REQUIRE(axis >= 0 && axis <= 2 && in != nullptr && out != nullptr && filter != nullptr);
   static const char* const names[3] = { "k_xshift", "k_zfused_shift_y", "k_zfused_shift_z" };
   KW_PROF(ctx, names[axis]);
+  if (f.slab && axis == 2)
+  { // lines along z cross the slabs: the real array travels as [nz local][ny / P rows per peer][nx] chunks to the
+    // owner of each row range ([nz global][nyl][nx] there), is shifted along z and travels back — two exchanges of one
+    // real array per sampled step (KSpaceFirstOrderSolver.cpp:2731-2733 on the decomposed grid).  x and y lines are
+    // slab-local.  Staging: scratch pair 1 (only S[0] carries a chained spectrum between stages).
+    const uint32_t nyl = f.nyl, nzl = c.nz, P = f.nranks;
+    const size_t   row = static_cast<size_t>(c.nx) * sizeof(float), chunk = static_cast<size_t>(nzl) * nyl * c.nx;
+    float* snd = reinterpret_cast<float*>(f.s[1]);
+    float* rcv = reinterpret_cast<float*>(f.t[1]);
+    for (uint32_t q = 0; q < P; q++)
+      KW_HIP(hipMemcpy2DAsync(snd + q * chunk, nyl * row, in + static_cast<size_t>(q) * nyl * c.nx, c.ny * row, nyl * row, nzl,
+                              hipMemcpyDeviceToDevice, ctx->stream));
+    KW_TRY(xstart_bytes(ctx, 1, snd, rcv, chunk * sizeof(float)));
+    KW_TRY(xwait(ctx, 1));
+    ZArgs z{};
+    z.in[0]   = reinterpret_cast<const float2*>(rcv);
+    z.out[0]  = reinterpret_cast<float2*>(rcv);
+    z.dd[2]   = reinterpret_cast<const float2*>(filter);
+    z.tw      = f.tw[2];
+    z.nxc     = c.nx / 2;
+    z.P       = c.nx / 2;
+    z.ny      = nyl;
+    z.nz      = f.nz_global;
+    z.narr    = 1;
+    z.lstride = nyl * z.P;
+    z.bstride = z.P;
+    const uint32_t nl = nl_of(f.nz_global);
+    const dim3 grid((z.nxc + nl - 1) / nl, nyl, 1);
+#define M(LEN) LAUNCH((k_zfused<LEN, Z_SHIFT>), grid, dim3(Geo<LEN>::THREADS), z)
+    KW_LEN_SWITCH(f.nz_global, M)
+#undef M
+    KW_TRY(xstart_bytes(ctx, 1, rcv, snd, chunk * sizeof(float)));
+    KW_TRY(xwait(ctx, 1));
+    for (uint32_t q = 0; q < P; q++)
+      KW_HIP(hipMemcpy2DAsync(out + static_cast<size_t>(q) * nyl * c.nx, c.ny * row, snd + q * chunk, nyl * row, nyl * row, nzl,
+                              hipMemcpyDeviceToDevice, ctx->stream));
+    return KW_OK;
+  }
   if (axis == 0)
   {
     XshiftArgs a{ in, out, f.tw[0], reinterpret_cast<const float2*>(filter), c.ny * c.nz, 0u };

@@ -123,6 +123,119 @@ __global__ __launch_bounds__(256) void k_sample_index_compress(float2* c1, float
   }
 }
 
+// ---- --40-bit_complex: accumulators and frames held as 5-byte complex numbers (Compression/CompressHelper.cpp:224-389):
+// byte 0 = sign(re) | sign(im) | top mantissa bit of re | of im | 4-bit shared exponent (biased by e: 138 pressure,
+// 114 velocity); bytes 1-2 / 3-4 = the low 16 bits of the 17-bit mantissas (explicit leading one).  The reference
+// decodes, adds and re-encodes the accumulator of every (point, harmonic) at every sampled step
+// (IndexOutputStream.cpp:410-436) — the rounding of that round trip is part of the result, so it is done here too.
+__device__ __forceinline__ uint32_t pack40_mantissa(uint32_t fraction, uint32_t shift)
+{
+  uint32_t m = fraction >> shift;
+  if (m > 0u && m != (0x7FFFFFu >> shift)) m++; // round up unless the field is all ones
+  m |= 1u << (23u - shift);                       // the float's hidden one becomes an explicit bit
+  return m >> 1;
+}
+__device__ __forceinline__ void pack40(float2 v, uint8_t* out, int e)
+{
+  const uint32_t bR = __float_as_uint(v.x), bI = __float_as_uint(v.y);
+  const uint32_t sR = bR >> 31, sI = bI >> 31;
+  const int eR = static_cast<int>((bR & 0x7F800000u) >> 23) - e, eI = static_cast<int>((bI & 0x7F800000u) >> 23) - e;
+  int      eS = max(eR, eI); // shared exponent: the larger one; the other mantissa is shifted down by the difference
+  uint32_t shR = 6u + static_cast<uint32_t>(eS - eR), shI = 6u + static_cast<uint32_t>(eS - eI);
+  if (eS < 0)
+  { // below the range: denormalise against exponent 0
+    shR += static_cast<uint32_t>(-eS);
+    shI += static_cast<uint32_t>(-eS);
+    eS = 0;
+  }
+  shR = min(shR, 23u);
+  shI = min(shI, 23u);
+  uint32_t mR = pack40_mantissa(bR & 0x007FFFFFu, shR), mI = pack40_mantissa(bI & 0x007FFFFFu, shI);
+  if (eS > 0xF)
+  { // above the range: saturate
+    mR = mI = 0xFFFFu;
+    eS = 0xF;
+  }
+  out[0] = static_cast<uint8_t>((sR << 7) | (sI << 6) | ((mR & 0x10000u) >> 11) | ((mI & 0x10000u) >> 12) | (static_cast<uint32_t>(eS) & 0xFu));
+  out[1] = static_cast<uint8_t>(mR & 0xFFu);
+  out[2] = static_cast<uint8_t>((mR >> 8) & 0xFFu);
+  out[3] = static_cast<uint8_t>(mI & 0xFFu);
+  out[4] = static_cast<uint8_t>((mI >> 8) & 0xFFu);
+}
+__device__ __forceinline__ float unpack40_component(uint32_t field17, uint32_t sign, int exponent)
+{
+  uint32_t m = field17 << 6;
+  if (m == 0u) return __uint_as_float(sign << 31);
+  const int index = 31 - __clz(static_cast<int>(m)); // position of the explicit leading one
+  m <<= 23 - index;
+  exponent -= 22 - index;
+  return __uint_as_float((sign << 31) | (static_cast<uint32_t>(exponent) << 23) | (m & 0x007FFFFFu));
+}
+__device__ __forceinline__ float2 unpack40(const uint8_t* in, int e)
+{
+  const uint32_t head = in[0];
+  const uint32_t mR = ((head & 0x20u) << 11) | (static_cast<uint32_t>(in[2]) << 8) | in[1];
+  const uint32_t mI = ((head & 0x10u) << 12) | (static_cast<uint32_t>(in[4]) << 8) | in[3];
+  const int ex = static_cast<int>(head & 0xFu) + e;
+  return make_float2(unpack40_component(mR, head >> 7, ex), unpack40_component(mI, (head & 0x40u) >> 6, ex));
+}
+
+__global__ __launch_bounds__(256) void k_sample_index_compress_40b(uint8_t* c1, uint8_t* c2, const float* __restrict__ src,
+                                                                    const uint64_t* __restrict__ mask, uint64_t n,
+                                                                    uint32_t harmonics, const float2* __restrict__ bE,
+                                                                    const float2* __restrict__ bE_1, uint32_t b_size,
+                                                                    uint32_t step_local, int mirror, int no_overlap, int e)
+{
+  for (uint64_t i = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n;
+       i += static_cast<uint64_t>(gridDim.x) * blockDim.x)
+  {
+    const float x = src[mask[i]];
+    for (uint32_t h = 0; h < harmonics; h++)
+    {
+      const uint64_t ph = (harmonics * i + h) * 5u;
+      const float2   b0 = bE[static_cast<size_t>(h) * b_size + step_local];
+      const float2   b1 = bE_1[static_cast<size_t>(h) * b_size + step_local];
+      float2 cc1 = unpack40(c1 + ph, e);
+      if (no_overlap)
+      { // IndexOutputStream.cpp:416-421: one buffer, cc1 += bE*x + bE_1*x
+        cc1.x += b0.x * x + b1.x * x;
+        cc1.y += b0.y * x + b1.y * x;
+        pack40(cc1, c1 + ph, e);
+        continue;
+      }
+      float2 cc2 = unpack40(c2 + ph, e);
+      cc1.x += b0.x * x;
+      cc1.y += b0.y * x;
+      cc2.x += b1.x * x;
+      cc2.y += b1.y * x;
+      pack40(cc1, c1 + ph, e);
+      if (mirror)
+      { // :431-435: the first half frame mirrored onto the second buffer, from the unquantised sums
+        cc2.x += cc1.x;
+        cc2.y += cc1.y;
+      }
+      pack40(cc2, c2 + ph, e);
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void k_intensity_avg_c_40b(float* __restrict__ iavg, const uint8_t* __restrict__ P,
+                                                              const uint8_t* __restrict__ U, uint64_t n, uint32_t harmonics,
+                                                              int e_p, int e_u)
+{ // IndexOutputStream.cpp:315-339 with the frames decoded first (:325-329)
+  for (uint64_t i = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n;
+       i += static_cast<uint64_t>(gridDim.x) * blockDim.x)
+  {
+    float acc = iavg[i];
+    for (uint32_t h = 0; h < harmonics; h++)
+    {
+      const float2 p = unpack40(P + (harmonics * i + h) * 5u, e_p), u = unpack40(U + (harmonics * i + h) * 5u, e_u);
+      acc += (p.x * u.x + p.y * u.y) / 2.0f;
+    }
+    iavg[i] = acc;
+  }
+}
+
 // I_avg_c accumulation from one emitted pair of coefficient frames (IndexOutputStream.cpp:315-339):
 // iavg[i] += sum_h real(P * conj(U)) / 2
 __global__ __launch_bounds__(256) void k_intensity_avg_c(float* __restrict__ iavg, const float2* __restrict__ P,
@@ -271,6 +384,32 @@ kw_status kw_sample_index_compress(kw_ctx* ctx, float* c1, float* c2, const floa
   KW_REQUIRE(harmonics >= 1 && b_size >= 3 && step_local < b_size);
   LAUNCH(k_sample_index_compress, dim3(sampler_grid(ctx, n)), dim3(256), (float2*)c1, (float2*)c2, src, mask, n,
          harmonics, (const float2*)bE, (const float2*)bE_1, b_size, step_local, mirror_first_half_frame);
+  return KW_OK;
+}
+
+kw_status kw_sample_index_compress_40b(kw_ctx* ctx, void* c1, void* c2, const float* src, const uint64_t* mask, uint64_t n,
+                                       uint32_t harmonics, const float* bE, const float* bE_1, uint32_t b_size,
+                                       uint32_t step_local, int mirror_first_half_frame, int no_overlap, int max_exp)
+{
+  KW_CHECK_CTX(ctx);
+  KW_PROF(ctx, "sample_index_compress_40b");
+  if (n == 0) return KW_OK;
+  KW_REQUIRE(c1 && (c2 || no_overlap) && src && mask && bE && bE_1);
+  KW_REQUIRE(harmonics >= 1 && b_size >= 3 && step_local < b_size);
+  LAUNCH(k_sample_index_compress_40b, dim3(sampler_grid(ctx, n)), dim3(256), (uint8_t*)c1, (uint8_t*)c2, src, mask, n,
+         harmonics, (const float2*)bE, (const float2*)bE_1, b_size, step_local, mirror_first_half_frame, no_overlap, max_exp);
+  return KW_OK;
+}
+
+kw_status kw_intensity_avg_c_accumulate_40b(kw_ctx* ctx, float* iavg, const void* frame_p, const void* frame_u, uint64_t n,
+                                            uint32_t harmonics, int max_exp_p, int max_exp_u)
+{
+  KW_CHECK_CTX(ctx);
+  KW_PROF(ctx, "intensity_avg_c_accumulate_40b");
+  if (n == 0) return KW_OK;
+  KW_REQUIRE(iavg && frame_p && frame_u && harmonics >= 1);
+  LAUNCH(k_intensity_avg_c_40b, dim3(sampler_grid(ctx, n)), dim3(256), iavg, (const uint8_t*)frame_p, (const uint8_t*)frame_u,
+         n, harmonics, max_exp_p, max_exp_u);
   return KW_OK;
 }
 

@@ -10,7 +10,7 @@ the fused z-pass on `Ny/P` rows with all `Nz` planes, and the mirror image on th
   "host"    device -> pinned host -> gloo all-to-all -> device, for ranks that share one GPU (tests).
 
 partition_problem() cuts a global problem dict (HDF5 dataset names) into the slab of one rank:
-  * 3-D arrays, pml_z, pml_z_sgz         -> planes z0 <= z < z1
+  * 3-D arrays, pml_z, pml_z_sgz, dzudzn* -> planes z0 <= z < z1
   * source / sensor index masks (1-based) -> entries inside the slab, re-based to the slab, original order kept
   * per-point source series, delay mask    -> the matching columns
   * everything else (scalars, x/y PML, ddx/ddy/ddz operators) unchanged; "Nz" becomes the local plane count.
@@ -70,7 +70,7 @@ def partition_problem(pr: Dict[str, np.ndarray], rank: int, nranks: int, arrays_
             out[name] = np.ascontiguousarray(a[z0:z1])
         elif arrays_are_local and a.ndim == 3 and a.shape == (z1 - z0, ny, nx):
             out[name] = a
-        elif name in ("pml_z", "pml_z_sgz"):
+        elif name in ("pml_z", "pml_z_sgz", "dzudzn", "dzudzn_sgz"):
             out[name] = np.ascontiguousarray(a.reshape(-1)[z0:z1])
         elif name == "p_source_index":
             out[name] = p_loc.reshape(1, 1, -1)

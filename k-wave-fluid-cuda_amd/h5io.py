@@ -244,6 +244,11 @@ class FileSolver(HostSolver):
     def write_output(self, path: str, compression_level: int = 0, copy_sensor_mask: bool = False):
         _h5check(self.L.kwh_write_output_file_ex(self._h, path.encode(), compression_level, int(copy_sensor_mask)))
 
+    def post_process(self, path: str):
+        """--post: compute I_avg / I_avg_c / Q_term / Q_term_c from the series stored in the output file `path` and add
+        them to it (the solver must have been created with only_post_processing=1)."""
+        _h5check(self.L.kwh_post_process_output_file(self._h, path.encode()))
+
     def write_checkpoint(self, path: str):
         """State arrays, time index and stream states -> checkpoint file (KSpaceFirstOrderSolver.cpp:1176-1224)."""
         _h5check(self.L.kwh_checkpoint_write(self._h, path.encode()))

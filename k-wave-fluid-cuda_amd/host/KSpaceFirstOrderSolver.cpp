@@ -71,9 +71,7 @@ void KSpaceFirstOrderSolver::initializeFftPlans()
                               static_cast<uint32_t>(opt.nzGlobal), opt.exchangeFn, opt.exchangeUser));
   if (mParameters.isSlabDecomposed() && opt.exchangeStartFn != nullptr)
     kwCheck(kw_fused_set_slab_async(ctx, opt.exchangeStartFn, opt.exchangeWaitFn));
-  // non-uniform grids run the launch-per-kernel path (their gradient scaling is a kernel of its own there, .cu:1285-1301)
-  if ((opt.fusedKernels && mParameters.getNonUniformGridFlag() == 0) || mParameters.isSlabDecomposed())
-    kwCheck(kw_fused_supported(ctx, &fusedOk));
+  if (opt.fusedKernels || mParameters.isSlabDecomposed()) kwCheck(kw_fused_supported(ctx, &fusedOk));
   mFused = (fusedOk != 0);
   if (mParameters.isSlabDecomposed() && !mFused)
     throw std::invalid_argument("Z-slab decomposition needs the fused pipeline (supported line lengths; Ny and Nz divisible by the rank count)");
@@ -87,8 +85,8 @@ void KSpaceFirstOrderSolver::initializeFftPlans()
     HipFftComplexMatrix::createR2CFftPlanND(dims);
     HipFftComplexMatrix::createC2RFftPlanND(dims);
   }
-  if (mParameters.needsShiftedVelocity())
-  {
+  if (mParameters.needsShiftedVelocity() && !mParameters.isSlabDecomposed())
+  { // (slab runs shift through the fused pipeline only: the z lines cross the slabs, kw_fused_shift_velocity)
     HipFftComplexMatrix::createR2CFftPlan1DX(dims);
     HipFftComplexMatrix::createR2CFftPlan1DY(dims);
     if (mParameters.isSimulation3D()) HipFftComplexMatrix::createR2CFftPlan1DZ(dims);
@@ -272,6 +270,10 @@ template<SD sd> void KSpaceFirstOrderSolver::postProcessing()
   PhaseTimer timer(mPhaseTime[3]);
   // average intensity from the stored p and u_non_staggered series (:982-987)
   if (mParameters.getStoreQTermFlag() || mParameters.getStoreIntensityAvgFlag()) computeAverageIntensities();
+  // --post: the intensity of the compression path from the stored coefficient frames (:989-996); a simulating run has
+  // accumulated it frame by frame already
+  if (mParameters.getOnlyPostProcessingFlag() && (mParameters.getStoreQTermCFlag() || mParameters.getStoreIntensityAvgCFlag()))
+    computeAverageIntensitiesC();
   mOutputStreamContainer.postProcessStreams();
   // volume rate of heat deposition from the average intensity (:1001-1021)
   if (mParameters.getStoreQTermFlag())
@@ -376,6 +378,35 @@ void KSpaceFirstOrderSolver::computeAverageIntensities()
     if (BaseOutputStream* us = mOutputStreamContainer.get(ui[a])) us->releaseSeries();
 }
 
+void KSpaceFirstOrderSolver::computeAverageIntensitiesC()
+{ // :1541-1780: frame by frame, I += sum_h Re(P conj(U)) / 2; the mean over the frames is taken by the stream's postProcess
+  using OI = OutputStreamContainer::OutputStreamIdx;
+  BaseOutputStream* pc = mOutputStreamContainer.get(OI::kPressureC);
+  const OI ui[3] = {OI::kVelocityXNonStaggeredC, OI::kVelocityYNonStaggeredC, OI::kVelocityZNonStaggeredC};
+  const OI ii[3] = {OI::kIntensityXAvgC, OI::kIntensityYAvgC, OI::kIntensityZAvgC};
+  if (pc == nullptr) throw std::runtime_error("computeAverageIntensitiesC: the stream p_c is missing");
+  pc->loadSeries();
+  const size_t frames = pc->sampledSteps(), floats = pc->size();
+  for (int a = 0; a < (mParameters.isSimulation3D() ? 3 : 2); a++)
+  {
+    BaseOutputStream* uc = mOutputStreamContainer.get(ui[a]);
+    auto* is = dynamic_cast<IntensityAvgCOutputStream*>(mOutputStreamContainer.get(ii[a]));
+    if (uc == nullptr || is == nullptr) throw std::runtime_error("computeAverageIntensitiesC: stream missing");
+    uc->loadSeries();
+    if (uc->sampledSteps() != frames || uc->size() != floats) throw std::runtime_error("computeAverageIntensitiesC: p_c and u_c series differ in shape");
+    for (size_t f = 0; f < frames; f++) is->accumulateStoredFrames(pc->dataset().data() + f * floats, uc->dataset().data() + f * floats);
+    uc->releaseSeries();
+  }
+  pc->releaseSeries();
+}
+
+void KSpaceFirstOrderSolver::postProcessStoredOutput()
+{ // compute() of a --post run (:373-415): no time loop, straight to the post-processing of what the output file holds
+  prepare();
+  mParameters.setTimeIndex(mParameters.getNt());
+  postProcessing<SD::k3D>();
+}
+
 void KSpaceFirstOrderSolver::computeQTerm(OutputStreamContainer::OutputStreamIdx intensityX,
                                           OutputStreamContainer::OutputStreamIdx intensityY,
                                           OutputStreamContainer::OutputStreamIdx intensityZ,
@@ -465,6 +496,21 @@ template<SD sd> void KSpaceFirstOrderSolver::computeVelocity()
 
 template<SD sd> void KSpaceFirstOrderSolver::computeVelocityGradient()
 { // :2126-2150
+  if (mFused && mParameters.getNonUniformGridFlag() != 0)
+  { // non-uniform grid: the gradient scaling sits between the gradient and the density update (:2145-2149), so the
+    // gradients are produced as arrays by the fused FFT passes and the element-wise kernels of the reference follow
+    const MatrixContainer& c = mMatrixContainer;
+    kwCheck(kw_fused_velocity_gradient(mParameters.getHipParameters().getContext(), real(MI::kUxSgx).getDeviceData(),
+                                       real(MI::kUySgy).getDeviceData(), real(MI::kUzSgz).getDeviceData(),
+                                       real(MI::kDuxdx).getDeviceData(), real(MI::kDuydy).getDeviceData(),
+                                       real(MI::kDuzdz).getDeviceData(), mKappaPadded,
+                                       c.getMatrix<ComplexMatrix>(MI::kDdxKShiftNegR).getDeviceData(),
+                                       c.getMatrix<ComplexMatrix>(MI::kDdyKShiftNeg).getDeviceData(),
+                                       c.getMatrix<ComplexMatrix>(MI::kDdzKShiftNeg).getDeviceData(),
+                                       mVelocityChained ? KW_FUSED_U_IN_SCRATCH : 0));
+    SolverHipKernels::computeVelocityGradientShiftNonuniform<sd>(mMatrixContainer);
+    return;
+  }
   if (mFused) return; // folded into the density stage (kw_fused_density)
   getTempHipFftX().computeR2CFftND(real(MI::kUxSgx));
   getTempHipFftY().computeR2CFftND(real(MI::kUySgy));
@@ -521,13 +567,21 @@ void KSpaceFirstOrderSolver::fusedDensity(bool nonlinear)
 
 template<SD sd> void KSpaceFirstOrderSolver::computeDensityNonliner()
 {
-  if (mFused) fusedDensity(true);
-  else SolverHipKernels::computeDensityNonlinear<sd>(mMatrixContainer);
+  if (mFused && mParameters.getNonUniformGridFlag() == 0) fusedDensity(true);
+  else
+  {
+    mTermsFused = mPressureFused = false; // (non-uniform grid on the fused passes: element-wise kernels from here on)
+    SolverHipKernels::computeDensityNonlinear<sd>(mMatrixContainer);
+  }
 }
 template<SD sd> void KSpaceFirstOrderSolver::computeDensityLinear()
 {
-  if (mFused) fusedDensity(false);
-  else SolverHipKernels::computeDensityLinear<sd>(mMatrixContainer);
+  if (mFused && mParameters.getNonUniformGridFlag() == 0) fusedDensity(false);
+  else
+  {
+    mTermsFused = mPressureFused = false;
+    SolverHipKernels::computeDensityLinear<sd>(mMatrixContainer);
+  }
 }
 
 template<SD sd> void KSpaceFirstOrderSolver::computePressureNonlinear()
@@ -738,12 +792,12 @@ void KSpaceFirstOrderSolver::initializeFusedPipeline()
     mNabla2Padded = importPadded(MI::kAbsorbNabla2);
   }
   if (mMatrixContainer.has(MI::kSourceKappa)) mSourceKappaPadded = importPadded(MI::kSourceKappa);
-  if (mParameters.needsShiftedVelocity() && !mParameters.isSlabDecomposed())
+  if (mParameters.needsShiftedVelocity())
   { // filters of the one-kernel-per-axis shift: the half-length shift vectors of the input file extended to full length
     // the way R2C -> multiply -> C2R acts on a real line (imaginary parts of the DC and Nyquist bins are dropped), with
     // the 1/N of the transform pair folded in (the reference multiplies by it in computeVelocityShiftIn*, .cu:2617-2710)
     kw_ctx* ctx = mParameters.getHipParameters().getContext();
-    const DimensionSizes dims = mParameters.getFullDimensionSizes();
+    const DimensionSizes dims = mParameters.getGlobalDimensionSizes(); // z lines have the global length in slab mode
     const size_t n[3]   = {dims.nx, dims.ny, dims.nz};
     const MI     idx[3] = {MI::kXShiftNegR, MI::kYShiftNegR, MI::kZShiftNegR};
     const int    axes   = mParameters.isSimulation3D() ? 3 : 2;

@@ -30,6 +30,7 @@ class KSpaceFirstOrderSolver
   void prepare();                       // initializeFftPlans + preProcessing + constants + copyMatricesToDevice
   void runTimeSteps(size_t nSteps);     // body of computeMainLoop for nSteps (stops at Nt)
   void finish();                        // last delayed flush + postProcessing
+  void postProcessStoredOutput();       // --post: post-processing of the series an existing output file holds
 
   MatrixContainer&       getMatrixContainer() { return mMatrixContainer; }
   OutputStreamContainer& getOutputStreamContainer() { return mOutputStreamContainer; }
@@ -62,6 +63,7 @@ class KSpaceFirstOrderSolver
   template<SD simulationDimension> void computeShiftedVelocity();
   // post-processing of the stored series (KSpaceFirstOrderSolver.cpp:1231-1534, :1783-2080)
   void computeAverageIntensities();
+  void computeAverageIntensitiesC();
   void computeQTerm(OutputStreamContainer::OutputStreamIdx intensityX, OutputStreamContainer::OutputStreamIdx intensityY,
                     OutputStreamContainer::OutputStreamIdx intensityZ, OutputStreamContainer::OutputStreamIdx qTerm);
   std::vector<size_t> sensorGridIndices(); // grid index of every sensor point, in stream-buffer order

@@ -114,6 +114,7 @@ void MatrixContainer::init()
   if (params.needsShiftedVelocity())
   {
     const size_t nxR = fullDims.nx / 2 + 1, nyR = fullDims.ny / 2 + 1, nzR = fullDims.nz / 2 + 1;
+    const size_t nzRGlobal = nzGlobal / 2 + 1; // z lines (and z_shift_neg_r) keep their global length on a slab
     const size_t xCut = nxR * fullDims.ny * fullDims.nz, yCut = fullDims.nx * nyR * fullDims.nz,
                  zCut = fullDims.nx * fullDims.ny * nzR;
     DimensionSizes shiftDims = fullDims;
@@ -127,7 +128,7 @@ void MatrixContainer::init()
     mContainer[MI::kXShiftNegR].set(MT::kComplex, DimensionSizes(nxR, 1, 1), kLoad, kNoCheckpoint, kXShiftNegRName);
     mContainer[MI::kYShiftNegR].set(MT::kComplex, DimensionSizes(1, nyR, 1), kLoad, kNoCheckpoint, kYShiftNegRName);
     if (params.isSimulation3D())
-      mContainer[MI::kZShiftNegR].set(MT::kComplex, DimensionSizes(1, 1, nzR), kLoad, kNoCheckpoint, kZShiftNegRName);
+      mContainer[MI::kZShiftNegR].set(MT::kComplex, DimensionSizes(1, 1, nzRGlobal), kLoad, kNoCheckpoint, kZShiftNegRName);
   }
 
   // ---- temporaries (MatrixContainer.cpp:387-410): alpha_coeff is loaded *into* Temp1 ----

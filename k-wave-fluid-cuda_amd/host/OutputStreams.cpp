@@ -4,6 +4,7 @@
 #include <new>
 
 #include <algorithm>
+#include <cmath>
 #include <cstring>
 #include <limits>
 #include <stdexcept>
@@ -118,6 +119,13 @@ void BaseOutputStream::loadSeries()
   if (!mSink || !isSeries()) return;
   mSink->flush();
   mSink->read(mDataset, mFlushedSteps);
+}
+
+void BaseOutputStream::adoptStoredSeries(size_t rows)
+{ // --post: the series was written by an earlier run; this stream only reads it back
+  if (!mSink || !isSeries()) throw std::runtime_error("stream " + mName + " has no stored series to adopt");
+  mSink->setRows(rows);
+  mSampledSteps = mFlushedSteps = rows;
 }
 
 void BaseOutputStream::copyAggregateFromDevice()
@@ -237,7 +245,10 @@ CompressedIndexOutputStream::~CompressedIndexOutputStream()
 void CompressedIndexOutputStream::create()
 {
   const CompressHelper& ch = CompressHelper::getInstance();
-  mSize = mSensorMask.size() * ch.getHarmonics() * 2; // floats per frame (BaseOutputStream: mSize for kC streams)
+  m40bit = Parameters::getInstance().get40bitCompressionFlag();
+  // floats per frame: a complex coefficient is 2 floats, or 5 bytes = 1.25 floats (IndexOutputStream.cpp:90-93)
+  mSize = m40bit ? static_cast<size_t>(std::ceil(mSensorMask.size() * 1.25f)) * ch.getHarmonics()
+                 : mSensorMask.size() * ch.getHarmonics() * 2;
   auto dalloc = [&](size_t floats) {
     void* d = nullptr;
     kwCheck(kw_malloc(ctx(), floats * sizeof(float), &d));
@@ -261,15 +272,27 @@ void CompressedIndexOutputStream::sample()
   mSavingFlag              = ((stepLocal + 1) % ch.getOSize() == 0);
   const bool oddFrameFlag  = ((mCompressedTimeStep + 1) % 2 == 0);
   const bool mirror = (mCompressedTimeStep == 0 && mSavingFlag && !params.getNoCompressionOverlapFlag());
-  kwCheck(kw_sample_index_compress(ctx(), mC1, mC2, mSourceMatrix.getDeviceData(),
-                                   (const uint64_t*)mSensorMask.getDeviceData(), mSensorMask.size(),
-                                   static_cast<uint32_t>(ch.getHarmonics()), mBE, mBE_1,
-                                   static_cast<uint32_t>(ch.getBSize()), static_cast<uint32_t>(stepLocal), mirror ? 1 : 0));
+  if (m40bit)
+    kwCheck(kw_sample_index_compress_40b(ctx(), mC1, mC2, mSourceMatrix.getDeviceData(),
+                                         (const uint64_t*)mSensorMask.getDeviceData(), mSensorMask.size(),
+                                         static_cast<uint32_t>(ch.getHarmonics()), mBE, mBE_1,
+                                         static_cast<uint32_t>(ch.getBSize()), static_cast<uint32_t>(stepLocal), mirror ? 1 : 0,
+                                         params.getNoCompressionOverlapFlag() ? 1 : 0, maxExp()));
+  else
+    kwCheck(kw_sample_index_compress(ctx(), mC1, mC2, mSourceMatrix.getDeviceData(),
+                                     (const uint64_t*)mSensorMask.getDeviceData(), mSensorMask.size(),
+                                     static_cast<uint32_t>(ch.getHarmonics()), mBE, mBE_1,
+                                     static_cast<uint32_t>(ch.getBSize()), static_cast<uint32_t>(stepLocal), mirror ? 1 : 0));
   const size_t steps  = params.getNt() - params.getSamplingStartTimeIndex();
   const bool lastStep = ((steps - mSampledSteps == 1) && steps <= ch.getOSize());
   mCurrent = (mSavingFlag || lastStep) ? (oddFrameFlag ? mC1 : mC2) : nullptr; // :456-459
   mSampledSteps++;
 }
+int CompressedIndexOutputStream::maxExp() const
+{ // BaseOutputStream.cpp:68-83: the streams on the time-shifted basis (u_non_staggered_c) use the velocity bias
+  return mShifted ? CompressHelper::kMaxExpU : CompressHelper::kMaxExpP;
+}
+
 void CompressedIndexOutputStream::postSample2()
 {
   if (mCurrent == nullptr) return;
@@ -339,11 +362,34 @@ void IntensityAvgCOutputStream::postSample()
   const float* bufferU = mU.getCurrentStoreBuffer();
   if (bufferP && bufferU)
   {
+    if (mP.is40bit())
+      kwCheck(kw_intensity_avg_c_accumulate_40b(ctx(), mDeviceBuffer, bufferP, bufferU, mSize,
+                                                static_cast<uint32_t>(CompressHelper::getInstance().getHarmonics()),
+                                                mP.maxExp(), mU.maxExp()));
+    else
     kwCheck(kw_intensity_avg_c_accumulate(ctx(), mDeviceBuffer, bufferP, bufferU, mSize,
                                           static_cast<uint32_t>(CompressHelper::getInstance().getHarmonics())));
     mCompressedTimeStep++;
   }
 }
+void IntensityAvgCOutputStream::accumulateStoredFrames(const float* frameP, const float* frameU)
+{
+  if (mP.is40bit()) // the reference's computeAverageIntensitiesC does not handle them either (:1541 "NOTE does not work ...")
+    throw std::runtime_error("--post cannot compute I_avg_c / Q_term_c from 40-bit complex coefficients");
+  const size_t floats = mSize * CompressHelper::getInstance().getHarmonics() * 2;
+  void *dp = nullptr, *du = nullptr;
+  kwCheck(kw_malloc(ctx(), floats * sizeof(float), &dp));
+  kwCheck(kw_malloc(ctx(), floats * sizeof(float), &du));
+  kwCheck(kw_memcpy_h2d(ctx(), dp, frameP, floats * sizeof(float)));
+  kwCheck(kw_memcpy_h2d(ctx(), du, frameU, floats * sizeof(float)));
+  kwCheck(kw_intensity_avg_c_accumulate(ctx(), mDeviceBuffer, static_cast<float*>(dp), static_cast<float*>(du), mSize,
+                                        static_cast<uint32_t>(CompressHelper::getInstance().getHarmonics())));
+  kwCheck(kw_sync(ctx()));
+  kw_free(ctx(), dp);
+  kw_free(ctx(), du);
+  mCompressedTimeStep++;
+}
+
 void IntensityAvgCOutputStream::postProcess()
 { // IndexOutputStream.cpp:482-490
   if (mCompressedTimeStep > 0) kwCheck(kw_divide(ctx(), mDeviceBuffer, static_cast<float>(mCompressedTimeStep), mSize));
@@ -506,8 +552,9 @@ void OutputStreamContainer::init(MatrixContainer& mc)
         mContainer[is[a]]->setDoNotSave(!params.getStoreIntensityAvgCFlag());
       }
       // coefficient series that only feed the intensities are not part of the output (:274-292: doNotSaveFlag)
-      if (!params.getStorePressureCFlag()) mContainer[OI::kPressureC]->setDoNotSave(true);
-      if (!params.getStoreVelocityNonStaggeredCFlag())
+      // (--post reads them from the output file: there they are ordinary stored streams, OutputStreamContainer.cpp:275-285)
+      if (!params.getStorePressureCFlag() && !params.getOnlyPostProcessingFlag()) mContainer[OI::kPressureC]->setDoNotSave(true);
+      if (!params.getStoreVelocityNonStaggeredCFlag() && !params.getOnlyPostProcessingFlag())
         for (int a = 0; a < axes; a++) mContainer[us[a]]->setDoNotSave(true);
       if (params.getStoreQTermCFlag())
         mContainer[OI::kQTermC] = new PostProcessedOutputStream("Q_term_c", mc.getMatrix<RealMatrix>(MI::kP), RO::kQTermC, mask, false);

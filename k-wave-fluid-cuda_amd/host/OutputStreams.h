@@ -62,6 +62,7 @@ class BaseOutputStream
   void attachSink(std::unique_ptr<SeriesSink> sink) { mSink = std::move(sink); std::vector<float>().swap(mDataset); }
   bool hasSink() const { return static_cast<bool>(mSink); }
   void loadSeries();
+  void adoptStoredSeries(size_t rows); ///< --post: `rows` rows of this series are in the (re-opened) output file
   void releaseSeries() { if (mSink) std::vector<float>().swap(mDataset); }
   size_t size() const { return mSize; }
   size_t sampledSteps() const { return mFlushedSteps; }
@@ -133,6 +134,8 @@ class CompressedIndexOutputStream : public BaseOutputStream
   size_t frames() const { return mCompressedTimeStep; }
   size_t points() const { return mSensorMask.size(); }
   bool   shiftedBasis() const { return mShifted; }
+  bool   is40bit() const { return m40bit; }
+  int    maxExp() const; ///< exponent bias of the 40-bit format: 138, or 114 on the shifted (velocity) basis
 
  private:
   const IndexMatrix& mSensorMask;
@@ -143,6 +146,7 @@ class CompressedIndexOutputStream : public BaseOutputStream
   float*  mBE_1 = nullptr;
   float*  mCurrent = nullptr;
   bool    mSavingFlag = false;
+  bool    m40bit = false; // --40-bit_complex: accumulators and frames are 5-byte packed complex numbers
   size_t  mCompressedTimeStep = 0;
   std::vector<float> mFrameHost;
 };
@@ -158,6 +162,8 @@ class IntensityAvgCOutputStream : public BaseOutputStream
   void sample() override {}
   void postSample();
   void postProcess() override;
+  /// --post: one stored pair of coefficient frames (host) added like postSample() adds the device ones
+  void accumulateStoredFrames(const float* frameP, const float* frameU);
   /// state = the running sum; steps = number of frames added so far
   void checkpointState(std::vector<float>& state, size_t& sampledSteps) override;
   void restoreState(const float* state, size_t n, size_t sampledSteps) override;

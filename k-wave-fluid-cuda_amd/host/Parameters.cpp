@@ -35,8 +35,8 @@ void Parameters::init(const InputProvider& in, const Options& options)
     if (mOptions.nzGlobal != z * mOptions.slabRanks || mOptions.slabRank >= mOptions.slabRanks || y % mOptions.slabRanks != 0)
       throw std::invalid_argument("Z-slab decomposition: Nz_global must equal slabRanks * local Nz and Ny must divide by slabRanks");
     mGlobalDimensionSizes.nz = mOptions.nzGlobal;
-    if (needsShiftedVelocity())
-      throw std::invalid_argument("Z-slab decomposition: non-staggered velocity / intensity streams are not supported yet");
+    if (mOptions.storeQTerm || mOptions.storeQTermC)
+      throw std::invalid_argument("Z-slab decomposition: the Q-term streams (divergence of the intensity over the whole grid) need a single GPU");
   }
   if (!isSimulation3D())
   { // 2-D (Nz == 1): what this build carries over from the 3-D path; the rest says so instead of computing nonsense
@@ -92,8 +92,8 @@ void Parameters::init(const InputProvider& in, const Options& options)
   in.readScalarValue(kNonUniformGridFlagName, mNonUniformGridFlag);
   in.readScalarValue(kAbsorbingFlagName, mAbsorbingFlag);
   in.readScalarValue(kNonLinearFlagName, mNonLinearFlag);
-  if (mNonUniformGridFlag != 0 && (isSlabDecomposed() || !isSimulation3D()))
-    throw std::invalid_argument("Non-uniform grids are implemented for single-GPU 3-D simulations only");
+  if (mNonUniformGridFlag != 0 && !isSimulation3D())
+    throw std::invalid_argument("Non-uniform grids are implemented for 3-D simulations only");
 
   mTransducerSourceInputSize = (mTransducerSourceFlag == 0) ? 0 : in.getDatasetSize(kTransducerSourceInputName);
   mVelocitySourceIndexSize   = 0;

@@ -54,6 +54,8 @@ class Parameters
     bool   storePressureC = false, storeVelocityNonStaggeredC = false, storeIntensityAvgC = false;
     bool   storeIntensityAvg = false, storeQTerm = false, storeQTermC = false; // --I_avg, --Q_term, --Q_term_c
     bool   storeVelocityC = false; // --u_c
+    bool   complex40bit = false;       // --40-bit_complex
+    bool   onlyPostProcessing = false; // --post: post-processing of an existing output file, no time loop
     float  frequency = 0.0f;       // --frequency [Hz], alternative to --period
     float  period = 0.0f; // --period (time steps per period)
     size_t mos = 1, harmonics = 1;
@@ -179,6 +181,8 @@ class Parameters
   bool getStoreQTermFlag() const { return mOptions.storeQTerm; }
   bool getStoreQTermCFlag() const { return mOptions.storeQTermC; }
   bool getStoreVelocityCFlag() const { return mOptions.storeVelocityC; }
+  bool getOnlyPostProcessingFlag() const { return mOptions.onlyPostProcessing; }
+  bool get40bitCompressionFlag() const { return mOptions.complex40bit; }
   bool getNoCompressionOverlapFlag() const { return mOptions.noCompressionOverlap; }
   float  getPeriod() const { return mOptions.period; }
   size_t getMOS() const { return mOptions.mos; }

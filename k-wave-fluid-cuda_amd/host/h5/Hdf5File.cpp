@@ -176,6 +176,10 @@ void Hdf5File::writeMatrix(const std::string& name, const DimensionSizes& dims, 
   writeStringAttribute(name, kMatrixDataTypeName, kDataNames[1]);
   writeStringAttribute(name, kMatrixDomainTypeName, kDomainNames[0]);
 }
+void Hdf5File::remove(const std::string& name)
+{
+  if (H5Ldelete(mFile, name.c_str(), H5P_DEFAULT) < 0) fail("Error: cannot remove \"" + name + "\" from the file");
+}
 void Hdf5File::createGroup(const std::string& name)
 {
   hid_t g = H5Gcreate2(mFile, name.c_str(), H5P_DEFAULT, H5P_DEFAULT, H5P_DEFAULT);

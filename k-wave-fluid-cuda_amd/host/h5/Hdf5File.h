@@ -48,6 +48,7 @@ class Hdf5File
   /// group + dataset of one sampled cuboid (CuboidOutputStream.cpp:656-722): dims = (nx, ny, nz[, nt]); 4-D when nt > 0;
   /// chunk = one time step of the cuboid, cut into z-slabs of ~4 MB above 32 MB
   void createGroup(const std::string& name);
+  void remove(const std::string& name); ///< unlink a dataset (its space is not reclaimed until the file is repacked)
   void writeCuboid(const std::string& name, const DimensionSizes& dims, const float* data);
   void writeScalarValue(const std::string& name, float value);
   void writeScalarValue(const std::string& name, size_t value);

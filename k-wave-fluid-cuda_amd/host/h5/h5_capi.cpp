@@ -35,8 +35,8 @@ static void writeCompressionAttributes(Hdf5File& out, const std::string& name, c
   out.writeFloatAttribute(name, "c_period", ch.getPeriod());
   out.writeLongLongAttribute(name, "c_mos", static_cast<long long>(ch.getMos()));
   out.writeLongLongAttribute(name, "c_shift", cs.shiftedBasis() ? 1 : 0);
-  out.writeFloatAttribute(name, "c_complex_size", 2.0f);
-  out.writeLongLongAttribute(name, "c_max_exp", cs.shiftedBasis() ? CompressHelper::kMaxExpU : CompressHelper::kMaxExpP);
+  out.writeFloatAttribute(name, "c_complex_size", cs.is40bit() ? 1.25f : 2.0f);
+  out.writeLongLongAttribute(name, "c_max_exp", cs.maxExp());
 }
 
 // Per-step output (IndexOutputStream.cpp:87-160 create, :348-372 flushRaw; CuboidOutputStream.cpp:95-140, :656-722): the
@@ -246,6 +246,43 @@ void kwh_write_output(kwh_solver* s, const std::string& path, unsigned compressi
 }
 void kwh_write_output(kwh_solver* s, const std::string& path) { kwh_write_output(s, path, 0, false); }
 
+// --post (KSpaceFirstOrderSolver.cpp:373-415, :977-1024): no simulation; the time-averaged intensities and the Q terms are
+// computed from the p / u_non_staggered series (I_avg, Q_term) or the coefficient frames (I_avg_c, Q_term_c) that an
+// earlier run left in the output file, and are added to that file (replacing older results of the same name).
+void kwh_post_process_output(kwh_solver* s, const std::string& path)
+{
+  const Parameters& params = Parameters::getInstance();
+  if (!params.getOnlyPostProcessingFlag()) throw std::invalid_argument("post-processing of an output file needs the --post option set at creation");
+  if (!(params.getStoreIntensityAvgFlag() || params.getStoreIntensityAvgCFlag() || params.getStoreQTermFlag() || params.getStoreQTermCFlag()))
+    throw std::invalid_argument("--post needs at least one of --I_avg, --I_avg_c, --Q_term, --Q_term_c"); // CommandLineParameters.cpp:931-936
+  kwh_open_output(s, path, 0, true);
+  Hdf5SeriesWriter* writer = seriesWriter(s);
+  OutputStreamContainer& streams = s->solver->getOutputStreamContainer();
+  const size_t steps = (params.getNt() > params.getSamplingStartTimeIndex()) ? params.getNt() - params.getSamplingStartTimeIndex() : 0;
+  for (const std::string& name : streams.names())
+  {
+    BaseOutputStream* st = streams.find(name);
+    if (!st->isSeries() || !st->hasSink()) continue;
+    const bool frames = dynamic_cast<CompressedIndexOutputStream*>(st) != nullptr;
+    st->adoptStoredSeries(frames ? std::max<size_t>(steps / CompressHelper::getInstance().getOSize(), 1) : steps);
+  }
+  s->solver->postProcessStoredOutput();
+  writer->finish();
+  Hdf5File& out = writer->file();
+  using RO = BaseOutputStream::ReduceOperator;
+  for (const std::string& name : streams.names())
+  {
+    BaseOutputStream* st = streams.find(name);
+    const RO op = st->reduceOp();
+    if (op != RO::kIAvg && op != RO::kIAvgC && op != RO::kQTerm && op != RO::kQTermC) continue;
+    if (st->dataset().size() != st->size()) continue;
+    if (out.datasetExists(name)) out.remove(name);
+    out.writeMatrix(name, DimensionSizes(st->size(), 1, 1), st->dataset().data(), Hdf5File::MatrixDomainType::kReal);
+  }
+  out.close();
+  s->series_writer.reset();
+}
+
 // ---- checkpoint file (KSpaceFirstOrderSolver.cpp:1176-1224 write, :186-228 + :1124-1169 read / check) --------------
 // Root datasets: the seven state arrays under their matrix names (MatrixContainer.cpp:504-537), t_index, Nx, Ny, Nz;
 // header file_type = "checkpoint".  Streams: "stream_<name>" (series so far or accumulator) + "stream_<name>_steps";
@@ -317,6 +354,7 @@ void kwh_checkpoint_read_impl(kwh_solver* s, const std::string& path)
       throw std::invalid_argument(path + " holds no state for the output stream \"" + name + "\": checkpoints of this build carry "
                                   "their streams inside the checkpoint file (datasets stream_<name>), the reference's "
                                   "kspaceFirstOrder-CUDA keeps them in the output file - the two cannot resume each other's runs");
+    f.readCompleteDataset("stream_" + name + "_steps", 1, &steps);
     std::vector<float> state;
     if (f.datasetExists("stream_" + name))
     {
@@ -469,6 +507,14 @@ KWH_API int kwh_open_output_file(kwh_solver* s, const char* path, uint32_t compr
   KWH_TRY
   if (!s || !path) throw std::invalid_argument("kwh_open_output_file: NULL argument");
   kwh_open_output(s, path, compression_level, reopen != 0);
+  KWH_CATCH
+}
+
+KWH_API int kwh_post_process_output_file(kwh_solver* s, const char* path)
+{
+  KWH_TRY
+  if (!s || !path) throw std::invalid_argument("kwh_post_process_output_file: NULL argument");
+  kwh_post_process_output(s, path);
   KWH_CATCH
 }
 

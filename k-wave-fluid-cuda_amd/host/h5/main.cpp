@@ -15,6 +15,7 @@
 
 void kwh_write_output(kwh_solver* s, const std::string& path, unsigned compressionLevel, bool copySensorMask);
 void kwh_open_output(kwh_solver* s, const std::string& path, unsigned compressionLevel, bool reopen);
+void kwh_post_process_output(kwh_solver* s, const std::string& path);
 void kwh_checkpoint_write_impl(kwh_solver* s, const std::string& path);
 void kwh_checkpoint_read_impl(kwh_solver* s, const std::string& path);
 
@@ -30,7 +31,9 @@ static void usage()
               "      (or once SECONDS of wall-clock time have passed), leaving a checkpoint; the same command line resumes\n"
               "      from it (CommandLineParameters.cpp:264-292)\n"
               "  [--version] [-h|--help]; accepted without effect: -r <percent>, -t <threads>, --verbose <level>,\n"
-              "      --block_size <n>.  Not available: --post, --40-bit_complex\n");
+              "      --block_size <n>\n"
+              "  [--40-bit_complex]  compression coefficients kept and stored as 5-byte complex numbers\n"
+              "  [--post --I_avg|--I_avg_c|--Q_term|--Q_term_c]  no simulation: compute these from the series stored in <output.h5>\n");
 }
 
 // numeric command-line values: anything but a plain non-negative number is an error (the reference's getopt loop
@@ -120,12 +123,23 @@ int main(int argc, char** argv)
     else if (a == "--checkpoint_interval") ckptSeconds = parseReal("--checkpoint_interval", next());
     else if (a == "--version") { std::printf("%s\n", KSpaceFirstOrderSolver().getCodeName().c_str()); return EXIT_SUCCESS; }
     else if (a == "-r" || a == "-t" || a == "--verbose" || a == "--block_size") (void)next(); // progress / threads / log level / host block: nothing to set here
-    else if (a == "--post" || a == "--40-bit_complex")
-    { std::fprintf(stderr, "Error: %s is not available in this build\n", a.c_str()); return EXIT_FAILURE; }
+    else if (a == "--post") o.only_post_processing = 1;
+    else if (a == "--40-bit_complex") o.complex_40bit = 1;
     else if (a == "-h" || a == "--help") { usage(); return EXIT_SUCCESS; }
     else { std::fprintf(stderr, "unknown flag %s\n", a.c_str()); usage(); return EXIT_FAILURE; }
   }
   if (in.empty() || out.empty()) { usage(); return EXIT_FAILURE; }
+  if (o.only_post_processing)
+  { // CommandLineParameters.cpp:919-936: --post goes with the post-processed quantities only
+    const bool other = o.p_raw || o.p_rms || o.p_max || o.p_min || o.p_max_all || o.p_min_all || o.p_final || o.u_raw || o.u_rms ||
+                       o.u_max || o.u_min || o.u_max_all || o.u_min_all || o.u_final || o.u_non_staggered_raw || o.p_c || o.u_c ||
+                       o.u_non_staggered_c || !ckpt.empty();
+    if (other || !(o.i_avg || o.i_avg_c || o.q_term || o.q_term_c))
+    {
+      std::fprintf(stderr, "Error: --post takes --I_avg, --I_avg_c, --Q_term, --Q_term_c (at least one) and no other output or checkpoint flag\n");
+      return EXIT_FAILURE;
+    }
+  }
   try
   {
     kwh_solver s;
@@ -135,6 +149,13 @@ int main(int argc, char** argv)
     std::printf("%s on %s\n", s.solver->getCodeName().c_str(),
                 Parameters::getInstance().getHipParameters().getDeviceName().c_str());
     Parameters& params = Parameters::getInstance();
+    if (o.only_post_processing)
+    {
+      kwh_post_process_output(&s, out);
+      std::printf("post-processing of %s done\n", out.c_str());
+      s.solver.reset();
+      return EXIT_SUCCESS;
+    }
     const bool checkpointing = !ckpt.empty() && (ckptSteps > 0 || ckptSeconds > 0.0);
     bool resuming = false;
     if (checkpointing)

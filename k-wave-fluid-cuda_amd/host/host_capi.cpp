@@ -32,6 +32,8 @@ Parameters::Options kwh_convert_options(const kwh_options* o)
   opt.storeIntensityAvgC = o->i_avg_c; opt.noCompressionOverlap = o->no_overlap;
   opt.storeIntensityAvg = o->i_avg; opt.storeQTerm = o->q_term; opt.storeQTermC = o->q_term_c;
   opt.storeVelocityC = o->u_c; opt.frequency = o->frequency;
+  opt.onlyPostProcessing = o->only_post_processing != 0;
+  opt.complex40bit = o->complex_40bit != 0;
   opt.period = o->period; opt.mos = o->mos ? o->mos : 1; opt.harmonics = o->harmonics ? o->harmonics : 1;
   opt.slabRanks = o->slab_ranks ? o->slab_ranks : 1;
   opt.slabRank  = o->slab_rank;

@@ -18,7 +18,8 @@ import sys
 import numpy as np
 
 STREAM_FLAGS = ("p_raw", "p_rms", "p_max", "p_min", "p_max_all", "p_min_all", "p_final",
-                "u_raw", "u_rms", "u_max", "u_min", "u_max_all", "u_min_all", "u_final")
+                "u_raw", "u_rms", "u_max", "u_min", "u_max_all", "u_min_all", "u_final",
+                "u_non_staggered_raw", "p_c", "u_c", "u_non_staggered_c", "I_avg_c", "I_avg", "no_overlap")
 OUTPUT_SCALARS = ("Nx", "Ny", "Nz", "Nt", "dt", "dx", "dy", "dz", "c_ref", "pml_x_size", "pml_y_size", "pml_z_size",
                   "pml_x_alpha", "pml_y_alpha", "pml_z_alpha", "p_source_flag", "p0_source_flag", "transducer_source_flag",
                   "ux_source_flag", "uy_source_flag", "uz_source_flag", "nonuniform_grid_flag", "absorbing_flag",
@@ -37,6 +38,10 @@ def main(argv=None) -> int:
     ap.add_argument("-u", action="store_true", help="same as --u_raw")
     for f in STREAM_FLAGS:
         ap.add_argument("--" + f, action="store_true")
+    ap.add_argument("--period", type=float, default=0.0)
+    ap.add_argument("--frequency", type=float, default=0.0)
+    ap.add_argument("--mos", type=int, default=1)
+    ap.add_argument("--harmonics", type=int, default=1)
     a = ap.parse_args(argv)
     a.p_raw |= a.p
     a.u_raw |= a.u
@@ -60,7 +65,8 @@ def main(argv=None) -> int:
     if "sensor_mask_corners" in pr:
         raise SystemExit("run_slab: corner (cuboid) sensor masks are not supported in slab mode")
     loc, info = partition_problem(pr, rank, world, arrays_are_local=True)
-    opts = {f: 1 for f in STREAM_FLAGS if getattr(a, f)}
+    opts = {f.lower(): 1 for f in STREAM_FLAGS if getattr(a, f)}
+    opts.update(period=a.period, frequency=a.frequency, mos=a.mos, harmonics=a.harmonics)
     if a.start < 1:
         raise SystemExit("Error: The beginning of data sampling is out of the simulation time span <1, Nt>.")
     sim = DistSolver(loc, rank, world, nz, device_index=dev, sampling_start=a.start - 1, benchmark_steps=a.benchmark, **opts)
@@ -94,12 +100,15 @@ def main(argv=None) -> int:
             if name.endswith("_all"):      # whole-domain aggregate: the slabs stacked along z
                 out[name] = np.concatenate([p.reshape(-1, ny, nx) for p in parts], axis=0)
                 continue
-            steps = max((p.size // max(g["pos"].size, 1) for p, g in zip(parts, gathered) if g["pos"].size), default=0)
-            full = np.zeros((steps, nsens), dtype=np.float32)
+            # per sensor point and stored step: one value, or 2 * harmonics coefficients of a compression frame
+            shapes = [(np.asarray(p).shape[0] if np.asarray(p).ndim == 2 else 1) for p, g in zip(parts, gathered) if g["pos"].size]
+            steps = max(shapes, default=0)
+            w = max((np.asarray(p).size // max(steps * g["pos"].size, 1) for p, g in zip(parts, gathered) if g["pos"].size), default=1)
+            full = np.zeros((steps, nsens, w), dtype=np.float32)
             for p, g in zip(parts, gathered):
                 if g["pos"].size:
-                    full[:, g["pos"]] = p.reshape(steps, g["pos"].size)
-            out[name] = full.reshape(1, steps, nsens)     # dataset dims (Nsens, steps, 1)
+                    full[:, g["pos"], :] = np.asarray(p).reshape(steps, g["pos"].size, w)
+            out[name] = full.reshape(1, steps, nsens * w)     # dataset dims (Nsens [* 2 * harmonics], steps, 1)
         for name in piece["fields"]:
             out[name] = np.concatenate([g["fields"][name].reshape(-1, ny, nx) for g in gathered], axis=0)
         assert all(v.size == plane * nz for k, v in out.items() if k.endswith(("_final", "_all")))

@@ -41,7 +41,8 @@ class Options(C.Structure):
                 ("exchange_fn", C.c_void_p), ("exchange_user", C.c_void_p),
                 ("exchange_start_fn", C.c_void_p), ("exchange_wait_fn", C.c_void_p), ("scratch", C.c_void_p * 6),
                 ("i_avg", C.c_int32), ("q_term", C.c_int32), ("q_term_c", C.c_int32), ("u_c", C.c_int32),
-                ("frequency", C.c_float), ("reserved_", C.c_int32), ("comm_unique_id", C.c_void_p)]
+                ("frequency", C.c_float), ("only_post_processing", C.c_int32), ("comm_unique_id", C.c_void_p),
+                ("complex_40bit", C.c_int32), ("reserved_", C.c_int32)]
 
 
 _hlib: Optional[C.CDLL] = None

@@ -24,6 +24,8 @@ def main():
     ap.add_argument("--backend", default="gloo")
     ap.add_argument("--medium", default="111", help="heterogeneous, nonlinear, absorbing as three 0/1 digits")
     ap.add_argument("--exchange", default=None, help="native | torch | host (DistSolver's default when omitted)")
+    ap.add_argument("--config5", action="store_true",
+                    help="also store the non-staggered velocity, compression and intensity streams (BASELINE config 5's set)")
     ap.add_argument("--pml", type=int, default=4)
     ap.add_argument("--sensor", default="random")
     ap.add_argument("--per-rank", action="store_true",
@@ -40,7 +42,12 @@ def main():
                                 source_mode=a.mode, source_many=1, nt=a.steps, pml_size=a.pml, sensor=a.sensor, zslab=zslab)
     loc, info = partition_problem(pr, rank, P, arrays_are_local=a.per_rank)
     del pr
-    sim = DistSolver(loc, rank, P, nz, device_index=dev, exchange=a.exchange, p_raw=1, p_max=1)
+    extra = {}
+    if a.config5:
+        dt = float(np.asarray(loc["dt"]).ravel()[0])
+        extra = dict(u_non_staggered_raw=1, p_c=1, u_non_staggered_c=1, i_avg_c=1, i_avg=1, period=1.0 / (1.0e6 * dt) / 2.0,
+                     mos=1, harmonics=2)
+    sim = DistSolver(loc, rank, P, nz, device_index=dev, exchange=a.exchange, p_raw=1, p_max=1, **extra)
     sim.run(a.steps)
     sim.finish()
     fields = {k: sim.field(k) for k in ("p", "ux", "uz", "rhoy")}
@@ -52,8 +59,14 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
         return
+    streams = {}
+    if a.config5 and info["sensor_positions"].size:
+        for name in sim.stream_names():
+            if name not in ("p", "p_max"):
+                streams[name] = sim.stream(name)
+        fields["uz_shifted"] = sim.field("uz_shifted")
     gathered = [None] * P if rank == 0 else None
-    dist.gather_object({"fields": fields, "series": series, "pos": info["sensor_positions"]}, gathered, dst=0)
+    dist.gather_object({"fields": fields, "series": series, "pos": info["sensor_positions"], "streams": streams}, gathered, dst=0)
     if rank == 0:
         out = {k: np.concatenate([g["fields"][k] for g in gathered], axis=0) for k in fields}
         n_sens = sum(g["pos"].size for g in gathered)
@@ -62,6 +75,19 @@ def main():
             if g["pos"].size:
                 full[:, g["pos"]] = g["series"]
         out["series"] = full
+        if a.config5:
+            out["uz_shifted"] = np.concatenate([g["fields"]["uz_shifted"] for g in gathered], axis=0)
+            names = sorted({k for g in gathered for k in g["streams"]})
+            for name in names:  # per sensor point: w floats per step (1, or 2 * harmonics for compression frames)
+                some = next(g for g in gathered if name in g["streams"])
+                a0 = np.asarray(some["streams"][name])
+                steps = a0.shape[0] if a0.ndim == 2 else 1
+                w = a0.size // (steps * some["pos"].size)
+                full_s = np.zeros((steps, n_sens, w), dtype=np.float32)
+                for g in gathered:
+                    if name in g["streams"]:
+                        full_s[:, g["pos"], :] = np.asarray(g["streams"][name]).reshape(steps, g["pos"].size, w)
+                out["stream_" + name] = full_s
         out["exchanges"] = np.array([sim.exchanges])
         np.savez(a.out, **out)
     sim.close()

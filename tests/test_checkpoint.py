@@ -106,19 +106,28 @@ def test_command_line_checkpoint_legs(h5io, syn, tmp_path):
     r = subprocess.run([exe, "-i", path_in, "-o", out1] + flags, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
                        text=True, timeout=300)
     assert r.returncode == 0, r.stdout
+
+    def complete(path):
+        """the output file is there from the first leg on (sampled series are appended step by step, like the reference's,
+        OutputStreamContainer.cpp:380-403); its header is written when the run is complete"""
+        try:
+            return h5io.read_attribute(path, "/", "file_type") == "output"
+        except capi.KWaveError:
+            return False
+
     for leg in range(3):
         r = subprocess.run([exe, "-i", path_in, "-o", out2, "--checkpoint_file", ckpt, "--checkpoint_timesteps", "7"] + flags,
                            stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
         assert r.returncode == 0, r.stdout
         assert os.path.exists(ckpt) == (leg < 2), r.stdout
-        assert os.path.exists(out2) == (leg == 2)
+        assert os.path.exists(out2) and complete(out2) == (leg == 2)
     for name in ("p", "p_max", "ux_rms", "uz_rms", "p_final"):
         assert np.array_equal(h5io.read_dataset(out2, name), h5io.read_dataset(out1, name)), name
     # --checkpoint_interval <seconds>: a leg ends at the first step boundary after the budget (here: after every step
     # of the first legs); --version / the flags accepted for command-line compatibility do not disturb the run
     out3 = str(tmp_path / "out_interval.h5")
     legs = 0
-    while not os.path.exists(out3):
+    while not (os.path.exists(out3) and complete(out3)):
         budget = "0.000001" if legs < 3 else "3600"
         r = subprocess.run([exe, "-i", path_in, "-o", out3, "--checkpoint_file", ckpt, "--checkpoint_interval", budget,
                             "-r", "10", "--verbose", "1"] + flags, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
@@ -131,9 +140,12 @@ def test_command_line_checkpoint_legs(h5io, syn, tmp_path):
         assert np.array_equal(h5io.read_dataset(out3, name), h5io.read_dataset(out1, name)), name
     r = subprocess.run([exe, "--version"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=60)
     assert r.returncode == 0 and "kspaceFirstOrder-HIP" in r.stdout
-    r = subprocess.run([exe, "-i", path_in, "-o", out3, "--post"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
-                       text=True, timeout=60)
-    assert r.returncode != 0 and "not available" in r.stdout
+    # --post wants one of the post-processed quantities and nothing else (CommandLineParameters.cpp:919-936)
+    for extra in ([], ["--I_avg", "--p_raw"]):
+        r = subprocess.run([exe, "-i", path_in, "-o", out3, "--post"] + extra, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                           text=True, timeout=60)
+        assert r.returncode != 0 and "--post takes" in r.stdout
+
 
 
 @pytest.mark.parametrize("opts,names", [

@@ -434,3 +434,87 @@ def test_step_graph_replay_is_bit_identical(syn, monkeypatch):
         b.finish()
         assert np.array_equal(b.field("p"), pa) and np.array_equal(b.stream("p"), sa) and np.array_equal(b.stream("p_max"), ma)
         b.close()
+
+
+@pytest.mark.parametrize("no_overlap", [0, 1])
+def test_40bit_complex_compression_streams(orc, syn, no_overlap):
+    """--40-bit_complex (IndexOutputStream.cpp:410-436; codec CompressHelper.cpp:224-389): the accumulators are decoded,
+    updated and re-encoded as 5-byte complex numbers at every sampled step, and the frames are stored that way (dataset
+    width ceil(1.25 Nsens) * harmonics floats).  Emulated on the host with the codec that is pinned bit-for-bit to the
+    compiled reference (tests/test_compress_host.py), fed with the GPU's own raw series."""
+    import ctypes as C
+    from kwave_amd import solver
+    L = solver.load_host()
+    L.kwh_pack_complex_40b.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_int32]
+    L.kwh_unpack_complex_40b.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_int32]
+    n, nt, harm = 32, 70, 2
+    pr = syn.make_problem(n, heterogeneous=True, nonlinear=False, absorbing=False, source="p_source", source_mode=1,
+                          nt=nt, pml_size=4, sensor="random")
+    dt = float(pr["dt"].ravel()[0])
+    period = 1.0 / (1.0e6 * dt) / 2.0
+    g = make_gpu(pr, p_raw=1, u_non_staggered_raw=1, p_c=1, u_non_staggered_c=1, i_avg_c=1, period=period, mos=1,
+                 harmonics=harm, complex_40bit=1, no_overlap=no_overlap)
+    g.run(nt)
+    g.finish()
+    nsens = pr["sensor_mask_index"].size
+    width = int(np.ceil(nsens * 1.25)) * harm  # floats per stored frame
+
+    def unpack(buf, e):
+        out = np.zeros((nsens * harm, 2), dtype=np.float32)
+        assert L.kwh_unpack_complex_40b(buf.ctypes.data, nsens * harm, out.ctypes.data, e) == 0
+        return out
+
+    def pack(vals, buf, e):
+        assert L.kwh_pack_complex_40b(np.ascontiguousarray(vals, dtype=np.float32).ctypes.data, nsens * harm, buf.ctypes.data, e) == 0
+
+    def emulate(series, shifted, e):
+        bE, bE1 = orc.compress_basis(period, 1, harm, shifted)  # [harm][bSize][2]
+        o_size, b_size = int(orc.lib().kwo_compress_osize(period, 1)), int(orc.lib().kwo_compress_bsize(period, 1))
+        c1 = np.zeros(width * 4, dtype=np.uint8)
+        c2 = c1 if no_overlap else np.zeros(width * 4, dtype=np.uint8)
+        frames, compressed = [], 0
+        for s, row in enumerate(series):
+            local = s % (b_size - 1)
+            save = (local + 1) % o_size == 0
+            odd = (compressed + 1) % 2 == 0
+            mirror = compressed == 0 and save and not no_overlap
+            x = np.repeat(row.astype(np.float32), harm)[:, None]                     # [point*harm][1]
+            b0 = np.tile(bE[:, local, :], (nsens, 1)).astype(np.float32)             # [point*harm][2]
+            b1 = np.tile(bE1[:, local, :], (nsens, 1)).astype(np.float32)
+            cc1 = unpack(c1, e)
+            if no_overlap:
+                cc1 = cc1 + (b0 * x + b1 * x)
+                pack(cc1, c1, e)
+            else:
+                cc2 = unpack(c2, e)
+                cc1 = cc1 + b0 * x
+                cc2 = cc2 + b1 * x
+                pack(cc1, c1, e)
+                if mirror:
+                    cc2 = cc2 + cc1
+                pack(cc2, c2, e)
+            if save:
+                cur = c1 if odd else c2
+                frames.append(cur.copy())
+                cur[:] = 0
+                compressed += 1
+        return np.array(frames)
+
+    for name, raw, shifted, e in (("p_c", "p", False, 138), ("ux_non_staggered_c", "ux_non_staggered", True, 114)):
+        got = g.stream(name)
+        assert got.shape[1] == width and got.shape[0] == nt // int(period)
+        ref = emulate(g.stream(raw), shifted, e)
+        got_b = np.ascontiguousarray(got).view(np.uint8).reshape(got.shape[0], -1)
+        # decoded values agree to the 17-bit mantissa (a fused multiply-add on the device may move a sum by one fp32 ulp
+        # and thereby a 40-bit code by one step); most codes are identical
+        same = (got_b == ref).mean()
+        assert same > 0.97, (name, same)
+        for f in range(got.shape[0]):
+            a, b = unpack(got_b[f], e), unpack(ref[f], e)
+            assert np.abs(a - b).max() <= 4e-5 * np.abs(b).max(), (name, f)
+    # the intensity built from the 40-bit frames: mean over frames of sum_h Re(P conj(U)) / 2 on the decoded frames
+    P = [unpack(np.ascontiguousarray(fr).view(np.uint8), 138) for fr in g.stream("p_c")]
+    U = [unpack(np.ascontiguousarray(fr).view(np.uint8), 114) for fr in g.stream("ux_non_staggered_c")]
+    ref_i = np.mean([((p[:, 0] * u[:, 0] + p[:, 1] * u[:, 1]) / 2.0).reshape(nsens, harm).sum(axis=1) for p, u in zip(P, U)], axis=0)
+    assert rel_l2(g.stream("Ix_avg_c"), ref_i) < 1e-5
+    g.close()

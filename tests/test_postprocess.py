@@ -3,6 +3,7 @@ p / u_non_staggered series (--I_avg, :1231-1534) and the volume rate of heat dep
 --Q_term_c, :1783-2080).  CPU part: the numpy oracle against closed forms.  GPU part: the device implementation
 against the oracle fed with the run's own stored series (tolerance: 1e-5 of the largest magnitude, fp32 FFTs)."""
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -213,3 +214,57 @@ def test_command_line_i_avg_and_q_term(orc, syn, tmp_path):
     spacing = tuple(float(pr[k].ravel()[0]) for k in ("dx", "dy", "dz"))
     ref = orc.q_term(*inten, grid_indices(pr), dims, spacing)
     assert err_rel_max(h5io.read_dataset(path_out, "Q_term"), ref) < 1e-5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("streamed", [False, True])
+def test_only_post_processing_of_an_existing_output_file(syn, tmp_path, streamed):
+    """--post (KSpaceFirstOrderSolver.cpp:373-415, :977-1024): a first run stores the raw p / u_non_staggered series and
+    the compression coefficients; a second invocation without any time loop computes I_avg, Q_term (from the series) and
+    I_avg_c, Q_term_c (from the coefficient frames) out of that file and adds them to it — the same values a single run
+    with those flags produces.  Through the C++ entry point and through the command-line program."""
+    import subprocess
+    import kwave_amd  # noqa: F401
+    from kwave_amd import capi, h5io
+    if not os.path.exists(h5io.H5_LIB_PATH):
+        pytest.skip("HDF5 component not built")
+    nt = 60
+    pr = syn.make_problem(32, heterogeneous=True, nonlinear=False, absorbing=False, source="p_source", source_mode=1,
+                          nt=nt, pml_size=4, sensor="random")
+    dt = float(pr["dt"].ravel()[0])
+    comp = dict(period=1.0 / (1.0e6 * dt) / 2.0, harmonics=2)
+    path_in, direct, staged, cli = (str(tmp_path / n) for n in ("in.h5", "direct.h5", "staged.h5", "cli.h5"))
+    h5io.write_input_file(pr, path_in)
+    post = dict(i_avg=1, q_term=1, i_avg_c=1, q_term_c=1)
+    fs = h5io.FileSolver(path_in, **post, **comp)  # the reference result: everything in one run
+    fs.run(nt)
+    fs.finish()
+    fs.write_output(direct)
+    fs.close()
+    for target in (staged, cli):
+        fs = h5io.FileSolver(path_in, output=target if streamed else None, p_raw=1, u_non_staggered_raw=1, p_c=1,
+                             u_non_staggered_c=1, **comp)
+        fs.run(nt)
+        fs.finish()
+        fs.write_output(target)
+        fs.close()
+        assert not h5io.dataset_exists(target, "Ix_avg") and not h5io.dataset_exists(target, "Q_term_c")
+    ps = h5io.FileSolver(path_in, only_post_processing=1, **post, **comp)
+    ps.post_process(staged)
+    ps.close()
+    exe = os.path.join(capi.PKG, "lib", "kspaceFirstOrder-HIP")
+    r = subprocess.run([exe, "-i", path_in, "-o", cli, "--post", "--I_avg", "--Q_term", "--I_avg_c", "--Q_term_c", "--period",
+                        repr(comp["period"]), "--harmonics", "2"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True,
+                       timeout=300)
+    assert r.returncode == 0, r.stdout
+    for out in (staged, cli):
+        for name in ("Ix_avg", "Iy_avg", "Iz_avg", "Q_term", "Ix_avg_c", "Iz_avg_c", "Q_term_c"):
+            a, b = h5io.read_dataset(out, name), h5io.read_dataset(direct, name)
+            assert a.shape == b.shape and np.abs(b).max() > 0, name
+            assert np.abs(a - b).max() <= 2e-6 * np.abs(b).max(), name
+        assert np.array_equal(h5io.read_dataset(out, "p"), h5io.read_dataset(direct, "p"))  # the series are untouched
+    # a second --post replaces the earlier results instead of failing on the existing names
+    ps = h5io.FileSolver(path_in, only_post_processing=1, i_avg=1, **comp)
+    ps.post_process(staged)
+    ps.close()
+    assert np.array_equal(h5io.read_dataset(staged, "Ix_avg"), h5io.read_dataset(cli, "Ix_avg"))
