@@ -79,7 +79,7 @@ def _dataset(block):
             m = re.search(r"CHUNKED \( ([\d, ]+) \)", text)
             d["chunk"] = tuple(int(v) for v in m.group(1).split(",")) if m else None
         if head[:1] == ["FILTERS"]:
-            m = re.search(r"DEFLATE LEVEL (\d+)", text)
+            m = re.search(r"DEFLATE (?:\{ )?LEVEL (\d+)", text)
             d["deflate"] = int(m.group(1)) if m else 0
     return d
 

@@ -8,11 +8,12 @@ O=$R/gpurun_out/$tag
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 set -x
-rocprofv3 --kernel-trace --stats -d $O/stats256 --output-format csv -- python3 $R/bench.py --steps 40 --warmup 3 --no-cpu > $O/stats256.log 2>&1 || exit 1
+(cd $R && python3 -c "import bench; print(bench.kernel_source_hash())") > $O/source_hash.txt
+rocprofv3 --kernel-trace --stats -d $O/stats256 --output-format csv -- python3 $R/bench.py --steps 40 --warmup 3 --no-cpu --no-512 > $O/stats256.log 2>&1 || exit 1
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --kernel-trace --pmc $c -d $O/pmc256_$c --output-format csv -- python3 $R/bench.py --steps 10 --warmup 2 --no-cpu --profile-steps 1 > $O/pmc256_$c.log 2>&1 || exit 1
+  rocprofv3 --kernel-trace --pmc $c -d $O/pmc256_$c --output-format csv -- python3 $R/bench.py --steps 10 --warmup 2 --no-cpu --no-512 --profile-steps 1 > $O/pmc256_$c.log 2>&1 || exit 1
   rocprofv3 --kernel-trace --pmc $c -d $O/pmcprobe_$c --output-format csv -- python3 $R/tools/probe_passes.py 256 3 > $O/pmcprobe_$c.log 2>&1 || exit 1
 done
-rocprofv3 --kernel-trace --stats -d $O/stats512 --output-format csv -- python3 $R/bench.py --size 512 --steps 10 --warmup 2 --no-cpu > $O/stats512.log 2>&1 || exit 1
+rocprofv3 --kernel-trace --stats -d $O/stats512 --output-format csv -- python3 $R/bench.py --size 512 --steps 10 --warmup 2 --no-cpu --no-512 > $O/stats512.log 2>&1 || exit 1
 rocprofv3 --kernel-trace --stats -d $O/statsslab --output-format csv -- python3 $R/bench.py --slab-selftest --steps 20 --warmup 3 > $O/statsslab.log 2>&1 || exit 1
 echo collected

@@ -104,10 +104,16 @@ def main():
         if k.startswith("k_xinv<256, 3, true"):
             steps = f256[k][0]
     by = {t["kernel"]: t for t in table}
-    for t in table:  # template arguments added later (k_xinv<L, EPI, CHAIN, TERMS>): also index by the 3-argument prefix
+    for t in table:  # template arguments added over time (k_xinv<L, EPI, CHAIN, TERMS, TAIL>, k_xfwd<L, TAIL>): the keys
+        # used below are the leading arguments; the unmasked (TAIL = false) instantiation is the one that matters
+        if t["kernel"].endswith(", true>") and re.match(r"k_x(inv|fwd|shift)<", t["kernel"]) and t["kernel"].count(",") in (1, 4):
+            continue
         m = re.match(r"(k_xinv<256, \d, (?:true|false))", t["kernel"])
         if m:
             by.setdefault(m.group(1) + ">", t)
+        m = re.match(r"(k_xfwd<256)", t["kernel"])
+        if m:
+            by.setdefault("k_xfwd<256>", t)
     per_step = sum(t["traffic_bytes"] * t["launches"] for t in table if t["kernel"].startswith("k_") and
                    not t["kernel"].startswith(("k_import", "k_add_initial", "k_xinv<256, 2"))) / max(steps or 1, 1)
 
@@ -131,7 +137,9 @@ def main():
     for na in (1, 2, 3):
         bench_names[f"k_ypass_fwd[{na}]"] = na * yf
         bench_names[f"k_ypass_inv[{na}]"] = na * yi
+    hash_file = os.path.join(src, "source_hash.txt")
     res = {"grid": [n, n, n], "units": "bytes per kernel launch; traffic = corrected reads + WRITE_SIZE",
+           "kernel_source_hash": open(hash_file).read().strip() if os.path.exists(hash_file) else None,
            "calibration": calib, "fetch_ratio_8B_per_lane": r8, "fetch_ratio_16B_per_lane": r16,
            "per_kernel_launch": table, "steps_profiled": steps, "traffic_bytes_per_step": round(per_step),
            "traffic_bytes_per_entry_point": {k: round(v) for k, v in entry.items()},
