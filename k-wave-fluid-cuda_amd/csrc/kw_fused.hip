@@ -163,38 +163,51 @@ __device__ __forceinline__ void st_uni(float2* __restrict__ p, uint64_t uniform_
 }
 
 // Tile coordinates of a block of a y- or z-pass.  Regular tiles: NL consecutive columns kx at one line position (the
-// plane z of a y-pass, the row ky of a z-pass; blockIdx.y).  Column tile: a half-spectrum row of nxc = NL*m + 1 bins —
-// every Nx that is a multiple of 32: the extra bin is the x-Nyquist column — leaves a last tile with ONE valid lane in
-// NL.  The blocks of that tile instead take the single column at NL line positions each (lane c <-> position
-// NL * blockIdx.y + c) and the blocks left over exit at once: the same cache lines are touched as before, by 1/NL of the
-// blocks — 2064 instead of 2304 blocks per pass at 256^3.  MEASURED SLOWER and therefore off unless KW_FUSED_COLT=1: every
-// wave-level access of a column-tile block touches 64 different cache lines (one 8-B element per row) instead of four
-// whole ones, and those 16 blocks become the critical path of the launch (256^3: y-passes +12 %, z-passes 0 .. +12 %,
-// step -4 %; gpurun_out/r02_abk3.txt).  What would help is the Nyquist column stored apart as a compact [z][ky] array.
+// plane z of a y-pass, the row ky of a z-pass; blockIdx.y).
+//
+// Side tile.  A half-spectrum row has nxc = Nx/2 + 1 bins: for every Nx that is a multiple of 32 that is a whole number
+// of 16-column tiles plus ONE bin, the x-Nyquist column.  Kept in the rows it costs a ninth tile of 16 lanes with one
+// useful lane at 256^3 (11 % of every y- and z-pass; 20 % at 128^3).  The pipeline therefore stores that column apart,
+// as a compact array N[line position][y] behind the main part (rows of Nx/2 bins, no padding at all), and the passes
+// handle it with one extra tile index whose blocks take the column at NL line positions each: lane c <-> position
+// NL * blockIdx.y + c.  Same kernel, same LDS traffic; the lanes of a side block read 8-B neighbours of one array.
+// (Tried before, with the column left in the padded rows: every wave-level access then touches 64 different cache
+// lines and those blocks become the critical path — y-passes +12 %, step -4 %.)
 struct TileCoord
 {
-  uint32_t kx, kxl, pos;
-  bool     valid, dead;
+  uint32_t kx;    // true column index (operator lookups along kx)
+  uint32_t col;   // column used for addressing: min(kx, last main column), 0 in a side block
+  uint32_t pos;   // line position: z (y-pass) / ky (z-pass)
+  uint32_t pitch; // row pitch of the region this block works in: P, or 1 (side array)
+  uint32_t off;   // element offset of that region in the scratch array
+  bool     valid, dead, side;
 };
-template<int NL> __device__ __forceinline__ TileCoord tile_coord(uint32_t nxc, uint32_t colt, uint32_t npos, int c)
+template<int NL>
+__device__ __forceinline__ TileCoord tile_coord(uint32_t nxc, uint32_t P, uint32_t side_off, uint32_t npos, int c)
 {
   TileCoord t;
-  const uint32_t ct = (nxc - 1u) / NL; // the tile holding the last column (tiles past it are row padding only)
-  if (colt != 0 && blockIdx.x >= ct)
+  if (side_off != 0 && blockIdx.x == gridDim.x - 1)
   {
     const uint32_t p = blockIdx.y * NL + c;
-    t.dead  = blockIdx.x > ct || blockIdx.y * NL >= npos;
-    t.kx    = t.kxl = nxc - 1u;
+    t.dead  = blockIdx.y * NL >= npos;
+    t.kx    = nxc; // the bin after the nxc main columns
+    t.col   = 0;
     t.valid = p < npos;
     t.pos   = min(p, npos - 1u); // lanes past the last position re-read it; their results are never stored
+    t.pitch = 1;
+    t.off   = side_off;
+    t.side  = true;
   }
   else
   {
     t.kx    = blockIdx.x * NL + c;
-    t.kxl   = min(t.kx, nxc - 1u); // pad lanes re-read the last column (no branch, no extra sector); never stored
+    t.col   = min(t.kx, nxc - 1u); // pad lanes re-read the last column (no branch, no extra sector); never stored
     t.valid = t.kx < nxc;
     t.pos   = blockIdx.y;
+    t.pitch = P;
+    t.off   = 0;
     t.dead  = false;
+    t.side  = false;
   }
   return t;
 }
@@ -250,7 +263,7 @@ struct PassArgs
   uint32_t      PX;   // row pitch of the packed (exchange) side (= P unless rows travel without their padding)
   uint32_t      narr; // arrays per block (grid.z * narr arrays in the launch)
   uint32_t      z0;   // first plane of this launch (chunked plane-local passes)
-  uint32_t      colt; // the last tile of a row is a column tile (see tile_coord)
+  uint32_t      side_off; // element offset of the x-Nyquist side array, 0 = the column lives in the rows (see tile_coord)
   const float2* mul[3]; // per array: optional factor mul[ky] applied to the line before its transform (ddy of the gradient)
   RowAddr       ain, aout;
 };
@@ -267,12 +280,13 @@ __global__ __launch_bounds__(Geo<L>::THREADS) void k_ypass(PassArgs a)
   load_twiddles<L>(twl, a.tw);
   const int      c     = threadIdx.x % G::NL;
   const int      j     = threadIdx.x / G::NL;
-  const TileCoord tc   = tile_coord<G::NL>(a.nxc, a.colt, gridDim.y, c);
+  const TileCoord tc   = tile_coord<G::NL>(a.nxc, a.P, (PIN || POUT) ? 0u : a.side_off, gridDim.y, c);
   if (tc.dead) return;
-  const uint32_t kx    = tc.kx;
+  const uint32_t kx    = tc.side ? 0u : tc.kx; // addressing column (side blocks: the one column of the side array)
   const bool     valid = tc.valid;
-  const uint32_t kxl   = tc.kxl;
+  const uint32_t kxl   = tc.col;
   const uint32_t z     = tc.pos + a.z0;
+  const uint32_t Pe    = tc.pitch, soff = tc.off; // row pitch / offset of the region (main rows, or the side array)
   const uint32_t arr0  = blockIdx.z * a.narr; // each block takes a.narr arrays back to back (next one's lines prefetched)
 
   auto load_lines = [&](float2 (&v)[R1], const float2* __restrict__ Sin) {
@@ -283,9 +297,9 @@ __global__ __launch_bounds__(Geo<L>::THREADS) void k_ypass(PassArgs a)
     }
     else
     {
-      uint32_t b = (z * a.ain.zmul + j * a.ain.estride) * a.P + kxl; // estride = 1 (y lines) or ny (z probe)
+      uint32_t b = (z * a.ain.zmul + j * a.ain.estride) * Pe + kxl + soff; // estride = 1 (y lines) or ny (z probe)
       asm volatile("" : "+v"(b));
-      const uint32_t step = R2 * a.ain.estride * a.P;
+      const uint32_t step = R2 * a.ain.estride * Pe;
 #pragma unroll
       for (int n1 = 0; n1 < R1; n1++)
         v[n1] = KW_SADDR ? ld_uni(Sin, static_cast<uint64_t>(n1) * step, b * static_cast<uint32_t>(sizeof(float2))) : Sin[b + n1 * step];
@@ -328,9 +342,9 @@ __global__ __launch_bounds__(Geo<L>::THREADS) void k_ypass(PassArgs a)
         }
         else
         {
-          uint32_t b = (z * a.aout.zmul + j * a.aout.estride) * a.P + kx;
+          uint32_t b = (z * a.aout.zmul + j * a.aout.estride) * Pe + kx + soff;
           asm volatile("" : "+v"(b));
-          const uint32_t step = R1 * a.aout.estride * a.P;
+          const uint32_t step = R1 * a.aout.estride * Pe;
 #pragma unroll
           for (int k2 = 0; k2 < R2; k2++)
           {
@@ -366,7 +380,8 @@ struct ZArgs
   uint32_t      narr; // arrays processed back to back by each block (VGRAD / ABSORB)
   uint32_t      ky0;  // global ky of local row 0 (slab mode: rank * ny/nranks); ny above = number of LOCAL rows
   uint32_t      lstride, bstride; // Z_SHIFT: element stride along a line, offset per blockIdx.y (both in complex units)
-  uint32_t      colt; // the last tile of a row is a column tile (see tile_coord)
+  uint32_t      side_off;    // element offset of the x-Nyquist side array in the scratch arrays (0: none; see tile_coord)
+  uint32_t      op_side_off; // float offset of the side column's values in the imported operators
 };
 
 // inverse along the line, started from the step-B register layout (thread (c,k1) holds X[k1 + R1*k2]); result:
@@ -422,20 +437,21 @@ template<int L, int MODE> __global__ __launch_bounds__(Geo<L>::THREADS) void k_z
   load_twiddles<L>(twl, a.tw);
   const int      c      = threadIdx.x % G::NL;
   const int      j      = threadIdx.x / G::NL;
-  const TileCoord tc    = tile_coord<G::NL>(a.nxc, (MODE == Z_SHIFT) ? 0u : a.colt, gridDim.y, c);
+  const TileCoord tc    = tile_coord<G::NL>(a.nxc, a.P, (MODE == Z_SHIFT) ? 0u : a.side_off, gridDim.y, c);
   if (tc.dead) return;
-  const uint32_t kx     = tc.kx;
   const uint32_t ky     = tc.pos;
   const bool     valid  = tc.valid;
-  const uint32_t zstr   = (MODE == Z_SHIFT) ? a.lstride : a.ny * a.P;
-  const uint32_t bstr   = (MODE == Z_SHIFT) ? a.bstride : a.P;
-  const uint32_t base   = ky * bstr + kx;
-  const uint32_t kxl    = tc.kxl;
-  const uint32_t basel  = ky * bstr + kxl;
+  const uint32_t zstr   = (MODE == Z_SHIFT) ? a.lstride : a.ny * tc.pitch;
+  const uint32_t bstr   = (MODE == Z_SHIFT) ? a.bstride : tc.pitch;
+  const uint32_t kxl    = tc.kx < a.nxc ? tc.kx : (tc.side ? a.nxc : a.nxc - 1u); // true column (ddx lookups)
+  const uint32_t base   = ky * bstr + (tc.side ? 0u : tc.kx) + tc.off;
+  const uint32_t basel  = ky * bstr + tc.col + tc.off;
   // operators live in a tile-blocked layout [ky][kx tile][kz][16]: the 16 x nz values of this block's tile are one
   // contiguous run (k_import_reduced), instead of 64-B pieces a whole plane apart
   constexpr int  OPV    = op_vec(R2);
-  const uint32_t opbase = (((ky * (a.Pop / NLMAX) + kxl / NLMAX) * (R2 / OPV) * R1 + j) * NLMAX + kxl % NLMAX) * OPV;
+  // side blocks: the side column's operator values are stored like one more row of tiles whose columns are the ky
+  const uint32_t opbase = tc.side ? a.op_side_off + (((ky / NLMAX) * (R2 / OPV) * R1 + j) * NLMAX + ky % NLMAX) * OPV
+                                  : (((ky * (a.Pop / NLMAX) + tc.col / NLMAX) * (R2 / OPV) * R1 + j) * NLMAX + tc.col % NLMAX) * OPV;
   constexpr bool MULTI  = (MODE == Z_VGRAD || MODE == Z_ABSORB);
   const uint32_t arr0   = MULTI ? a.arr0 : 0;
   const uint32_t narr   = MULTI ? a.narr : 1;
@@ -625,12 +641,13 @@ __global__ __launch_bounds__(Geo<L / 2>::THREADS) void k_ypass_split(PassArgs a)
   load_twiddles_split<L>(twl, tw2, a.tw);
   const int      c     = threadIdx.x % G::NL;
   const int      j     = threadIdx.x / G::NL;
-  const TileCoord tc   = tile_coord<G::NL>(a.nxc, a.colt, gridDim.y, c);
+  const TileCoord tc   = tile_coord<G::NL>(a.nxc, a.P, (PIN || POUT) ? 0u : a.side_off, gridDim.y, c);
   if (tc.dead) return;
-  const uint32_t kx    = tc.kx;
+  const uint32_t kx    = tc.side ? 0u : tc.kx;
   const bool     valid = tc.valid;
-  const uint32_t kxl   = tc.kxl;
+  const uint32_t kxl   = tc.col;
   const uint32_t z     = tc.pos + a.z0;
+  const uint32_t Pe    = tc.pitch, soff = tc.off;
   const float2* __restrict__ Sin = a.in[blockIdx.z];
   float2* __restrict__ Sout      = a.out[blockIdx.z];
 
@@ -646,8 +663,8 @@ __global__ __launch_bounds__(Geo<L / 2>::THREADS) void k_ypass_split(PassArgs a)
   }
   else
   {
-    const uint32_t b    = (z * a.ain.zmul + j * a.ain.estride) * a.P + kxl;
-    const uint32_t step = R2 * a.ain.estride * a.P;
+    const uint32_t b    = (z * a.ain.zmul + j * a.ain.estride) * Pe + kxl + soff;
+    const uint32_t step = R2 * a.ain.estride * Pe;
 #pragma unroll
     for (int n1 = 0; n1 < R1; n1++)
     {
@@ -682,8 +699,8 @@ __global__ __launch_bounds__(Geo<L / 2>::THREADS) void k_ypass_split(PassArgs a)
     }
     else
     {
-      const uint32_t b    = (z * a.aout.zmul + 2 * j * a.aout.estride) * a.P + kx;
-      const uint32_t one  = a.aout.estride * a.P;
+      const uint32_t b    = (z * a.aout.zmul + 2 * j * a.aout.estride) * Pe + kx + soff;
+      const uint32_t one  = a.aout.estride * Pe;
       const uint32_t step = 2 * R1 * one;
 #pragma unroll
       for (int k2 = 0; k2 < R2; k2++)
@@ -715,19 +732,19 @@ template<int L, int MODE> __global__ __launch_bounds__(Geo<L / 2>::THREADS) void
   load_twiddles_split<L>(twl, tw2, a.tw);
   const int      c      = threadIdx.x % G::NL;
   const int      j      = threadIdx.x / G::NL;
-  const TileCoord tc    = tile_coord<G::NL>(a.nxc, a.colt, gridDim.y, c);
+  const TileCoord tc    = tile_coord<G::NL>(a.nxc, a.P, a.side_off, gridDim.y, c);
   if (tc.dead) return;
-  const uint32_t kx     = tc.kx;
   const uint32_t ky     = tc.pos;
   const bool     valid  = tc.valid;
-  const uint32_t zstr   = a.ny * a.P;
-  const uint32_t base   = ky * a.P + kx;
-  const uint32_t kxl    = tc.kxl;
-  const uint32_t basel  = ky * a.P + kxl;
+  const uint32_t zstr   = a.ny * tc.pitch;
+  const uint32_t kxl    = tc.kx < a.nxc ? tc.kx : (tc.side ? a.nxc : a.nxc - 1u); // true column (ddx lookups)
+  const uint32_t base   = ky * tc.pitch + (tc.side ? 0u : tc.kx) + tc.off;
+  const uint32_t basel  = ky * tc.pitch + tc.col + tc.off;
   // operators live in a tile-blocked layout [ky][kx tile][kz][16]: the 16 x nz values of this block's tile are one
   // contiguous run (k_import_reduced), instead of 64-B pieces a whole plane apart
   constexpr int  OPV    = op_vec(2 * R2); // run of this thread: bins 2*(j + R1*k2) + h at run index 2*k2 + h
-  const uint32_t opbase = (((ky * (a.Pop / NLMAX) + kxl / NLMAX) * (2 * R2 / OPV) * R1 + j) * NLMAX + kxl % NLMAX) * OPV;
+  const uint32_t opbase = tc.side ? a.op_side_off + (((ky / NLMAX) * (2 * R2 / OPV) * R1 + j) * NLMAX + ky % NLMAX) * OPV
+                                  : (((ky * (a.Pop / NLMAX) + tc.col / NLMAX) * (2 * R2 / OPV) * R1 + j) * NLMAX + tc.col % NLMAX) * OPV;
   constexpr bool MULTI  = (MODE == Z_VGRAD || MODE == Z_ABSORB);
   const uint32_t arr    = MULTI ? a.arr0 + blockIdx.z : 0;
   // PGRAD: the x- and y-gradients share one z-inverse — ddx(kx), ddy(ky) do not depend on kz, so they are applied after
@@ -848,6 +865,7 @@ struct XfwdArgs
   const float2* tw;
   uint32_t      nx, P;
   uint32_t      nrows, tile0; // rows of the grid (ny * nz); first tile of this launch
+  uint32_t      side_off;     // element offset of the x-Nyquist side array in out[] (0: the bin stays in its row)
 };
 
 // The x kernels work on tiles of 2 * NL rows.  A grid whose row count ny * nz is not a whole number of tiles ends in a
@@ -860,7 +878,7 @@ struct XfwdArgs
 template<int L, bool TAIL = false>
 __device__ __forceinline__ void xfwd_tail(float2 (&v)[Fac<L>::R1], float2* lds, int c, int f,
                                           const float2* tw, float2* __restrict__ out, uint32_t P, uint32_t tile,
-                                          uint32_t nrows = 0)
+                                          uint32_t nrows = 0, uint32_t side_off = 0)
 {
   using G = Geo<L>;
   constexpr int R1 = G::R1, R2 = G::R2, HALF = L / 2 + 1;
@@ -895,8 +913,12 @@ __device__ __forceinline__ void xfwd_tail(float2 (&v)[Fac<L>::R1], float2* lds, 
     const float2 xa = make_float2(0.5f * (zk.x + zn.x), 0.5f * (zk.y - zn.y));
     const float2 xb = make_float2(0.5f * (zk.y + zn.y), 0.5f * (zn.x - zk.x));
     const uint32_t r = tile_row0 + 2 * cc;
-    if (!TAIL || r < nrows) out[r * P + k] = xa;
-    if (!TAIL || r + 1 < nrows) out[(r + 1) * P + k] = xb;
+    // the x-Nyquist bin of a row goes to the side array N[row] when the pipeline keeps that column apart (tile_coord)
+    const bool     ny_bin = (side_off != 0) && (k == L / 2);
+    const uint32_t ia = ny_bin ? side_off + r : r * P + k;
+    const uint32_t ib = ny_bin ? ia + 1u : ia + P;
+    if (!TAIL || r < nrows) out[ia] = xa;
+    if (!TAIL || r + 1 < nrows) out[ib] = xb;
   }
   lds_barrier();
 }
@@ -922,7 +944,7 @@ template<int L, bool TAIL = false> __global__ __launch_bounds__(Geo<L>::THREADS)
     for (int n1 = 0; n1 < R1; n1++) v[n1] = make_float2(ra[n1 * R2 + f], rb[n1 * R2 + f]);
   }
   lds_barrier(); // twiddle table visible
-  xfwd_tail<L, TAIL>(v, lds, c, f, twl, a.out[blockIdx.y], a.P, tile, a.nrows);
+  xfwd_tail<L, TAIL>(v, lds, c, f, twl, a.out[blockIdx.y], a.P, tile, a.nrows, a.side_off);
 }
 
 // =====================================================================================================================
@@ -952,13 +974,15 @@ struct XinvArgs
   const float2* mulx[3]; // per component: optional factor mulx[kx] applied to the rows before the inverse (ddx of the gradient)
   uint32_t      descending; // tiles (and components) are taken from the last to the first (experiment: KW_FUSED_XINV_DESC)
   uint32_t      nrows;      // rows of the grid (ny * nz): bounds the partial last tile (TAIL kernels)
+  uint32_t      side_off;   // element offset of the x-Nyquist side array in in[] / fout[] (0: none)
 };
 
 // standalone inverse of one array for this block's 32 rows; thread (c, f<R1) ends with x[f + R1*k2] of rows (2c, 2c+1)
 template<int L, int NGRP = 1, bool TAIL = false>
 __device__ __forceinline__ void xinv_lines(const float2* __restrict__ src, uint32_t P, float2* lds, int c, int f,
                                            const float2* tw, float2 (&w)[Fac<L>::R2], uint32_t tile,
-                                           const float2* __restrict__ mulx = nullptr, uint32_t nrows = 0)
+                                           const float2* __restrict__ mulx = nullptr, uint32_t nrows = 0,
+                                           uint32_t side_off = 0)
 {
   using G = Geo<L>;
   constexpr int R1 = G::R1, R2 = G::R2, HALF = L / 2 + 1;
@@ -978,8 +1002,10 @@ __device__ __forceinline__ void xinv_lines(const float2* __restrict__ src, uint3
       const int cc = e / HALF;
       const int k  = e - cc * HALF;
       const uint32_t r = tile_row0 + 2 * cc;
-      A[it] = src[(TAIL ? min(r, nrows - 1u) : r) * P + k];
-      B[it] = src[(TAIL ? min(r + 1u, nrows - 1u) : r + 1u) * P + k];
+      const uint32_t ra = TAIL ? min(r, nrows - 1u) : r, rb = TAIL ? min(r + 1u, nrows - 1u) : r + 1u;
+      const bool     ny_bin = (side_off != 0) && (k == L / 2); // the x-Nyquist bin lives in the side array N[row]
+      A[it] = src[ny_bin ? side_off + ra : ra * P + k];
+      B[it] = src[ny_bin ? side_off + rb : rb * P + k];
     }
 #pragma unroll
     for (int it = 0; it < NG; it++)
@@ -1064,7 +1090,7 @@ __global__ __launch_bounds__(Geo<L>::THREADS, (EPI == EPI_DENSITY && L == 256) ?
   {
     float2 w[R2];
     xinv_lines<L, (EPI == EPI_DENSITY) ? 2 : 1, TAIL>(a.in[(NA == 1) ? comp : i], a.P, lds, c, f, twl, w, tile,
-                                                       (NA == 1) ? a.mulx[comp] : nullptr, a.nrows); // ends with a barrier
+                                                       (NA == 1) ? a.mulx[comp] : nullptr, a.nrows, a.side_off); // ends with a barrier
     if (ACT(R1, f))
     {
 #pragma unroll
@@ -1343,7 +1369,7 @@ __global__ __launch_bounds__(Geo<L>::THREADS, (EPI == EPI_DENSITY && L == 256) ?
           v[n1] = make_float2(ldsr[(2 * c) * RP + n1 * R2c + f], ldsr[(2 * c + 1) * RP + n1 * R2c + f]);
       }
       lds_barrier(); // the real tile aliases the exchange buffer
-      xfwd_tail<L, TAIL>(v, lds, c, f, twl, a.fout[(NA == 1) ? comp : jf], a.P, tile, a.nrows);
+      xfwd_tail<L, TAIL>(v, lds, c, f, twl, a.fout[(NA == 1) ? comp : jf], a.P, tile, a.nrows, a.side_off);
     }
   }
 }
@@ -1451,7 +1477,9 @@ template<int L, bool TAIL = false> __global__ __launch_bounds__(Geo<L>::THREADS)
 // import of a reduced real operator into the layout the z-pass reads (see load_op_run):
 // dst[ky][kx tile][q][j][c][V] <- src[kz][ky][nxc], kz = j + r1*(q*V + r)  (split lines: 2j + h + 2*r1*k2, run index 2*k2 + h)
 // (rows = nyl local ky, nzg planes: the transposed operators of slab mode have the same form)
-__global__ void k_import_reduced(float* __restrict__ dst, const float* __restrict__ src, uint32_t nxc, uint32_t P,
+// nxc: columns of the source rows; nxm <= nxc: columns that go into the row tiles (nxc - 1 when the x-Nyquist column is
+// kept apart: k_import_reduced_side stores that one)
+__global__ void k_import_reduced(float* __restrict__ dst, const float* __restrict__ src, uint32_t nxc, uint32_t nxm, uint32_t P,
                                  uint32_t nyl, uint32_t nzg, size_t total, uint32_t r1, uint32_t vec, uint32_t split)
 {
   const uint32_t nt = P / NLMAX, nq = nzg / (r1 * vec);
@@ -1468,7 +1496,27 @@ __global__ void k_import_reduced(float* __restrict__ dst, const float* __restric
     const uint32_t ri = q * vec + r4; // position in the thread's run
     const uint32_t kz = split ? 2u * j + (ri & 1u) + 2u * r1 * (ri >> 1) : j + r1 * ri;
     const uint32_t kx = t * NLMAX + c;
-    dst[e] = (kx < nxc) ? src[(static_cast<size_t>(kz) * nyl + ky) * nxc + kx] : 0.f;
+    dst[e] = (kx < nxm) ? src[(static_cast<size_t>(kz) * nyl + ky) * nxc + kx] : 0.f;
+  }
+}
+// the side column (kx = nxc - 1) in the same per-thread run layout, its 16-wide tiles running over ky:
+// dst[ky tile][q][j][c][V] <- src[kz][ky = 16 * tile + c][nxc - 1]
+__global__ void k_import_reduced_side(float* __restrict__ dst, const float* __restrict__ src, uint32_t nxc, uint32_t nyl,
+                                      uint32_t nzg, size_t total, uint32_t r1, uint32_t vec, uint32_t split)
+{
+  const uint32_t nq = nzg / (r1 * vec);
+  for (size_t e = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x; e < total;
+       e += static_cast<size_t>(gridDim.x) * blockDim.x)
+  {
+    size_t         r  = e;
+    const uint32_t r4 = static_cast<uint32_t>(r % vec); r /= vec;
+    const uint32_t c  = static_cast<uint32_t>(r % NLMAX); r /= NLMAX;
+    const uint32_t j  = static_cast<uint32_t>(r % r1); r /= r1;
+    const uint32_t q  = static_cast<uint32_t>(r % nq); r /= nq;
+    const uint32_t ky = static_cast<uint32_t>(r) * NLMAX + c;
+    const uint32_t ri = q * vec + r4;
+    const uint32_t kz = split ? 2u * j + (ri & 1u) + 2u * r1 * (ri >> 1) : j + r1 * ri;
+    dst[e] = (ky < nyl) ? src[(static_cast<size_t>(kz) * nyl + ky) * nxc + (nxc - 1u)] : 0.f;
   }
 }
 
@@ -1662,6 +1710,7 @@ kw_status launch_xfwd(kw_ctx* ctx, int narr, const float* const* in, float2* con
   a.tw = ctx->fused.tw[0];
   a.nx = c.nx;
   a.P  = ctx->fused.P;
+  a.side_off = ctx->fused.side_off;
   a.nrows = c.ny * c.nz;
   const uint32_t rows_per_tile = 2u * static_cast<uint32_t>(nl_of(c.nx)), full = a.nrows / rows_per_tile;
   if (full > 0)
@@ -1703,27 +1752,28 @@ kw_status launch_ypass(kw_ctx* ctx, int dir, int narr, float2* const* in, float2
   PassArgs a{};
   for (int i = 0; i < narr; i++) { a.in[i] = in[i]; a.out[i] = out[i]; a.mul[i] = mul ? mul[i] : nullptr; }
   a.tw  = f.tw[1];
-  a.nxc = c.nx_complex;
+  a.nxc = f.nxm;
   a.P   = f.P;
   a.PX  = f.PX;
+  a.side_off = (pack_in || pack_out) ? 0u : f.side_off;
+  const uint32_t side_tile = (a.side_off != 0) ? 1u : 0u; // one more tile index: the blocks of the x-Nyquist side array
   const RowAddr natural{0u, 0u, 0u, c.ny, 1u};
   const RowAddr packed{(1u << 20) / f.nyl + 1u, f.nyl, c.nz * f.nyl, f.nyl, 1u};
   a.ain  = pack_in ? packed : natural;
   a.aout = pack_out ? packed : natural;
   a.narr = f.ypass_loop ? narr : 1;
   a.z0   = z0;
-  a.colt = (f.colt && c.nx_complex % static_cast<uint32_t>((c.ny == 512 && f.split512) ? NLMAX : nl_of(c.ny)) == 1u) ? 1u : 0u;
   if (c.ny == 512 && f.split512)
   { // 2 x 256 lines: 16-column tiles, one array per block
     a.narr = 1;
-    const dim3 g(f.P / NLMAX, nzc ? nzc : c.nz, narr), b(Geo<256>::THREADS);
+    const dim3 g(f.P / NLMAX + side_tile, nzc ? nzc : c.nz, narr), b(Geo<256>::THREADS);
     if (dir < 0) { if (pack_out) LAUNCH((k_ypass_split<512, kFwd, false, true>), g, b, a);
                    else LAUNCH((k_ypass_split<512, kFwd, false, false>), g, b, a); }
     else         { if (pack_in) LAUNCH((k_ypass_split<512, kInv, true, false>), g, b, a);
                    else LAUNCH((k_ypass_split<512, kInv, false, false>), g, b, a); }
     return KW_OK;
   }
-  const dim3 grid(f.P / nl_of(c.ny), nzc ? nzc : c.nz, narr / a.narr);
+  const dim3 grid(f.P / nl_of(c.ny) + side_tile, nzc ? nzc : c.nz, narr / a.narr);
   // forward: natural in, natural or packed out; inverse: natural or packed in, natural out
 #define M(LEN)                                                                                                         \
   if (dir < 0) { if (pack_out) LAUNCH((k_ypass<LEN, kFwd, false, true>), grid, dim3(Geo<LEN>::THREADS), a);           \
@@ -1747,20 +1797,22 @@ template<int MODE> kw_status launch_zfused(kw_ctx* ctx, int narr, ZArgs a)
   KW_PROF(ctx, names[MODE][narr - 1]);
   a.tw      = f.tw[2];
   a.divider = c.fft_divider;
-  a.nxc     = c.nx_complex;
+  a.nxc     = f.nxm;
+  a.side_off    = f.side_off;
+  a.op_side_off = f.side_off; // the imported operators hold the side column's values behind the P * ny * nz of the row tiles
+  const uint32_t side_tile = (f.side_off != 0) ? 1u : 0u;
   a.P       = f.slab ? f.PX : f.P; // slab mode: the z-pass works on the exchanged rows in place
   a.Pop     = f.P;
   a.ny      = f.nyl;
   a.nz      = f.nz_global;
   a.ky0     = f.rank * f.nyl;
   a.narr    = narr;
-  a.colt    = (f.colt && c.nx_complex % static_cast<uint32_t>((f.nz_global == 512 && f.split512) ? NLMAX : nl_of(f.nz_global)) == 1u) ? 1u : 0u;
   if (f.nz_global == 512 && f.split512)
   {
-    LAUNCH((k_zfused_split<512, MODE>), dim3(f.P / NLMAX, f.nyl, narr), dim3(Geo<256>::THREADS), a);
+    LAUNCH((k_zfused_split<512, MODE>), dim3(f.P / NLMAX + side_tile, f.nyl, narr), dim3(Geo<256>::THREADS), a);
     return KW_OK;
   }
-  const dim3 grid(f.P / nl_of(f.nz_global), f.nyl, 1);
+  const dim3 grid(f.P / nl_of(f.nz_global) + side_tile, f.nyl, 1);
 #define M(LEN) LAUNCH((k_zfused<LEN, MODE>), grid, dim3(Geo<LEN>::THREADS), a)
   KW_LEN_SWITCH(f.nz_global, M)
 #undef M
@@ -1786,6 +1838,7 @@ kw_status launch_xinv_impl(kw_ctx* ctx, int ncomp, XinvArgs a, uint32_t z0, uint
   a.tw = ctx->fused.tw[0];
   a.c  = c;
   a.P  = ctx->fused.P;
+  a.side_off = ctx->fused.side_off;
   a.nrows = c.ny * c.nz;
   a.descending = ctx->fused.xinv_desc ? 1u : 0u;
   const uint32_t rows_per_tile = 2u * static_cast<uint32_t>(nl_of(c.nx));
@@ -1949,7 +2002,7 @@ kw_status alloc_scratch(kw_ctx* ctx, void* const s[3], void* const t[3])
 {
   auto& f = ctx->fused;
   const kw_constants& c = ctx->c;
-  const size_t elems = static_cast<size_t>(f.P) * c.ny * c.nz;
+  const size_t elems = static_cast<size_t>(f.Palloc) * c.ny * c.nz;
   f.owns_scratch     = (s == nullptr);
   for (int i = 0; i < 3; i++)
   {
@@ -1991,7 +2044,16 @@ kw_status create_impl(kw_ctx* ctx, void* const s[3], void* const t[3])
   const kw_constants& c = ctx->c;
   f.nz_global = (f.slab) ? slab.nz_global : c.nz;
   f.nyl       = c.ny / f.nranks;
-  f.P         = (c.nx_complex + NLMAX - 1) / NLMAX * NLMAX;
+  f.Palloc    = (c.nx_complex + NLMAX - 1) / NLMAX * NLMAX;
+  {
+    // x-Nyquist column apart (see tile_coord) whenever it is the one bin beyond whole tiles; not on slabs, whose
+    // exchange chunks are plain [z][ky][P] blocks.  KW_FUSED_SIDE=0 keeps it in the (padded) rows (A/B).
+    const char* e   = getenv("KW_FUSED_SIDE");
+    const bool side = !f.slab && (e == nullptr || e[0] != '0') && (c.nx_complex % NLMAX == 1u) && (c.nx_complex > NLMAX);
+    f.nxm      = side ? c.nx_complex - 1u : c.nx_complex;
+    f.P        = side ? f.nxm : f.Palloc;
+    f.side_off = side ? f.P * c.ny * c.nz : 0u;
+  }
   // Exchange-side row pitch.  Default: the padded pitch — every 16-column tile segment of the packed y-passes and of the
   // transposed z-pass is one aligned 128-B line.  KW_SLAB_UNPADDED=1 sends rows without their padding (nx/2+1 complex:
   // -10 % wire bytes at 256, -5.5 % at 512) at the price of tile segments that straddle two lines: measured on one
@@ -2026,8 +2088,6 @@ kw_status create_impl(kw_ctx* ctx, void* const s[3], void* const t[3])
     f.split512    = (e == nullptr) || (e[0] != '0');
     e             = getenv("KW_FUSED_YPASS_LOOP");
     f.ypass_loop  = (e == nullptr) || (e[0] != '0');
-    e             = getenv("KW_FUSED_COLT");
-    f.colt        = (e != nullptr) && (e[0] != '0');
   }
   f.ready = true;
   return KW_OK;
@@ -2167,7 +2227,7 @@ kw_status kw_fused_reduced_elems(kw_ctx* ctx, size_t* out)
 {
   KW_FUSED_READY(ctx);
   KW_REQUIRE(out != nullptr);
-  *out = static_cast<size_t>(ctx->fused.P) * ctx->c.ny * ctx->c.nz;
+  *out = static_cast<size_t>(ctx->fused.Palloc) * ctx->c.ny * ctx->c.nz;
   return KW_OK;
 }
 
@@ -2177,7 +2237,6 @@ kw_status kw_fused_import_reduced(kw_ctx* ctx, float* dst_padded, const float* s
   KW_FUSED_READY(ctx);
   KW_REQUIRE(dst_padded && src);
   const kw_constants& c = ctx->c;
-  const size_t total = static_cast<size_t>(c.ny) * c.nz * ctx->fused.P;
   // factorisation of the z lines, as the z-pass kernels are instantiated
   const bool split = (ctx->fused.nz_global == 512 && ctx->fused.split512);
   uint32_t r1 = Fac<256>::R1, r2 = Fac<256>::R2; // the split lines are built on the 256-point transform
@@ -2190,8 +2249,16 @@ kw_status kw_fused_import_reduced(kw_ctx* ctx, float* dst_padded, const float* s
       default: kw_set_error("kw_fused_import_reduced: unsupported length %u", ctx->fused.nz_global); return KW_ERR_INVALID;
     }
   const uint32_t vec = static_cast<uint32_t>(op_vec(static_cast<int>(split ? 2 * r2 : r2)));
-  LAUNCH(k_import_reduced, dim3(ctx->cu_count * 8), dim3(256), dst_padded, src, c.nx_complex, ctx->fused.P,
-         ctx->fused.nyl, ctx->fused.nz_global, total, r1, vec, split ? 1u : 0u);
+  const auto& f = ctx->fused;
+  const size_t main_total = static_cast<size_t>(c.ny) * c.nz * f.P; // (f.P = row pitch of the main part: nxm rounded up to 16)
+  LAUNCH(k_import_reduced, dim3(ctx->cu_count * 8), dim3(256), dst_padded, src, c.nx_complex, f.nxm, f.P, f.nyl, f.nz_global,
+         main_total, r1, vec, split ? 1u : 0u);
+  if (f.side_off != 0)
+  { // ceil(nyl / 16) tiles of 16 ky x nz values
+    const size_t side_total = static_cast<size_t>((f.nyl + NLMAX - 1) / NLMAX) * NLMAX * f.nz_global;
+    LAUNCH(k_import_reduced_side, dim3(ctx->cu_count * 2), dim3(256), dst_padded + main_total, src, c.nx_complex, f.nyl,
+           f.nz_global, side_total, r1, vec, split ? 1u : 0u);
+  }
   return KW_OK;
 }
 
@@ -2542,7 +2609,7 @@ kw_status kw_fused_probe(kw_ctx* ctx, int which, const float* op)
     PassArgs a{};
     a.in[0] = f.s[0]; a.out[0] = f.s[0];
     a.tw  = f.tw[2];
-    a.nxc = c.nx_complex;
+    a.nxc = f.nxm;
     a.P   = f.P;
     a.narr = 1;
     a.ain = a.aout = RowAddr{0u, 0u, 0u, 1u, c.ny}; // element k of line (ky = blockIdx.y): row k*ny + ky
@@ -2563,7 +2630,7 @@ kw_status kw_fused_probe(kw_ctx* ctx, int which, const float* op)
     KW_REQUIRE(c.nz == c.ny && Fac<256>::R1 == Fac<256>::R2);
     PassArgs a{};
     a.out[0] = f.s[0];
-    a.nxc = c.nx_complex;
+    a.nxc = f.nxm;
     a.P   = f.P;
     a.ain = (which <= 12) ? RowAddr{0u, 0u, 0u, c.ny, 1u} : RowAddr{0u, 0u, 0u, 1u, c.ny};
     const dim3 grid(f.P / nl_of(c.ny), c.nz, 1);
@@ -2579,7 +2646,7 @@ kw_status kw_fused_probe(kw_ctx* ctx, int which, const float* op)
     KW_REQUIRE(c.nz == c.ny && c.ny == 256);
     PassArgs a{};
     a.out[0] = f.s[0];
-    a.nxc = c.nx_complex;
+    a.nxc = f.nxm;
     a.P   = f.P;
     a.ain = (which == 15) ? RowAddr{0u, 0u, 0u, c.ny, 1u} : RowAddr{0u, 0u, 0u, 1u, c.ny};
     LAUNCH((k_probe_tile_wide<256>), dim3((f.P + 31) / 32, c.nz, 1), dim3(256), a);
@@ -2591,7 +2658,7 @@ kw_status kw_fused_probe(kw_ctx* ctx, int which, const float* op)
     const int w = which - 30;
     PassArgs a{};
     a.out[0] = f.s[0];
-    a.nxc = c.nx_complex;
+    a.nxc = f.nxm;
     a.P   = f.P;
     a.ain = (w & 1) ? RowAddr{0u, 0u, 0u, 1u, c.ny} : RowAddr{0u, 0u, 0u, c.ny, 1u};
     const int  vec = (w & 2) ? 2 : 1;

@@ -45,11 +45,13 @@ struct kw_ctx
     bool     per_array = false;                    // launch order: chain per array instead of batched (A/B knob; batched is faster)
     bool     ypass_loop = true;                    // y-pass blocks walk the arrays of a launch (prefetching) instead of one array per block
     bool     split512 = true;                      // 512-point y / z lines as 2 x 256 (A/B knob against the 16 x 32 kernels)
-    bool     colt = false;                         // x-Nyquist column handled by column tiles in the y / z passes (KW_FUSED_COLT=1; measured slower)
+    uint32_t nxm = 0;                              // columns kept in the rows: nx/2+1, or nx/2 when the x-Nyquist column is kept apart
+    uint32_t side_off = 0;                         // element offset of that column's compact array N[z][y] in s[] (0: none)
+    uint32_t Palloc = 0;                           // pitch the scratch / imported operator arrays are sized by (nx/2+1 rounded up to 16)
     bool     xinv_desc = false;                    // x-inverse kernels take their tiles last-to-first (KW_FUSED_XINV_DESC)
     uint32_t zchunks = 1;                          // plane-local passes (y^-1, x^-1 + epilogue, chained x, y) run per chunk of planes
     int      y_done  = 0;                          // chained spectra in s[0..y_done) already carry their forward y-pass
-    uint32_t P     = 0;                            // padded half-spectrum row pitch (complex), multiple of 16
+    uint32_t P     = 0;                            // row pitch of the spectra (complex), multiple of 16: nxm rounded up
     uint32_t PX    = 0;                            // row pitch of exchange-side buffers (slab mode: nx/2+1, no padding)
     float2*  s[3]  = {nullptr, nullptr, nullptr};  // three padded complex scratch arrays [nz][ny][P]
     float2*  tw[3] = {nullptr, nullptr, nullptr};  // exp(-2 pi i m / n) for n = nx, ny, nz
