@@ -310,8 +310,11 @@ KW_API kw_status kw_fused_set_slab(kw_ctx* ctx, uint32_t nranks, uint32_t rank, 
                                    kw_exchange_fn exchange, void* user);   /* before kw_fused_create; NULL = RCCL path */
 /* Optional split-phase form of the same all-to-all, so that transposes overlap with compute: start(user, send, recv,
  * bytes_per_peer, slot) begins the exchange (ordered after the work enqueued so far on the context's stream) and
- * returns; wait(user, slot) makes the context's stream wait for that exchange (slot in 0..2, one exchange in flight per
- * slot).  E.g. all_to_all_single(async_op=True) / work.wait().  Without it the blocking callback is used. */
+ * returns; wait(user, slot) makes the context's stream wait for that exchange (slot in 0..5, one exchange in flight per
+ * slot).  E.g. all_to_all_single(async_op=True) / work.wait().  Without it the blocking callback is used.
+ * A spectral array travels as two pieces when its x-Nyquist bins are kept in the side array (even Nx, the default):
+ * the rows on slot 0..2 and the side array on slot + 3 — the callbacks see two exchanges per array, the library's own
+ * RCCL path puts both pieces into one group. */
 typedef int (*kw_exchange_start_fn)(void* user, void* send, void* recv, size_t bytes_per_peer, int slot);
 typedef int (*kw_exchange_wait_fn)(void* user, int slot);
 KW_API kw_status kw_fused_set_slab_async(kw_ctx* ctx, kw_exchange_start_fn start, kw_exchange_wait_fn wait);

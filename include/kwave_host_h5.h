@@ -21,6 +21,16 @@ KWH_API int kwh_write_output_file(kwh_solver* s, const char* path);
 /* the same with the reference's -c <deflate level 0..9> (datasets are chunked as in RealMatrix.cpp:88-121 either way) and
  * --copy_sensor_mask (KSpaceFirstOrderSolver.cpp:1036-1052: sensor_mask_index / sensor_mask_corners, 1-based) */
 KWH_API int kwh_write_output_file_ex(kwh_solver* s, const char* path, uint32_t compression_level, int32_t copy_sensor_mask);
+/* Per-step output (OutputStreamContainer.cpp:380-403, IndexOutputStream.cpp:87-160, :348-372): open the output file before
+ * the first step; every stored time series (raw and compression streams) then owns its dataset(s) in it and appends one
+ * hyperslab per sampled step / finished frame through a writer thread, instead of being held in host memory until the
+ * end.  kwh_write_output_file(_ex) on the same path completes the file.  reopen != 0 continues the output file of a
+ * checkpointed run (call before kwh_checkpoint_read). */
+KWH_API int kwh_open_output_file(kwh_solver* s, const char* path, uint32_t compression_level, int32_t reopen);
+/* --post (KSpaceFirstOrderSolver.cpp:373-415, :977-1024): for a solver created with kwh_options.only_post_processing —
+ * I_avg / Q_term from the p and u_non_staggered series, I_avg_c / Q_term_c from the coefficient frames that an earlier
+ * run stored in the output file `path`; the results are added to that file (replacing earlier ones of the same name). */
+KWH_API int kwh_post_process_output_file(kwh_solver* s, const char* path);
 /* write an input file from in-memory datasets (what the MATLAB side / a generator produces); is_complex[i] != 0 marks
  * interleaved complex float data (domain_type = "complex", fastest dimension doubled: Hdf5File.cpp:898-915) */
 KWH_API int kwh_write_input_file(const char* path, const kwh_dataset* datasets, size_t n, const int32_t* is_complex);

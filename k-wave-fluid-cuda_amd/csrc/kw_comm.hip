@@ -96,29 +96,43 @@ void release(kw_comm_state* st)
 } // namespace
 
 // ---- used by the pipeline (kw_fused.hip) ----------------------------------------------------------------------------
-kw_status kw_comm_exchange_start(kw_ctx* ctx, int slot, const void* send, void* recv, size_t bytes_per_peer)
+// One all-to-all of up to two regions (the spectral rows and, behind them, the x-Nyquist side array): every peer's
+// chunk of both goes out in the same RCCL group, so the pair costs one launch of the communication kernel.
+kw_status kw_comm_exchange_start2(kw_ctx* ctx, int slot, const void* send, void* recv, size_t bytes_per_peer,
+                                  const void* send2, void* recv2, size_t bytes_per_peer2)
 {
   kw_comm_state* st = ctx->comm;
   if (st == nullptr) { kw_set_error("kw_comm: no communicator (kw_comm_init has not been called)"); return KW_ERR_STATE; }
   KW_REQUIRE(slot >= 0 && slot < KW_COMM_SLOTS && send != nullptr && recv != nullptr && bytes_per_peer % sizeof(float) == 0);
+  KW_REQUIRE(bytes_per_peer2 == 0 || (send2 != nullptr && recv2 != nullptr && bytes_per_peer2 % sizeof(float) == 0));
   KW_HIP(hipEventRecord(st->ready[slot], ctx->stream));
   KW_HIP(hipStreamWaitEvent(st->stream, st->ready[slot], 0));
-  const size_t count = bytes_per_peer / sizeof(float);
-  const char*  s     = static_cast<const char*>(send);
-  char*        r     = static_cast<char*>(recv);
+  const size_t count[2] = {bytes_per_peer / sizeof(float), bytes_per_peer2 / sizeof(float)};
+  const char*  s[2]     = {static_cast<const char*>(send), static_cast<const char*>(send2)};
+  char*        r[2]     = {static_cast<char*>(recv), static_cast<char*>(recv2)};
+  const size_t bytes[2] = {bytes_per_peer, bytes_per_peer2};
   KW_NCCL(st, st->groupStart());
   for (uint32_t q = 0; q < st->nranks; q++)
   {
     // peers are taken starting from the right-hand neighbour: rank r talks to r+1, r+2, ... — no two ranks open with
     // the same peer, so the first chunks of every rank go out on different links
     const uint32_t peer = (st->rank + 1 + q) % st->nranks;
-    KW_NCCL(st, st->send(s + peer * bytes_per_peer, count, ncclFloat, static_cast<int>(peer), st->comm, st->stream));
-    KW_NCCL(st, st->recv(r + peer * bytes_per_peer, count, ncclFloat, static_cast<int>(peer), st->comm, st->stream));
+    for (int part = 0; part < 2; part++)
+    {
+      if (count[part] == 0) continue;
+      KW_NCCL(st, st->send(s[part] + peer * bytes[part], count[part], ncclFloat, static_cast<int>(peer), st->comm, st->stream));
+      KW_NCCL(st, st->recv(r[part] + peer * bytes[part], count[part], ncclFloat, static_cast<int>(peer), st->comm, st->stream));
+    }
   }
   KW_NCCL(st, st->groupEnd());
   KW_HIP(hipEventRecord(st->done[slot], st->stream));
   st->exchanges++;
   return KW_OK;
+}
+
+kw_status kw_comm_exchange_start(kw_ctx* ctx, int slot, const void* send, void* recv, size_t bytes_per_peer)
+{
+  return kw_comm_exchange_start2(ctx, slot, send, recv, bytes_per_peer, nullptr, nullptr, 0);
 }
 
 kw_status kw_comm_exchange_wait(kw_ctx* ctx, int slot)

@@ -280,20 +280,21 @@ __global__ __launch_bounds__(Geo<L>::THREADS) void k_ypass(PassArgs a)
   load_twiddles<L>(twl, a.tw);
   const int      c     = threadIdx.x % G::NL;
   const int      j     = threadIdx.x / G::NL;
-  const TileCoord tc   = tile_coord<G::NL>(a.nxc, a.P, (PIN || POUT) ? 0u : a.side_off, gridDim.y, c);
+  const TileCoord tc   = tile_coord<G::NL>(a.nxc, a.P, a.side_off, gridDim.y, c);
   if (tc.dead) return;
   const uint32_t kx    = tc.side ? 0u : tc.kx; // addressing column (side blocks: the one column of the side array)
   const bool     valid = tc.valid;
   const uint32_t kxl   = tc.col;
   const uint32_t z     = tc.pos + a.z0;
   const uint32_t Pe    = tc.pitch, soff = tc.off; // row pitch / offset of the region (main rows, or the side array)
+  const uint32_t PXe   = tc.side ? 1u : a.PX;     // the same on the packed (exchange) side: per-peer chunks of the side array
   const uint32_t arr0  = blockIdx.z * a.narr; // each block takes a.narr arrays back to back (next one's lines prefetched)
 
   auto load_lines = [&](float2 (&v)[R1], const float2* __restrict__ Sin) {
     if (PIN)
     {
 #pragma unroll
-      for (int n1 = 0; n1 < R1; n1++) v[n1] = Sin[a.ain.row(z, n1 * R2 + j) * a.PX + kxl];
+      for (int n1 = 0; n1 < R1; n1++) v[n1] = Sin[a.ain.row(z, n1 * R2 + j) * PXe + kxl + soff];
     }
     else
     {
@@ -338,7 +339,7 @@ __global__ __launch_bounds__(Geo<L>::THREADS) void k_ypass(PassArgs a)
         if (POUT)
         {
 #pragma unroll
-          for (int k2 = 0; k2 < R2; k2++) Sout[a.aout.row(z, j + R1 * k2) * a.PX + kx] = w[k2];
+          for (int k2 = 0; k2 < R2; k2++) Sout[a.aout.row(z, j + R1 * k2) * PXe + kx + soff] = w[k2];
         }
         else
         {
@@ -641,13 +642,14 @@ __global__ __launch_bounds__(Geo<L / 2>::THREADS) void k_ypass_split(PassArgs a)
   load_twiddles_split<L>(twl, tw2, a.tw);
   const int      c     = threadIdx.x % G::NL;
   const int      j     = threadIdx.x / G::NL;
-  const TileCoord tc   = tile_coord<G::NL>(a.nxc, a.P, (PIN || POUT) ? 0u : a.side_off, gridDim.y, c);
+  const TileCoord tc   = tile_coord<G::NL>(a.nxc, a.P, a.side_off, gridDim.y, c);
   if (tc.dead) return;
   const uint32_t kx    = tc.side ? 0u : tc.kx;
   const bool     valid = tc.valid;
   const uint32_t kxl   = tc.col;
   const uint32_t z     = tc.pos + a.z0;
   const uint32_t Pe    = tc.pitch, soff = tc.off;
+  const uint32_t PXe   = tc.side ? 1u : a.PX;
   const float2* __restrict__ Sin = a.in[blockIdx.z];
   float2* __restrict__ Sout      = a.out[blockIdx.z];
 
@@ -657,8 +659,8 @@ __global__ __launch_bounds__(Geo<L / 2>::THREADS) void k_ypass_split(PassArgs a)
 #pragma unroll
     for (int n1 = 0; n1 < R1; n1++)
     {
-      va[n1] = Sin[a.ain.row(z, n1 * R2 + j) * a.PX + kxl];
-      vb[n1] = Sin[a.ain.row(z, H + n1 * R2 + j) * a.PX + kxl];
+      va[n1] = Sin[a.ain.row(z, n1 * R2 + j) * PXe + kxl + soff];
+      vb[n1] = Sin[a.ain.row(z, H + n1 * R2 + j) * PXe + kxl + soff];
     }
   }
   else
@@ -693,8 +695,8 @@ __global__ __launch_bounds__(Geo<L / 2>::THREADS) void k_ypass_split(PassArgs a)
 #pragma unroll
       for (int k2 = 0; k2 < R2; k2++)
       {
-        Sout[a.aout.row(z, 2 * (j + R1 * k2)) * a.PX + kx]     = wa[k2];
-        Sout[a.aout.row(z, 2 * (j + R1 * k2) + 1) * a.PX + kx] = wb[k2];
+        Sout[a.aout.row(z, 2 * (j + R1 * k2)) * PXe + kx + soff]     = wa[k2];
+        Sout[a.aout.row(z, 2 * (j + R1 * k2) + 1) * PXe + kx + soff] = wb[k2];
       }
     }
     else
@@ -1755,7 +1757,7 @@ kw_status launch_ypass(kw_ctx* ctx, int dir, int narr, float2* const* in, float2
   a.nxc = f.nxm;
   a.P   = f.P;
   a.PX  = f.PX;
-  a.side_off = (pack_in || pack_out) ? 0u : f.side_off;
+  a.side_off = f.side_off; // (packed sides: the side array travels as per-peer chunks [nz local][nyl] behind the row chunks)
   const uint32_t side_tile = (a.side_off != 0) ? 1u : 0u; // one more tile index: the blocks of the x-Nyquist side array
   const RowAddr natural{0u, 0u, 0u, c.ny, 1u};
   const RowAddr packed{(1u << 20) / f.nyl + 1u, f.nyl, c.nz * f.nyl, f.nyl, 1u};
@@ -1877,12 +1879,26 @@ kw_status xstart_bytes(kw_ctx* ctx, int slot, void* send, void* recv, size_t byt
   if (rc != 0) { kw_set_error("slab exchange: the caller's exchange callback failed (status %d)", rc); return KW_ERR_COMM; }
   return KW_OK;
 }
+kw_status xwait_one(kw_ctx* ctx, int slot);
 kw_status xstart(kw_ctx* ctx, int slot, float2* send, float2* recv)
-{ // one spectral scratch array: nz local planes x nyl rows per peer
+{ // one spectral scratch array: nz local planes x nyl rows per peer, and the same of the x-Nyquist side array behind them
   const auto& f = ctx->fused;
-  return xstart_bytes(ctx, slot, send, recv, static_cast<size_t>(ctx->c.nz) * f.nyl * f.PX * sizeof(float2));
+  const size_t rows = static_cast<size_t>(ctx->c.nz) * f.nyl;
+  if (f.side_off == 0) return xstart_bytes(ctx, slot, send, recv, rows * f.PX * sizeof(float2));
+  if (f.exchange_start == nullptr && f.exchange == nullptr) // the library's exchange: both pieces in one RCCL group
+    return kw_comm_exchange_start2(ctx, slot, send, recv, rows * f.PX * sizeof(float2), send + f.side_off, recv + f.side_off,
+                                   rows * sizeof(float2));
+  KW_TRY(xstart_bytes(ctx, slot, send, recv, rows * f.PX * sizeof(float2)));
+  return xstart_bytes(ctx, slot + KW_COMM_SLOTS, send + f.side_off, recv + f.side_off, rows * sizeof(float2));
 }
 kw_status xwait(kw_ctx* ctx, int slot)
+{
+  const auto& f = ctx->fused;
+  KW_TRY(xwait_one(ctx, slot));
+  if (f.side_off != 0 && f.exchange_start != nullptr) KW_TRY(xwait_one(ctx, slot + KW_COMM_SLOTS)); // callback pair: the side piece
+  return KW_OK;
+}
+kw_status xwait_one(kw_ctx* ctx, int slot)
 {
   const auto& f = ctx->fused;
   if (f.exchange_start == nullptr && f.exchange == nullptr) return kw_comm_exchange_wait(ctx, slot);
@@ -2046,10 +2062,11 @@ kw_status create_impl(kw_ctx* ctx, void* const s[3], void* const t[3])
   f.nyl       = c.ny / f.nranks;
   f.Palloc    = (c.nx_complex + NLMAX - 1) / NLMAX * NLMAX;
   {
-    // x-Nyquist column apart (see tile_coord) whenever it is the one bin beyond whole tiles; not on slabs, whose
-    // exchange chunks are plain [z][ky][P] blocks.  KW_FUSED_SIDE=0 keeps it in the (padded) rows (A/B).
+    // x-Nyquist column apart (see tile_coord) whenever it is the one bin beyond whole tiles.  On slabs the exchange then
+    // moves two pieces per peer — the row chunk [nz local][nyl][Nx/2] and the side chunk [nz local][nyl] — i.e. exactly
+    // the Nx/2 + 1 bins per row, in aligned rows.  KW_FUSED_SIDE=0 keeps the column in the (padded) rows (A/B).
     const char* e   = getenv("KW_FUSED_SIDE");
-    const bool side = !f.slab && (e == nullptr || e[0] != '0') && (c.nx_complex % NLMAX == 1u) && (c.nx_complex > NLMAX);
+    const bool side = (e == nullptr || e[0] != '0') && (c.nx_complex % NLMAX == 1u) && (c.nx_complex > NLMAX);
     f.nxm      = side ? c.nx_complex - 1u : c.nx_complex;
     f.P        = side ? f.nxm : f.Palloc;
     f.side_off = side ? f.P * c.ny * c.nz : 0u;
@@ -2061,7 +2078,7 @@ kw_status create_impl(kw_ctx* ctx, void* const s[3], void* const t[3])
   // (profiles/r02_statsslab_*), i.e. +0.45 ms of local time per step for 0.2 ms less on the wire at 8 GPUs / 512^3.
   {
     const char* e = getenv("KW_SLAB_UNPADDED");
-    f.PX = (f.slab && e != nullptr && e[0] != '0') ? c.nx_complex : f.P;
+    f.PX = (f.slab && f.side_off == 0 && e != nullptr && e[0] != '0') ? c.nx_complex : f.P;
   }
   KW_TRY(alloc_scratch(ctx, s, t));
   const uint32_t lens[3] = { c.nx, c.ny, f.nz_global };
@@ -2502,7 +2519,7 @@ kw_status kw_fused_shift_velocity(kw_ctx* ctx, int axis, const float* in, float*
       KW_HIP(hipMemcpy2DAsync(snd + q * chunk, nyl * row, in + static_cast<size_t>(q) * nyl * c.nx, c.ny * row, nyl * row, nzl,
                               hipMemcpyDeviceToDevice, ctx->stream));
     KW_TRY(xstart_bytes(ctx, 1, snd, rcv, chunk * sizeof(float)));
-    KW_TRY(xwait(ctx, 1));
+    KW_TRY(xwait_one(ctx, 1));
     ZArgs z{};
     z.in[0]   = reinterpret_cast<const float2*>(rcv);
     z.out[0]  = reinterpret_cast<float2*>(rcv);
@@ -2521,7 +2538,7 @@ kw_status kw_fused_shift_velocity(kw_ctx* ctx, int axis, const float* in, float*
     KW_LEN_SWITCH(f.nz_global, M)
 #undef M
     KW_TRY(xstart_bytes(ctx, 1, rcv, snd, chunk * sizeof(float)));
-    KW_TRY(xwait(ctx, 1));
+    KW_TRY(xwait_one(ctx, 1));
     for (uint32_t q = 0; q < P; q++)
       KW_HIP(hipMemcpy2DAsync(out + static_cast<size_t>(q) * nyl * c.nx, c.ny * row, snd + q * chunk, nyl * row, nyl * row, nzl,
                               hipMemcpyDeviceToDevice, ctx->stream));

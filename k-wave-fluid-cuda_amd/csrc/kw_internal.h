@@ -97,6 +97,8 @@ struct kw_prof_scope
 
 // split-phase all-to-all on the context's communicator (kw_comm.hip); slot < KW_COMM_SLOTS
 kw_status kw_comm_exchange_start(kw_ctx* ctx, int slot, const void* send, void* recv, size_t bytes_per_peer);
+kw_status kw_comm_exchange_start2(kw_ctx* ctx, int slot, const void* send, void* recv, size_t bytes_per_peer, const void* send2,
+                                  void* recv2, size_t bytes_per_peer2);
 kw_status kw_comm_exchange_wait(kw_ctx* ctx, int slot);
 
 // thread-local error text (kw_last_error)

@@ -157,11 +157,20 @@ class SlabExchange:
             capi.check(capi.load().kw_set_stream(ctx, C.c_void_p(stream.cuda_stream)))
             self.torch.cuda.set_stream(stream)
 
+    def _slice(self, ptr, n):
+        """n bytes at device address ptr as a view of the scratch tensor that holds them (the spectral rows start at
+        the tensor's base, the x-Nyquist side array lies further in)."""
+        for base, t in self.tensors.items():
+            if base <= ptr and ptr + n <= base + t.numel() * 4:
+                first = (ptr - base) // 4
+                return t[first: first + n // 4]
+        raise KeyError(f"exchange buffer {ptr:#x} (+{n} bytes) is not inside the scratch arrays")
+
     def _views(self, send, recv, n):
         key = (send, recv, n)
         v = self._view_cache.get(key)
         if v is None:
-            v = (self.tensors[send][: n // 4], self.tensors[recv][: n // 4])
+            v = (self._slice(send, n), self._slice(recv, n))
             self._view_cache[key] = v
         return v
 
