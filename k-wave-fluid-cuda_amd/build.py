@@ -156,7 +156,7 @@ def build_all(force: bool = False, verbose: bool = False):
 
 if __name__ == "__main__":
     if len(sys.argv) > 2 and sys.argv[1] == "--variant":  # build.py --variant <name> [flags...]
-        print("built:", build_hip_variant(sys.argv[2], sys.argv[3:]))
+        print("built:", build_hip_variant(sys.argv[2], sys.argv[3:], int(os.environ.get("KW_VARIANT_LENGTH", "256"))))
         sys.exit(0)
     build_all(force="--force" in sys.argv, verbose="--verbose" in sys.argv)
     print("built:", HIP_LIB, HOST_LIB if os.path.exists(HOST_LIB) else "")

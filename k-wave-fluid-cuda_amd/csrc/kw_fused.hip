@@ -40,18 +40,30 @@ kw_status kw_fused_xinv_other(int epi, int chain, kw_ctx* ctx, int ncomp, const 
 namespace {
 
 constexpr int NLMAX = 16; // widest tile: 16 complex = 128-B segments (also the row-pitch granule)
-// lines per tile: 16 (128-B row segments) up to L = 384; 8 from L = 400 on, where the 20- to 32-point register DFTs of
-// the epilogue kernels need the VGPR budget of a small block (384^3 measured: 244 steps/s with 16 lines, 235 with 8)
-constexpr int nl_of(int L) { return L >= 400 ? 8 : 16; }
+// x passes, rows per block = 2 * nl_x: 16 line pairs up to L = 384; 8 from L = 400 on, where the 20- to 32-point register
+// DFTs of the epilogue kernels need the VGPR budget of a small block (384^3 measured: 244 steps/s with 16, 235 with 8)
+constexpr int nl_x(int L) { return L >= 400 ? 8 : 16; }
+// y / z passes, columns per tile: 16 (128-B row segments).  500^3 measured with 8-column tiles (64-B segments) for the
+// long lines: y passes 1.5x, z-fused 1.25x slower.  KW_NLYZ_LONG: tile width of lines longer than 512 (LDS: 128 B * L).
+#ifndef KW_NLYZ_LONG
+#define KW_NLYZ_LONG 16
+#endif
+constexpr int nl_yz(int L) { return L > 512 ? KW_NLYZ_LONG : 16; }
 
 constexpr int cmax(int a, int b) { return a > b ? a : b; }
+// 20- to 32-point register DFTs next to a multi-array epilogue want more than 256 VGPRs, which leaves ONE wave per SIMD
+// (nothing to hide a memory round trip behind): hold those kernels to the two-wave budget instead
+#ifndef KW_BIGL_WAVES
+#define KW_BIGL_WAVES 2
+#endif
+constexpr int big_line_waves(int L) { return L >= 400 ? KW_BIGL_WAVES : 1; }
 // largest divisor of n that is <= want
 constexpr int gq_pick(int n, int want) { return (n % want == 0) ? want : gq_pick(n, want - 1); }
 
-template<int L> struct Geo
+template<int L, int NLV = nl_yz(L)> struct Geo
 {
   static constexpr int R1 = Fac<L>::R1, R2 = Fac<L>::R2;
-  static constexpr int NL      = nl_of(L);
+  static constexpr int NL      = NLV;
   static constexpr int TPL     = cmax(R1, R2);
   static constexpr int THREADS = NL * TPL;
   // y/z passes: LDS[k1][n2][c]; +16 complex per k1 block keeps the step-B reads conflict-free
@@ -71,6 +83,8 @@ template<int L> struct Geo
 
 // "thread t takes part in a step of R threads per line": compile-time true when every thread of a line does (R == TPL),
 // so that the common L = 256 kernels carry no divergent regions (and no phi-separated register sets) at all.
+template<int L> using GeoX = Geo<L, nl_x(L)>; // geometry of the x passes
+
 #define ACT(R, t) ((R) == G::TPL || (t) < (R))
 
 // Block barrier that orders LDS traffic only.  __syncthreads() also drains every outstanding global load and store
@@ -219,7 +233,7 @@ __device__ __forceinline__ TileCoord tile_coord(uint32_t nxc, uint32_t P, uint32
 template<int L> __device__ __forceinline__ void load_twiddles(float2* twl, const float2* __restrict__ tw)
 {
   using G = Geo<L>;
-  for (int e = threadIdx.x; e < G::R1 * G::R2; e += G::THREADS)
+  for (int e = threadIdx.x; e < G::R1 * G::R2; e += blockDim.x)
   {
     const int k = e / G::R2, n = e - k * G::R2;
     twl[k * G::TP + n] = tw[k * n];
@@ -429,7 +443,7 @@ __device__ __forceinline__ void inverse_from_regs(float2 (&w)[Fac<L>::R2], float
 // One block owns the z-lines of tile (ky = blockIdx.y, kx tile = blockIdx.x) of `narr` arrays (VGRAD: the three velocity
 // spectra, ABSORB: the two pressure terms), processed back to back: the lines of array i+1 are in flight while array i
 // is transformed, and kappa is fetched once for all three velocity components.  PGRAD has one input and three outputs.
-template<int L, int MODE> __global__ __launch_bounds__(Geo<L>::THREADS) void k_zfused(ZArgs a)
+template<int L, int MODE> __global__ __launch_bounds__(Geo<L>::THREADS, big_line_waves(L)) void k_zfused(ZArgs a)
 {
   using G = Geo<L>;
   constexpr int R1 = G::R1, R2 = G::R2;
@@ -882,7 +896,7 @@ __device__ __forceinline__ void xfwd_tail(float2 (&v)[Fac<L>::R1], float2* lds, 
                                           const float2* tw, float2* __restrict__ out, uint32_t P, uint32_t tile,
                                           uint32_t nrows = 0, uint32_t side_off = 0)
 {
-  using G = Geo<L>;
+  using G = GeoX<L>;
   constexpr int R1 = G::R1, R2 = G::R2, HALF = L / 2 + 1;
   if (ACT(R2, f))
   {
@@ -925,9 +939,9 @@ __device__ __forceinline__ void xfwd_tail(float2 (&v)[Fac<L>::R1], float2* lds, 
   lds_barrier();
 }
 
-template<int L, bool TAIL = false> __global__ __launch_bounds__(Geo<L>::THREADS) void k_xfwd(XfwdArgs a)
+template<int L, bool TAIL = false> __global__ __launch_bounds__(GeoX<L>::THREADS) void k_xfwd(XfwdArgs a)
 {
-  using G = Geo<L>;
+  using G = GeoX<L>;
   constexpr int R1 = G::R1, R2 = G::R2;
   __shared__ float2 lds[G::LDSX];
   __shared__ float2 twl[G::TWN];
@@ -986,7 +1000,7 @@ __device__ __forceinline__ void xinv_lines(const float2* __restrict__ src, uint3
                                            const float2* __restrict__ mulx = nullptr, uint32_t nrows = 0,
                                            uint32_t side_off = 0)
 {
-  using G = Geo<L>;
+  using G = GeoX<L>;
   constexpr int R1 = G::R1, R2 = G::R2, HALF = L / 2 + 1;
   const uint32_t tile_row0 = tile * G::NL * 2;
   // all row loads of the tile are requested before the first one is consumed (a load-use loop would expose the memory
@@ -1062,10 +1076,10 @@ __device__ __forceinline__ void   f4put(float4& v, int k, float s)
 // (the 256-point density epilogue sits two registers above the 3-waves-per-SIMD step: ask the allocator for that step)
 // TERMS: compile-time value of a.terms for the density epilogue (one specialised kernel per pressure-term mode)
 template<int L, int EPI, bool CHAIN, int TERMS = 0, bool TAIL = false>
-__global__ __launch_bounds__(Geo<L>::THREADS, (EPI == EPI_DENSITY && L == 256) ? 3 : 1) void k_xinv(XinvArgs a)
+__global__ __launch_bounds__(GeoX<L>::THREADS, (EPI == EPI_DENSITY && L == 256) ? 3 : big_line_waves(L)) void k_xinv(XinvArgs a)
 {
   constexpr int terms = TERMS;
-  using G = Geo<L>;
+  using G = GeoX<L>;
   constexpr int R1 = G::R1, R2 = G::R2;
   constexpr int NA  = (EPI == EPI_DENSITY) ? 3 : (EPI == EPI_PSUM) ? 2 : 1;
   constexpr int RP  = L + 8;                       // real-tile row pitch (floats): conflict-free 4-B scatter
@@ -1389,9 +1403,9 @@ struct XshiftArgs
   uint32_t      nrows, tile0;
 };
 
-template<int L, bool TAIL = false> __global__ __launch_bounds__(Geo<L>::THREADS) void k_xshift(XshiftArgs a)
+template<int L, bool TAIL = false> __global__ __launch_bounds__(GeoX<L>::THREADS) void k_xshift(XshiftArgs a)
 {
-  using G = Geo<L>;
+  using G = GeoX<L>;
   constexpr int R1 = G::R1, R2 = G::R2;
   constexpr int RP = L + 8, Q4 = L / 4, NQ = (2 * G::NL * Q4) / G::THREADS;
   static_assert((2 * G::NL * Q4) % G::THREADS == 0, "tile must divide evenly");
@@ -1622,9 +1636,9 @@ template<int R, int VEC, bool XCD> __global__ __launch_bounds__(256) void k_prob
 
 // memory pattern of k_xinv<velocity, chain> without its arithmetic: per block 32 spectrum rows in, 32 rows of two real
 // arrays in (float4), one real array out, 32 spectrum rows out
-template<int L> __global__ __launch_bounds__(Geo<L>::THREADS) void k_probe_xinv(XinvArgs a)
+template<int L> __global__ __launch_bounds__(GeoX<L>::THREADS) void k_probe_xinv(XinvArgs a)
 {
-  using G = Geo<L>;
+  using G = GeoX<L>;
   constexpr int HALF = L / 2 + 1, Q4 = L / 4, NQ = (2 * G::NL * Q4) / G::THREADS;
   const uint32_t comp = blockIdx.y;
   const uint32_t tile_row0 = blockIdx.x * G::NL * 2;
@@ -1714,11 +1728,11 @@ kw_status launch_xfwd(kw_ctx* ctx, int narr, const float* const* in, float2* con
   a.P  = ctx->fused.P;
   a.side_off = ctx->fused.side_off;
   a.nrows = c.ny * c.nz;
-  const uint32_t rows_per_tile = 2u * static_cast<uint32_t>(nl_of(c.nx)), full = a.nrows / rows_per_tile;
+  const uint32_t rows_per_tile = 2u * static_cast<uint32_t>(nl_x(c.nx)), full = a.nrows / rows_per_tile;
   if (full > 0)
   {
     const dim3 grid(full, narr, 1);
-#define M(LEN) LAUNCH((k_xfwd<LEN, false>), grid, dim3(Geo<LEN>::THREADS), a)
+#define M(LEN) LAUNCH((k_xfwd<LEN, false>), grid, dim3(GeoX<LEN>::THREADS), a)
     KW_LEN_SWITCH(c.nx, M)
 #undef M
   }
@@ -1726,7 +1740,7 @@ kw_status launch_xfwd(kw_ctx* ctx, int narr, const float* const* in, float2* con
   { // the partial last tile, masked
     a.tile0 = full;
     const dim3 grid(1, narr, 1);
-#define M(LEN) LAUNCH((k_xfwd<LEN, true>), grid, dim3(Geo<LEN>::THREADS), a)
+#define M(LEN) LAUNCH((k_xfwd<LEN, true>), grid, dim3(GeoX<LEN>::THREADS), a)
     KW_LEN_SWITCH(c.nx, M)
 #undef M
   }
@@ -1775,7 +1789,7 @@ kw_status launch_ypass(kw_ctx* ctx, int dir, int narr, float2* const* in, float2
                    else LAUNCH((k_ypass_split<512, kInv, false, false>), g, b, a); }
     return KW_OK;
   }
-  const dim3 grid(f.P / nl_of(c.ny) + side_tile, nzc ? nzc : c.nz, narr / a.narr);
+  const dim3 grid(f.P / nl_yz(c.ny) + side_tile, nzc ? nzc : c.nz, narr / a.narr);
   // forward: natural in, natural or packed out; inverse: natural or packed in, natural out
 #define M(LEN)                                                                                                         \
   if (dir < 0) { if (pack_out) LAUNCH((k_ypass<LEN, kFwd, false, true>), grid, dim3(Geo<LEN>::THREADS), a);           \
@@ -1814,7 +1828,7 @@ template<int MODE> kw_status launch_zfused(kw_ctx* ctx, int narr, ZArgs a)
     LAUNCH((k_zfused_split<512, MODE>), dim3(f.P / NLMAX + side_tile, f.nyl, narr), dim3(Geo<256>::THREADS), a);
     return KW_OK;
   }
-  const dim3 grid(f.P / nl_of(f.nz_global) + side_tile, f.nyl, 1);
+  const dim3 grid(f.P / nl_yz(f.nz_global) + side_tile, f.nyl, 1);
 #define M(LEN) LAUNCH((k_zfused<LEN, MODE>), grid, dim3(Geo<LEN>::THREADS), a)
   KW_LEN_SWITCH(f.nz_global, M)
 #undef M
@@ -1843,13 +1857,13 @@ kw_status launch_xinv_impl(kw_ctx* ctx, int ncomp, XinvArgs a, uint32_t z0, uint
   a.side_off = ctx->fused.side_off;
   a.nrows = c.ny * c.nz;
   a.descending = ctx->fused.xinv_desc ? 1u : 0u;
-  const uint32_t rows_per_tile = 2u * static_cast<uint32_t>(nl_of(c.nx));
+  const uint32_t rows_per_tile = 2u * static_cast<uint32_t>(nl_x(c.nx));
   const uint32_t rows = c.ny * (nzc ? nzc : c.nz), full = rows / rows_per_tile;
   a.tile0 = z0 * c.ny / rows_per_tile; // chunked launches start on tile boundaries (plane_local_tail)
   if (full > 0)
   {
     const dim3 grid(full, ncomp, 1);
-#define M(LEN) LAUNCH((k_xinv<LEN, EPI, CHAIN, TERMS, false>), grid, dim3(Geo<LEN>::THREADS), a)
+#define M(LEN) LAUNCH((k_xinv<LEN, EPI, CHAIN, TERMS, false>), grid, dim3(GeoX<LEN>::THREADS), a)
     KW_LEN_SWITCH(c.nx, M)
 #undef M
   }
@@ -1858,7 +1872,7 @@ kw_status launch_xinv_impl(kw_ctx* ctx, int ncomp, XinvArgs a, uint32_t z0, uint
     a.tile0 += full;
     a.descending = 0u;
     const dim3 grid(1, ncomp, 1);
-#define M(LEN) LAUNCH((k_xinv<LEN, EPI, CHAIN, TERMS, true>), grid, dim3(Geo<LEN>::THREADS), a)
+#define M(LEN) LAUNCH((k_xinv<LEN, EPI, CHAIN, TERMS, true>), grid, dim3(GeoX<LEN>::THREADS), a)
     KW_LEN_SWITCH(c.nx, M)
 #undef M
   }
@@ -1963,7 +1977,7 @@ kw_status plane_local_tail(kw_ctx* ctx, int narr, int ncomp, const XinvArgs& x, 
   auto& f = ctx->fused;
   const kw_constants& c = ctx->c;
   uint32_t nch = f.zchunks;
-  while (nch > 1 && (c.nz % nch != 0 || (c.nz / nch * c.ny) % (2 * nl_of(c.nx)) != 0)) nch--;
+  while (nch > 1 && (c.nz % nch != 0 || (c.nz / nch * c.ny) % (2 * nl_x(c.nx)) != 0)) nch--;
   const uint32_t nzc = c.nz / nch;
   for (uint32_t ch = 0; ch < nch; ch++)
   {
@@ -2532,7 +2546,7 @@ kw_status kw_fused_shift_velocity(kw_ctx* ctx, int axis, const float* in, float*
     z.narr    = 1;
     z.lstride = nyl * z.P;
     z.bstride = z.P;
-    const uint32_t nl = nl_of(f.nz_global);
+    const uint32_t nl = nl_yz(f.nz_global);
     const dim3 grid((z.nxc + nl - 1) / nl, nyl, 1);
 #define M(LEN) LAUNCH((k_zfused<LEN, Z_SHIFT>), grid, dim3(Geo<LEN>::THREADS), z)
     KW_LEN_SWITCH(f.nz_global, M)
@@ -2547,18 +2561,18 @@ kw_status kw_fused_shift_velocity(kw_ctx* ctx, int axis, const float* in, float*
   if (axis == 0)
   {
     XshiftArgs a{ in, out, f.tw[0], reinterpret_cast<const float2*>(filter), c.ny * c.nz, 0u };
-    const uint32_t rows_per_tile = 2u * static_cast<uint32_t>(nl_of(c.nx)), full = a.nrows / rows_per_tile;
+    const uint32_t rows_per_tile = 2u * static_cast<uint32_t>(nl_x(c.nx)), full = a.nrows / rows_per_tile;
     if (full > 0)
     {
       const dim3 grid(full, 1, 1);
-#define M(LEN) LAUNCH((k_xshift<LEN, false>), grid, dim3(Geo<LEN>::THREADS), a)
+#define M(LEN) LAUNCH((k_xshift<LEN, false>), grid, dim3(GeoX<LEN>::THREADS), a)
       KW_LEN_SWITCH(c.nx, M)
 #undef M
     }
     if (a.nrows % rows_per_tile != 0)
     {
       a.tile0 = full;
-#define M(LEN) LAUNCH((k_xshift<LEN, true>), dim3(1, 1, 1), dim3(Geo<LEN>::THREADS), a)
+#define M(LEN) LAUNCH((k_xshift<LEN, true>), dim3(1, 1, 1), dim3(GeoX<LEN>::THREADS), a)
       KW_LEN_SWITCH(c.nx, M)
 #undef M
     }
@@ -2579,7 +2593,7 @@ kw_status kw_fused_shift_velocity(kw_ctx* ctx, int axis, const float* in, float*
   const uint32_t lines = (axis == 1) ? c.nz : c.ny;
   z.lstride = (axis == 1) ? z.P : c.ny * z.P;
   z.bstride = (axis == 1) ? c.ny * z.P : z.P;
-  const uint32_t nl = nl_of(len);
+  const uint32_t nl = nl_yz(len);
   const dim3 grid((z.nxc + nl - 1) / nl, lines, 1);
 #define M(LEN) LAUNCH((k_zfused<LEN, Z_SHIFT>), grid, dim3(Geo<LEN>::THREADS), z)
   KW_LEN_SWITCH(len, M)
@@ -2630,7 +2644,7 @@ kw_status kw_fused_probe(kw_ctx* ctx, int which, const float* op)
     a.P   = f.P;
     a.narr = 1;
     a.ain = a.aout = RowAddr{0u, 0u, 0u, 1u, c.ny}; // element k of line (ky = blockIdx.y): row k*ny + ky
-    const dim3 grid(f.P / nl_of(c.nz), c.ny, 1);
+    const dim3 grid(f.P / nl_yz(c.nz), c.ny, 1);
 #define M(LEN) LAUNCH((k_ypass<LEN, kFwd, false, false>), grid, dim3(Geo<LEN>::THREADS), a)
     KW_LEN_SWITCH(c.nz, M)
 #undef M
@@ -2650,7 +2664,7 @@ kw_status kw_fused_probe(kw_ctx* ctx, int which, const float* op)
     a.nxc = f.nxm;
     a.P   = f.P;
     a.ain = (which <= 12) ? RowAddr{0u, 0u, 0u, c.ny, 1u} : RowAddr{0u, 0u, 0u, 1u, c.ny};
-    const dim3 grid(f.P / nl_of(c.ny), c.nz, 1);
+    const dim3 grid(f.P / nl_yz(c.ny), c.nz, 1);
 #define M(LEN)                                                                                                         \
   if (which & 1) LAUNCH((k_probe_tile<LEN, 0>), grid, dim3(Geo<LEN>::THREADS), a);                                    \
   else LAUNCH((k_probe_tile<LEN, 1>), grid, dim3(Geo<LEN>::THREADS), a)
@@ -2704,7 +2718,7 @@ kw_status kw_fused_probe(kw_ctx* ctx, int which, const float* op)
     const size_t N = static_cast<size_t>(c.nx) * c.ny * c.nz + pads[which - 20];
     for (int i = 0; i < 3; i++) { a.in[i] = f.s[i]; a.fout[i] = f.s[i]; a.out[i] = base + i * N; a.m0[i] = base + (3 + i) * N; }
     a.P = f.P;
-    LAUNCH((k_probe_xinv<256>), dim3(c.ny * c.nz / (2 * nl_of(c.nx)), 3, 1), dim3(Geo<256>::THREADS), a);
+    LAUNCH((k_probe_xinv<256>), dim3(c.ny * c.nz / (2 * nl_x(c.nx)), 3, 1), dim3(GeoX<256>::THREADS), a);
     return KW_OK;
   }
   if (which == 2)

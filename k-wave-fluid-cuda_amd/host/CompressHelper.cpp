@@ -1,5 +1,6 @@
 // CompressHelper.cpp — see CompressHelper.h (restates Compression/CompressHelper.cpp:48-65,672-778).
 #include "CompressHelper.h"
+#include "Parameters.h"
 #include <stdexcept>
 #include <limits>
 #include <cstring>
@@ -7,11 +8,7 @@
 
 #include <cmath>
 
-CompressHelper& CompressHelper::getInstance()
-{
-  static CompressHelper instance;
-  return instance;
-}
+CompressHelper& CompressHelper::getInstance() { return Parameters::getInstance().getCompressHelper(); }
 
 void CompressHelper::init(float period, size_t mos, size_t harmonics, bool normalize)
 {

@@ -16,6 +16,7 @@ using FloatComplex = std::complex<float>;
 class CompressHelper
 {
  public:
+  /// the basis of the parameter set the calling thread works on (Parameters::getInstance)
   static CompressHelper& getInstance();
   void init(float period, size_t mos, size_t harmonics, bool normalize = false);
   const FloatComplex* getBE() const { return mBE.data(); }
@@ -39,6 +40,7 @@ class CompressHelper
   static constexpr int32_t kMaxExpP = 138, kMaxExpU = 114; // CompressHelper.h:81-83
 
  private:
+  friend class Parameters; // one helper per parameter set
   CompressHelper() = default;
   void generateFunctions(std::vector<FloatComplex>& bE, std::vector<FloatComplex>& bE_1, bool normalize, bool shift) const;
   size_t mOSize = 0, mBSize = 0, mMos = 1, mHarmonics = 1;

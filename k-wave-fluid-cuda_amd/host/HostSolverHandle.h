@@ -10,14 +10,24 @@
 
 struct kwh_solver
 {
+  // this solver's parameter set, device context and compression basis; every entry point binds it to the calling
+  // thread (KWH_BIND) so that Parameters::getInstance() inside the solver classes means THIS solver's set
+  std::unique_ptr<Parameters>             params = Parameters::createDetached();
   MemoryInput                             input;       // datasets handed over in memory (kwh_create)
   std::unique_ptr<InputProvider>          file_input;  // or an input file (kwh_create_from_file)
   std::unique_ptr<KSpaceFirstOrderSolver> solver;
   // HDF5 component: the writer behind kwh_open_output_file (h5/SeriesWriter.h), kept type-erased because this header is
   // shared with the HDF5-free library; must go before the solver (its sinks live in the solver's streams)
   std::shared_ptr<void>                   series_writer;
-  ~kwh_solver() { series_writer.reset(); }
+  ~kwh_solver()
+  {
+    Parameters::Scope bound(params.get()); // the streams and matrices are released on this solver's device context
+    series_writer.reset();
+    solver.reset();
+  }
 };
+
+#define KWH_BIND(s) Parameters::Scope kwhBoundScope((s) != nullptr ? (s)->params.get() : nullptr);
 
 void kwh_set_error(const std::string& e);
 Parameters::Options kwh_convert_options(const kwh_options* o);

@@ -11,11 +11,38 @@
 #include "HipError.h"
 #include "MatrixNames.h"
 
+namespace
+{
+thread_local Parameters* tBound = nullptr; // the set of the solver handle whose entry point this thread is inside
+}
+
+Parameters::Parameters() : mCompressHelper(new CompressHelper()) {}
+
+Parameters::~Parameters()
+{
+  if (mDetached) mHipParameters.release();
+}
+
 Parameters& Parameters::getInstance()
 {
+  if (tBound != nullptr) return *tBound;
   static Parameters instance;
   return instance;
 }
+
+std::unique_ptr<Parameters> Parameters::createDetached()
+{
+  std::unique_ptr<Parameters> p(new Parameters());
+  p->mDetached = true;
+  return p;
+}
+
+Parameters::Scope::Scope(Parameters* p) : mPrevious(tBound)
+{
+  if (p != nullptr) tBound = p;
+}
+
+Parameters::Scope::~Scope() { tBound = mPrevious; }
 
 void Parameters::init(const InputProvider& in, const Options& options)
 {

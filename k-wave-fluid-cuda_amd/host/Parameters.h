@@ -7,6 +7,7 @@
 #ifndef KW_HOST_PARAMETERS_H
 #define KW_HOST_PARAMETERS_H
 #include <cstddef>
+#include <memory>
 #include <string>
 
 #include "DimensionSizes.h"
@@ -14,6 +15,8 @@
 #include "kwave_hip.h"
 
 /// Replaces class CudaParameters (Parameters/CudaParameters.h:140-146, .cpp:81-288).
+class CompressHelper;
+
 class HipParameters
 {
  public:
@@ -75,7 +78,25 @@ class Parameters
     void*  scratch[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}; // optional caller-owned pipeline scratch
   };
 
+  /// The parameter set the calling thread works on: the one bound by the innermost live Scope of this thread (every
+  /// C-ABI entry point binds its solver handle's set), else the process-wide one (command-line program).  The reference
+  /// keeps one set per process (Parameters.h:90-96); here every solver handle owns its own — parameters, device
+  /// context and compression basis — so several solvers can live in one process, also on different threads.
   static Parameters& getInstance();
+  static std::unique_ptr<Parameters> createDetached();
+  class Scope
+  {
+   public:
+    explicit Scope(Parameters* p);
+    ~Scope();
+    Scope(const Scope&)            = delete;
+    Scope& operator=(const Scope&) = delete;
+
+   private:
+    Parameters* mPrevious;
+  };
+  ~Parameters();
+  CompressHelper& getCompressHelper() { return *mCompressHelper; }
 
   /// Parameters::init + readScalarsFromInputFile (Parameters.cpp:113-553) on any InputProvider
   void init(const InputProvider& input, const Options& options);
@@ -195,8 +216,11 @@ class Parameters
   }
 
  private:
-  Parameters() = default;
+  Parameters();
   Parameters(const Parameters&) = delete;
+
+  bool                            mDetached = false; // owns its device context (released with the set)
+  std::unique_ptr<CompressHelper> mCompressHelper;
 
   HipParameters  mHipParameters;
   Options        mOptions;

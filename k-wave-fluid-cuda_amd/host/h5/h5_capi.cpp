@@ -385,6 +385,7 @@ KWH_API int kwh_create_from_file(const char* input_path, const kwh_options* o, k
 KWH_API int kwh_write_output_file(kwh_solver* s, const char* path)
 {
   KWH_TRY
+  KWH_BIND(s)
   if (!s || !path) throw std::invalid_argument("kwh_write_output_file: NULL argument");
   kwh_write_output(s, path);
   KWH_CATCH
@@ -493,6 +494,7 @@ KWH_API int kwh_h5_read_attribute(const char* path, const char* dataset, const c
 KWH_API int kwh_write_output_file_ex(kwh_solver* s, const char* path, uint32_t compression_level, int32_t copy_sensor_mask)
 {
   KWH_TRY
+  KWH_BIND(s)
   if (!s || !path) throw std::invalid_argument("kwh_write_output_file_ex: NULL argument");
   if (compression_level > 9) throw std::invalid_argument("compression level must be 0..9");
   kwh_write_output(s, path, compression_level, copy_sensor_mask != 0);
@@ -505,6 +507,7 @@ KWH_API int kwh_write_output_file_ex(kwh_solver* s, const char* path, uint32_t c
 KWH_API int kwh_open_output_file(kwh_solver* s, const char* path, uint32_t compression_level, int32_t reopen)
 {
   KWH_TRY
+  KWH_BIND(s)
   if (!s || !path) throw std::invalid_argument("kwh_open_output_file: NULL argument");
   kwh_open_output(s, path, compression_level, reopen != 0);
   KWH_CATCH
@@ -513,6 +516,7 @@ KWH_API int kwh_open_output_file(kwh_solver* s, const char* path, uint32_t compr
 KWH_API int kwh_post_process_output_file(kwh_solver* s, const char* path)
 {
   KWH_TRY
+  KWH_BIND(s)
   if (!s || !path) throw std::invalid_argument("kwh_post_process_output_file: NULL argument");
   kwh_post_process_output(s, path);
   KWH_CATCH
@@ -521,6 +525,7 @@ KWH_API int kwh_post_process_output_file(kwh_solver* s, const char* path)
 KWH_API int kwh_checkpoint_write(kwh_solver* s, const char* path)
 {
   KWH_TRY
+  KWH_BIND(s)
   if (!s || !path) throw std::invalid_argument("kwh_checkpoint_write: NULL argument");
   kwh_checkpoint_write_impl(s, path);
   KWH_CATCH
@@ -529,6 +534,7 @@ KWH_API int kwh_checkpoint_write(kwh_solver* s, const char* path)
 KWH_API int kwh_checkpoint_read(kwh_solver* s, const char* path)
 {
   KWH_TRY
+  KWH_BIND(s)
   if (!s || !path) throw std::invalid_argument("kwh_checkpoint_read: NULL argument");
   kwh_checkpoint_read_impl(s, path);
   KWH_CATCH

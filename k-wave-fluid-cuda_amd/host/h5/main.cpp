@@ -143,6 +143,7 @@ int main(int argc, char** argv)
   try
   {
     kwh_solver s;
+    KWH_BIND(&s) // the solver classes below find this run's parameter set through Parameters::getInstance()
     s.file_input.reset(new Hdf5Input(in));
     kwh_build_solver(s, *s.file_input, kwh_convert_options(&o));
     s.file_input.reset();

@@ -55,6 +55,7 @@ void kwh_build_solver(kwh_solver& s, const InputProvider& fileInput, const Param
   fileInput.readScalarValue(kNzName, nz);
   const Input2DAdapter adapter(fileInput);
   const InputProvider& input = (nz == 1) ? static_cast<const InputProvider&>(adapter) : fileInput;
+  KWH_BIND(&s)
   Parameters& params = Parameters::getInstance();
   params.init(input, opt);
   params.selectDevice();
@@ -100,10 +101,13 @@ int kwh_destroy(kwh_solver* s)
   KWH_TRY
   if (s)
   {
-    if (s->solver) kw_sync(Parameters::getInstance().getHipParameters().getContext());
-    s->series_writer.reset(); // drains and closes the streamed output datasets while the streams still exist
-    s->solver.reset();
-    delete s;
+    {
+      KWH_BIND(s)
+      if (s->solver) kw_sync(Parameters::getInstance().getHipParameters().getContext());
+      s->series_writer.reset(); // drains and closes the streamed output datasets while the streams still exist
+      s->solver.reset();
+    }
+    delete s; // releases the device context with the parameter set
   }
   KWH_CATCH
 }
@@ -111,6 +115,7 @@ int kwh_destroy(kwh_solver* s)
 int kwh_run(kwh_solver* s, uint64_t n_steps)
 {
   KWH_TRY
+  KWH_BIND(s)
   if (!s) throw std::invalid_argument("kwh_run: NULL solver");
   s->solver->runTimeSteps(n_steps);
   KWH_CATCH
@@ -119,6 +124,7 @@ int kwh_run(kwh_solver* s, uint64_t n_steps)
 int kwh_finish(kwh_solver* s)
 {
   KWH_TRY
+  KWH_BIND(s)
   if (!s) throw std::invalid_argument("kwh_finish: NULL solver");
   s->solver->finish();
   KWH_CATCH
@@ -127,13 +133,14 @@ int kwh_finish(kwh_solver* s)
 int kwh_sync(kwh_solver* s)
 {
   KWH_TRY
+  KWH_BIND(s)
   (void)s;
   kwCheck(kw_sync(Parameters::getInstance().getHipParameters().getContext()));
   KWH_CATCH
 }
 
-uint64_t kwh_time_index(const kwh_solver*) { return Parameters::getInstance().getTimeIndex(); }
-void*    kwh_context(kwh_solver*) { return Parameters::getInstance().getHipParameters().getContext(); }
+uint64_t kwh_time_index(const kwh_solver* s) { return s ? s->params->getTimeIndex() : 0; }
+void*    kwh_context(kwh_solver* s) { return s ? s->params->getHipParameters().getContext() : nullptr; }
 
 static BaseMatrix* findMatrix(kwh_solver* s, const char* name, MatrixRecord::MatrixType* type)
 {
@@ -149,6 +156,7 @@ static BaseMatrix* findMatrix(kwh_solver* s, const char* name, MatrixRecord::Mat
 int kwh_matrix_size(kwh_solver* s, const char* name, uint64_t* n)
 {
   KWH_TRY
+  KWH_BIND(s)
   MatrixRecord::MatrixType t;
   BaseMatrix* m = findMatrix(s, name, &t);
   if (t == MatrixRecord::MatrixType::kIndex) throw std::invalid_argument("index matrices are not float matrices");
@@ -159,6 +167,7 @@ int kwh_matrix_size(kwh_solver* s, const char* name, uint64_t* n)
 int kwh_get_matrix(kwh_solver* s, const char* name, float* dst, uint64_t n)
 {
   KWH_TRY
+  KWH_BIND(s)
   MatrixRecord::MatrixType t;
   BaseMatrix* m = findMatrix(s, name, &t);
   if (t == MatrixRecord::MatrixType::kIndex) throw std::invalid_argument("index matrices are not float matrices");
@@ -171,6 +180,7 @@ int kwh_get_matrix(kwh_solver* s, const char* name, float* dst, uint64_t n)
 int kwh_get_scalar(kwh_solver* s, const char* name, float* out)
 {
   KWH_TRY
+  KWH_BIND(s)
   const Parameters& p = Parameters::getInstance();
   const std::string n(name);
   if (n == "fused_pipeline")
@@ -192,6 +202,7 @@ int kwh_get_scalar(kwh_solver* s, const char* name, float* out)
 int kwh_stream_info(kwh_solver* s, const char* name, uint64_t* size, uint64_t* steps)
 {
   KWH_TRY
+  KWH_BIND(s)
   BaseOutputStream* st = s->solver->getOutputStreamContainer().find(name);
   if (!st) throw std::invalid_argument(std::string("no output stream named ") + name);
   *size  = st->size();
@@ -204,6 +215,7 @@ int kwh_stream_info(kwh_solver* s, const char* name, uint64_t* size, uint64_t* s
 int kwh_stream_read(kwh_solver* s, const char* name, float* dst, uint64_t n)
 {
   KWH_TRY
+  KWH_BIND(s)
   BaseOutputStream* st = s->solver->getOutputStreamContainer().find(name);
   if (!st) throw std::invalid_argument(std::string("no output stream named ") + name);
   st->loadSeries(); // a series streamed to the output file is read back from there
@@ -216,6 +228,7 @@ int kwh_stream_read(kwh_solver* s, const char* name, float* dst, uint64_t n)
 int kwh_set_matrix(kwh_solver* s, const char* name, const float* src, uint64_t n)
 {
   KWH_TRY
+  KWH_BIND(s)
   if (!s || !name || !src) throw std::invalid_argument("kwh_set_matrix: NULL argument");
   s->solver->prepare();
   MatrixRecord::MatrixType t;
@@ -230,6 +243,7 @@ int kwh_set_matrix(kwh_solver* s, const char* name, const float* src, uint64_t n
 int kwh_set_time_index(kwh_solver* s, uint64_t t)
 {
   KWH_TRY
+  KWH_BIND(s)
   if (!s) throw std::invalid_argument("kwh_set_time_index: NULL solver");
   if (t > Parameters::getInstance().getNt()) throw std::invalid_argument("kwh_set_time_index: beyond Nt");
   Parameters::getInstance().setTimeIndex(t);
@@ -239,6 +253,7 @@ int kwh_set_time_index(kwh_solver* s, uint64_t t)
 int kwh_stream_count(kwh_solver* s, uint64_t* n)
 {
   KWH_TRY
+  KWH_BIND(s)
   *n = s->solver->getOutputStreamContainer().names().size();
   KWH_CATCH
 }
@@ -246,6 +261,7 @@ int kwh_stream_count(kwh_solver* s, uint64_t* n)
 int kwh_stream_name(kwh_solver* s, uint64_t i, char* out, uint64_t cap)
 {
   KWH_TRY
+  KWH_BIND(s)
   const std::vector<std::string> names = s->solver->getOutputStreamContainer().names();
   if (i >= names.size() || names[i].size() + 1 > cap) throw std::invalid_argument("kwh_stream_name: bad index or buffer");
   std::memcpy(out, names[i].c_str(), names[i].size() + 1);
@@ -255,6 +271,7 @@ int kwh_stream_name(kwh_solver* s, uint64_t i, char* out, uint64_t cap)
 int kwh_stream_count_all(kwh_solver* s, uint64_t* n)
 {
   KWH_TRY
+  KWH_BIND(s)
   *n = s->solver->getOutputStreamContainer().names(true).size();
   KWH_CATCH
 }
@@ -262,6 +279,7 @@ int kwh_stream_count_all(kwh_solver* s, uint64_t* n)
 int kwh_stream_name_all(kwh_solver* s, uint64_t i, char* out, uint64_t cap)
 {
   KWH_TRY
+  KWH_BIND(s)
   const std::vector<std::string> names = s->solver->getOutputStreamContainer().names(true);
   if (i >= names.size() || names[i].size() + 1 > cap) throw std::invalid_argument("kwh_stream_name_all: bad index or buffer");
   std::memcpy(out, names[i].c_str(), names[i].size() + 1);
@@ -271,6 +289,7 @@ int kwh_stream_name_all(kwh_solver* s, uint64_t i, char* out, uint64_t cap)
 int kwh_stream_checkpoint(kwh_solver* s, const char* name, float* dst, uint64_t cap, uint64_t* n_floats, uint64_t* steps)
 {
   KWH_TRY
+  KWH_BIND(s)
   BaseOutputStream* st = s->solver->getOutputStreamContainer().find(name);
   if (!st) throw std::invalid_argument(std::string("no output stream named ") + name);
   std::vector<float> state;
@@ -289,6 +308,7 @@ int kwh_stream_checkpoint(kwh_solver* s, const char* name, float* dst, uint64_t 
 int kwh_stream_restore(kwh_solver* s, const char* name, const float* src, uint64_t n, uint64_t steps)
 {
   KWH_TRY
+  KWH_BIND(s)
   s->solver->prepare();
   BaseOutputStream* st = s->solver->getOutputStreamContainer().find(name);
   if (!st) throw std::invalid_argument(std::string("no output stream named ") + name);

@@ -43,7 +43,6 @@ def test_random_configuration(orc, syn, seed):
     fields = ("p", "ux", "uy", "uz", "rhox", "rhoz")
 
     def run(fused):
-        # one solver at a time: Parameters is a process-wide singleton like the reference's (Parameters.h:90-96)
         g = gpu(pr, fused_kernels=fused, **streams)
         for n in legs:
             g.run(n)
@@ -67,4 +66,47 @@ def test_random_configuration(orc, syn, seed):
     for name in sa:
         assert sa[name].shape == sb[name].shape, name
         assert np.abs(sa[name] - sb[name]).max() <= 2e-5 * max(np.abs(sb[name]).max(), 1e-30), (name, dims, kw)
+    o.close()
+
+
+def test_two_solvers_live_in_one_process(orc, syn):
+    """Every solver handle owns its parameter set, device context and compression basis (Parameters::Scope binds them to
+    the calling thread per entry point; the reference keeps one set per process, Parameters.h:90-96): two simulations of
+    different grids, media and stream sets, stepped in turn, give exactly what each gives alone."""
+    pa = syn.make_problem(32, 64, 16, heterogeneous=True, nonlinear=True, absorbing=True, source="p0", pml_size=4,
+                          sensor="random", nt=20)
+    pb = syn.make_problem(48, 16, 80, heterogeneous=False, nonlinear=False, absorbing=False, source="p_source", nt_src=9,
+                          pml_size=4, sensor="random", nt=20)
+    ka, kb = dict(p_raw=1, p_max=1), dict(p_raw=1, u_raw=1, p_c=1, period=5.0, harmonics=2)
+
+    def solo(pr, kw):
+        g = gpu(pr, **kw)
+        g.run(14)
+        g.finish()
+        out = ({f: g.field(f) for f in ("p", "ux", "rhoz")}, {n: g.stream(n) for n in g.stream_names()})
+        g.close()
+        return out
+
+    fa, sa = solo(pa, ka)
+    fb, sb = solo(pb, kb)
+    a, b = gpu(pa, **ka), gpu(pb, **kb)
+    for na, nb in ((3, 5), (4, 2), (7, 7)):
+        a.run(na)
+        b.run(nb)
+    b.finish()
+    a.finish()
+    for f in fa:
+        assert np.array_equal(a.field(f), fa[f]), f
+        assert np.array_equal(b.field(f), fb[f]), f
+    assert set(a.stream_names()) == set(sa) and set(b.stream_names()) == set(sb)
+    for n in sa:
+        assert np.array_equal(a.stream(n), sa[n]), n
+    for n in sb:
+        assert np.array_equal(b.stream(n), sb[n]), n
+    a.close()
+    assert np.array_equal(b.field("p"), fb["p"])  # b is untouched by a's release
+    b.close()
+    o = orc.OracleSim(pa)
+    o.step(14)
+    assert rel_l2(fa["p"], o.field("p")) < TOL
     o.close()
