@@ -178,8 +178,8 @@ def run_distributed(args):
     from kwave_amd import synthetic
     from kwave_amd.dist import DistSolver, partition_problem, slab_range
 
-    backend = "nccl" if args.exchange == "torch" else "gloo"
-    dist.init_process_group(backend)
+    state = {"exchange": args.exchange, "backend": "nccl" if args.exchange == "torch" else "gloo", "fallback": None}
+    dist.init_process_group(state["backend"])
     rank, world = dist.get_rank(), dist.get_world_size()
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if local_rank >= torch.cuda.device_count():
@@ -187,12 +187,35 @@ def run_distributed(args):
     torch.cuda.set_device(local_rank)
     K, W = args.steps, args.warmup
 
-    def reduce_max(x):
+    def reduce(x, op):
         t = torch.tensor([x], dtype=torch.float64)
-        if backend == "nccl":
+        if state["backend"] == "nccl":
             t = t.cuda()
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.all_reduce(t, op=op)
         return float(t.item())
+
+    def open_solver(loc, nz):
+        """DistSolver on every rank with the same transport.  If the device library's communicator cannot be created
+        on some rank (say, an RCCL build the library cannot bind), ALL ranks move to torch.distributed's RCCL group as
+        the callback transport — still RCCL over xGMI, still the HIP pipeline; the line reports which one ran."""
+        sim, err = None, None
+        try:
+            sim = DistSolver(loc, rank, world, nz, device_index=local_rank, exchange=state["exchange"], p_raw=1, p_max=1)
+        except Exception as e:  # noqa: BLE001 - decided collectively below
+            err = e
+        if reduce(0.0 if err is not None else 1.0, dist.ReduceOp.MIN) > 0.5:
+            return sim
+        if sim is not None:
+            sim.close()
+        if state["exchange"] != "native":
+            raise err if err is not None else RuntimeError("slab solver could not be created on another rank")
+        print(f"[bench rank {rank}] native RCCL exchange unavailable ({err!r}); using the torch.distributed transport",
+              file=sys.stderr, flush=True)
+        state.update(exchange="torch", backend="nccl", fallback=repr(err) if err is not None else "failed on another rank")
+        dist.barrier()
+        dist.destroy_process_group()
+        dist.init_process_group("nccl")
+        return DistSolver(loc, rank, world, nz, device_index=local_rank, exchange="torch", p_raw=1, p_max=1)
 
     def slab_run(grid, k, w):
         """k timed steps of the config-3 workload on `grid`, Z-slabs over all ranks; (seconds, exchanges per step)"""
@@ -202,7 +225,7 @@ def run_distributed(args):
                                     nt=w + k + 8, zslab=(z0, z1))
         loc, _ = partition_problem(pr, rank, world, arrays_are_local=True)
         del pr
-        sim = DistSolver(loc, rank, world, nz, device_index=local_rank, exchange=args.exchange, p_raw=1, p_max=1)
+        sim = open_solver(loc, nz)
         sim.run(w)
         sim.sync()
         torch.cuda.synchronize()
@@ -211,7 +234,7 @@ def run_distributed(args):
         sim.run(k)
         sim.sync()
         torch.cuda.synchronize()
-        sec = reduce_max(time.perf_counter() - t0)
+        sec = reduce(time.perf_counter() - t0, dist.ReduceOp.MAX)
         dist.barrier()
         per_step = sim.exchanges // max(k + w, 1)
         sim.close()
@@ -253,7 +276,8 @@ def run_distributed(args):
                                       f"({voxels // world} voxels per GPU), one all-to-all transpose per 3-D FFT",
                           "grid": [nx, ny, nz], "parallelism": f"zslab{world}",
                           "exchange": "RCCL inside libkwave_hip.so (ncclSend/ncclRecv groups on a communication stream)"
-                          if args.exchange == "native" else "torch.distributed.all_to_all_single (RCCL) callback",
+                          if state["exchange"] == "native" else "torch.distributed.all_to_all_single (RCCL) callback",
+                          "exchange_fallback": state["fallback"],
                           "global_steps_per_s": round(global_rate, 2),
                           "value_definition": "N x global time-steps/s (each GPU owns one 256^3-voxel block)" if args.weak
                           else "global time-steps/s of this grid on N GPUs",

@@ -53,6 +53,12 @@ namespace
 kw_status bind_rccl(kw_comm_state* st)
 {
   const char* names[] = { getenv("KW_RCCL_LIB"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1" };
+  const char* off = getenv("KW_RCCL_DISABLE"); // lets a test walk the caller's "no native exchange" path
+  if (off != nullptr && off[0] == '1')
+  {
+    kw_set_error("kw_comm: RCCL binding disabled (KW_RCCL_DISABLE=1)");
+    return KW_ERR_COMM;
+  }
   for (const char* n : names)
   {
     if (n == nullptr || n[0] == '\0') continue;

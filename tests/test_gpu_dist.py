@@ -11,6 +11,7 @@ from conftest import rel_l2
 
 pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
 TOL = 1e-5
 
 
@@ -263,3 +264,20 @@ def test_slab_config5_streams_match_the_single_gpu_run(syn, tmp_path, world, dim
         checked += 1
     assert checked >= 12  # ux/uy/uz non-staggered raw + _c, p_c, Ix/Iy/Iz_avg_c, Ix/Iy/Iz_avg
     g.close()
+
+
+def test_bench_moves_to_the_torch_transport_when_the_library_cannot_bind_rccl():
+    """bench.py --gpus N decides the transport collectively: if kw_comm_init fails on any rank, every rank re-creates its
+    solver on torch.distributed's RCCL group (callback transport) and the line says so."""
+    import json
+    import subprocess
+    import sys
+    env = dict(os.environ, KW_RCCL_DISABLE="1", MASTER_PORT="29547")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--slab-selftest", "--size", "64", "--steps", "4",
+                        "--warmup", "2", "--no-512"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600,
+                       env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["config"]["exchange"].startswith("torch.distributed")
+    assert "KW_RCCL_DISABLE" in line["config"]["exchange_fallback"]
+    assert line["config"]["exchanges_per_step"] >= 13 and line["value"] > 0
