@@ -1495,14 +1495,15 @@ template<int L, bool TAIL = false> __global__ __launch_bounds__(GeoX<L>::THREADS
 // (rows = nyl local ky, nzg planes: the transposed operators of slab mode have the same form)
 // nxc: columns of the source rows; nxm <= nxc: columns that go into the row tiles (nxc - 1 when the x-Nyquist column is
 // kept apart: k_import_reduced_side stores that one)
-__global__ void k_import_reduced(float* __restrict__ dst, const float* __restrict__ src, uint32_t nxc, uint32_t nxm, uint32_t P,
-                                 uint32_t nyl, uint32_t nzg, size_t total, uint32_t r1, uint32_t vec, uint32_t split)
+template<typename IDX>
+__device__ __forceinline__ void import_reduced_elems(float* __restrict__ dst, const float* __restrict__ src, uint32_t nxc,
+                                                     uint32_t nxm, uint32_t P, uint32_t nyl, uint32_t nzg, IDX total,
+                                                     uint32_t r1, uint32_t vec, uint32_t split)
 {
   const uint32_t nt = P / NLMAX, nq = nzg / (r1 * vec);
-  for (size_t e = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x; e < total;
-       e += static_cast<size_t>(gridDim.x) * blockDim.x)
+  for (IDX e = static_cast<IDX>(blockIdx.x) * blockDim.x + threadIdx.x; e < total; e += static_cast<IDX>(gridDim.x) * blockDim.x)
   {
-    size_t         r  = e;
+    IDX            r  = e;
     const uint32_t r4 = static_cast<uint32_t>(r % vec); r /= vec;
     const uint32_t c  = static_cast<uint32_t>(r % NLMAX); r /= NLMAX;
     const uint32_t j  = static_cast<uint32_t>(r % r1); r /= r1;
@@ -1514,6 +1515,14 @@ __global__ void k_import_reduced(float* __restrict__ dst, const float* __restric
     const uint32_t kx = t * NLMAX + c;
     dst[e] = (kx < nxm) ? src[(static_cast<size_t>(kz) * nyl + ky) * nxc + kx] : 0.f;
   }
+}
+__global__ void k_import_reduced(float* __restrict__ dst, const float* __restrict__ src, uint32_t nxc, uint32_t nxm, uint32_t P,
+                                 uint32_t nyl, uint32_t nzg, size_t total, uint32_t r1, uint32_t vec, uint32_t split)
+{ // 64-bit divisions cost ~25 ms per 256^3 operator: index in 32 bits whenever the array allows (up to 1024^3 it does)
+  if (total + static_cast<size_t>(gridDim.x) * blockDim.x <= 0xffffffffull)
+    import_reduced_elems<uint32_t>(dst, src, nxc, nxm, P, nyl, nzg, static_cast<uint32_t>(total), r1, vec, split);
+  else
+    import_reduced_elems<size_t>(dst, src, nxc, nxm, P, nyl, nzg, total, r1, vec, split);
 }
 // the side column (kx = nxc - 1) in the same per-thread run layout, its 16-wide tiles running over ky:
 // dst[ky tile][q][j][c][V] <- src[kz][ky = 16 * tile + c][nxc - 1]

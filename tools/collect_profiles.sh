@@ -14,6 +14,7 @@ for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --kernel-trace --pmc $c -d $O/pmc256_$c --output-format csv -- python3 $R/bench.py --steps 10 --warmup 2 --no-cpu --no-512 --profile-steps 1 > $O/pmc256_$c.log 2>&1 || exit 1
   rocprofv3 --kernel-trace --pmc $c -d $O/pmcprobe_$c --output-format csv -- python3 $R/tools/probe_passes.py 256 3 > $O/pmcprobe_$c.log 2>&1 || exit 1
 done
+rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY -d $O/pmc256_SQ --output-format csv -- python3 $R/bench.py --steps 10 --warmup 2 --no-cpu --no-512 --profile-steps 1 > $O/pmc256_SQ.log 2>&1 || echo "SQ counters not collected"
 rocprofv3 --kernel-trace --stats -d $O/stats512 --output-format csv -- python3 $R/bench.py --size 512 --steps 10 --warmup 2 --no-cpu --no-512 > $O/stats512.log 2>&1 || exit 1
 rocprofv3 --kernel-trace --stats -d $O/statsslab --output-format csv -- python3 $R/bench.py --slab-selftest --steps 20 --warmup 3 > $O/statsslab.log 2>&1 || exit 1
 echo collected

@@ -45,6 +45,36 @@ def pmc(d, counter):
     return {k: (n, v / n * 1024.0) for k, (n, v) in acc.items()}  # KB -> bytes per launch
 
 
+def sq_counters(d, out_path):
+    """issue-side picture per kernel from one SQ counter pass (sums over the chip, averaged over launches)"""
+    f = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+    if not f:
+        return
+    acc = collections.OrderedDict()
+    for r in csv.DictReader(open(f[0])):
+        a = acc.setdefault(short(r["Kernel_Name"]), collections.OrderedDict())
+        c = a.setdefault(r["Counter_Name"], [0, 0.0])
+        c[0] += 1
+        c[1] += float(r["Counter_Value"])
+    with open(out_path, "w") as fo:
+        fo.write("# SQ counters per kernel launch, 256^3 config 3 (rocprofv3 --pmc SQ_* --kernel-trace, its own pass).\n"
+                 "#   valu/inst  = SQ_ACTIVE_INST_VALU / SQ_ACTIVE_INST_ANY   share of issue activity that is VALU\n"
+                 "#   wait/wave  = SQ_WAIT_ANY / SQ_WAVE_CYCLES                share of wave lifetime spent waiting on anything\n"
+                 "#   winst/wave = SQ_WAIT_INST_ANY / SQ_WAVE_CYCLES           share waiting for an issue slot\n"
+                 "#   inst/wave  = SQ_ACTIVE_INST_ANY / SQ_WAVE_CYCLES;  lds/inst = SQ_ACTIVE_INST_LDS / SQ_ACTIVE_INST_ANY\n")
+        fo.write(f"{'kernel':42s} {'launches':>8s} {'waves':>7s} {'valu/inst':>9s} {'wait/wave':>9s} {'winst/wave':>10s} "
+                 f"{'inst/wave':>9s} {'lds/inst':>8s}\n")
+        for k, a in acc.items():
+            v = {c: x[1] / x[0] for c, x in a.items()}
+            if not all(c in v for c in ("SQ_WAVE_CYCLES", "SQ_ACTIVE_INST_ANY", "SQ_ACTIVE_INST_VALU", "SQ_WAIT_ANY",
+                                        "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_LDS", "SQ_WAVES")):
+                continue
+            n = list(a.values())[0][0]
+            wc, ia = v["SQ_WAVE_CYCLES"] or 1, v["SQ_ACTIVE_INST_ANY"] or 1
+            fo.write(f"{k:42s} {n:8d} {v['SQ_WAVES']:7.0f} {v['SQ_ACTIVE_INST_VALU'] / ia:9.2f} {v['SQ_WAIT_ANY'] / wc:9.2f} "
+                     f"{v['SQ_WAIT_INST_ANY'] / wc:10.2f} {ia / wc:9.2f} {v['SQ_ACTIVE_INST_LDS'] / ia:8.2f}\n")
+
+
 def bench_line(path):
     if os.path.exists(path):
         for line in open(path):
@@ -71,6 +101,7 @@ def main():
         if b:
             json.dump(b, open(os.path.join(dst, f"{rnd}_{name}_bench.json"), "w"), indent=1)
         out[name] = rows
+    sq_counters(os.path.join(src, "pmc256_SQ"), os.path.join(dst, f"{rnd}_sq_counters.txt"))
     # ---- PMC traffic ----
     n = 256
     nxc, P = n // 2 + 1, 144
