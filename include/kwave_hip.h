@@ -318,6 +318,17 @@ KW_API kw_status kw_fused_set_slab(kw_ctx* ctx, uint32_t nranks, uint32_t rank, 
 typedef int (*kw_exchange_start_fn)(void* user, void* send, void* recv, size_t bytes_per_peer, int slot);
 typedef int (*kw_exchange_wait_fn)(void* user, int slot);
 KW_API kw_status kw_fused_set_slab_async(kw_ctx* ctx, kw_exchange_start_fn start, kw_exchange_wait_fn wait);
+/* Strided form, for a caller-owned transport that can move PIECES of the arrays: for every peer q, `bytes` bytes at
+ * send + q * stride_bytes + offset_bytes go to rank q and land at recv + (sender) * stride_bytes + offset_bytes
+ * (stride == bytes, offset 0 is the plain all-to-all above).  start returns after beginning the exchange (or after
+ * completing it, with wait == NULL); wait(user, slot) orders the context's stream after it; slot < 64.  With this form —
+ * as with the library's own RCCL path — the pipeline runs its pipelined schedule: the plane-local tail of every stage
+ * (y-inverse, x-inverse + epilogue, chained forward x / y) works per chunk of planes while the other chunks are on the
+ * wire, and the forward transposes of the next stage leave as soon as their planes are done (KW_SLAB_CHUNKS, default 2;
+ * KW_SLAB_PIPELINE=0: whole-array schedule). */
+typedef int (*kw_exchange_piece_fn)(void* user, void* send, void* recv, size_t stride_bytes, size_t offset_bytes, size_t bytes,
+                                    int slot);
+KW_API kw_status kw_fused_set_slab_pieces(kw_ctx* ctx, kw_exchange_piece_fn start, kw_exchange_wait_fn wait);
 KW_API kw_status kw_fused_scratch_bytes(kw_ctx* ctx, size_t* out_bytes_per_array);
 /* like kw_fused_create but with caller-owned scratch (each of kw_fused_scratch_bytes bytes): s[3], and t[3] when
  * nranks > 1 — lets the caller register the buffers with its communication library */

@@ -68,6 +68,9 @@ typedef struct kwh_options
   int32_t  complex_40bit; /* --40-bit_complex: compression coefficients kept and stored as 5-byte complex numbers
                              (CompressHelper.cpp:224-389; BaseOutputStream.cpp:98-101: c_complex_size 1.25) */
   int32_t  reserved_;
+  void*    exchange_piece_fn; /* optional kw_exchange_piece_fn (strided pieces; exchange_wait_fn, if set, is its wait):
+                                 a caller-owned transport that lets the pipeline run its pipelined slab schedule.
+                                 Give exchange_fn as well (used when the pipeline is told not to pipeline). */
 } kwh_options;
 
 KWH_API const char* kwh_last_error(void);

@@ -133,6 +133,7 @@ _SIG: Dict[str, list] = {
     "kw_comm_info": [_P, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)],
     "kw_fused_set_slab": [_P, C.c_uint32, C.c_uint32, C.c_uint32, _P, _P],
     "kw_fused_set_slab_async": [_P, _P, _P],
+    "kw_fused_set_slab_pieces": [_P, _P, _P],
     "kw_fused_scratch_bytes": [_P, C.POINTER(C.c_size_t)],
     "kw_fused_create_with_scratch": [_P, _P, _P],
     "kw_fused_supported": [_P, C.POINTER(C.c_int)],

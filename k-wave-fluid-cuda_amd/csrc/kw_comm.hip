@@ -102,32 +102,34 @@ void release(kw_comm_state* st)
 } // namespace
 
 // ---- used by the pipeline (kw_fused.hip) ----------------------------------------------------------------------------
-// One all-to-all of up to two regions (the spectral rows and, behind them, the x-Nyquist side array): every peer's
-// chunk of both goes out in the same RCCL group, so the pair costs one launch of the communication kernel.
-kw_status kw_comm_exchange_start2(kw_ctx* ctx, int slot, const void* send, void* recv, size_t bytes_per_peer,
-                                  const void* send2, void* recv2, size_t bytes_per_peer2)
+// One all-to-all of up to four strided pieces (the rows of a chunk of planes and, behind them, the same planes of the
+// x-Nyquist side array): every peer's part of every piece goes out in the same RCCL group, so the set costs one launch
+// of the communication kernel.
+kw_status kw_comm_exchange_start_pieces(kw_ctx* ctx, int slot, const kw_comm_piece* pieces, int n)
 {
   kw_comm_state* st = ctx->comm;
   if (st == nullptr) { kw_set_error("kw_comm: no communicator (kw_comm_init has not been called)"); return KW_ERR_STATE; }
-  KW_REQUIRE(slot >= 0 && slot < KW_COMM_SLOTS && send != nullptr && recv != nullptr && bytes_per_peer % sizeof(float) == 0);
-  KW_REQUIRE(bytes_per_peer2 == 0 || (send2 != nullptr && recv2 != nullptr && bytes_per_peer2 % sizeof(float) == 0));
+  KW_REQUIRE(slot >= 0 && slot < KW_COMM_SLOTS && pieces != nullptr && n >= 1 && n <= 4);
+  for (int i = 0; i < n; i++)
+    KW_REQUIRE(pieces[i].send != nullptr && pieces[i].recv != nullptr && pieces[i].bytes % sizeof(float) == 0 &&
+               pieces[i].offset + pieces[i].bytes <= pieces[i].stride);
   KW_HIP(hipEventRecord(st->ready[slot], ctx->stream));
   KW_HIP(hipStreamWaitEvent(st->stream, st->ready[slot], 0));
-  const size_t count[2] = {bytes_per_peer / sizeof(float), bytes_per_peer2 / sizeof(float)};
-  const char*  s[2]     = {static_cast<const char*>(send), static_cast<const char*>(send2)};
-  char*        r[2]     = {static_cast<char*>(recv), static_cast<char*>(recv2)};
-  const size_t bytes[2] = {bytes_per_peer, bytes_per_peer2};
   KW_NCCL(st, st->groupStart());
   for (uint32_t q = 0; q < st->nranks; q++)
   {
     // peers are taken starting from the right-hand neighbour: rank r talks to r+1, r+2, ... — no two ranks open with
     // the same peer, so the first chunks of every rank go out on different links
     const uint32_t peer = (st->rank + 1 + q) % st->nranks;
-    for (int part = 0; part < 2; part++)
+    for (int i = 0; i < n; i++)
     {
-      if (count[part] == 0) continue;
-      KW_NCCL(st, st->send(s[part] + peer * bytes[part], count[part], ncclFloat, static_cast<int>(peer), st->comm, st->stream));
-      KW_NCCL(st, st->recv(r[part] + peer * bytes[part], count[part], ncclFloat, static_cast<int>(peer), st->comm, st->stream));
+      const kw_comm_piece& pc = pieces[i];
+      if (pc.bytes == 0) continue;
+      const size_t at = peer * pc.stride + pc.offset;
+      KW_NCCL(st, st->send(static_cast<const char*>(pc.send) + at, pc.bytes / sizeof(float), ncclFloat, static_cast<int>(peer),
+                           st->comm, st->stream));
+      KW_NCCL(st, st->recv(static_cast<char*>(pc.recv) + at, pc.bytes / sizeof(float), ncclFloat, static_cast<int>(peer), st->comm,
+                           st->stream));
     }
   }
   KW_NCCL(st, st->groupEnd());
@@ -136,9 +138,22 @@ kw_status kw_comm_exchange_start2(kw_ctx* ctx, int slot, const void* send, void*
   return KW_OK;
 }
 
+kw_status kw_comm_exchange_start2(kw_ctx* ctx, int slot, const void* send, void* recv, size_t bytes_per_peer,
+                                  const void* send2, void* recv2, size_t bytes_per_peer2)
+{
+  const kw_comm_piece pc[2] = { { send, recv, bytes_per_peer, 0, bytes_per_peer }, { send2, recv2, bytes_per_peer2, 0, bytes_per_peer2 } };
+  return kw_comm_exchange_start_pieces(ctx, slot, pc, bytes_per_peer2 != 0 ? 2 : 1);
+}
+
 kw_status kw_comm_exchange_start(kw_ctx* ctx, int slot, const void* send, void* recv, size_t bytes_per_peer)
 {
   return kw_comm_exchange_start2(ctx, slot, send, recv, bytes_per_peer, nullptr, nullptr, 0);
+}
+
+kw_status kw_comm_sync(kw_ctx* ctx)
+{
+  if (ctx->comm != nullptr && ctx->comm->stream != nullptr) KW_HIP(hipStreamSynchronize(ctx->comm->stream));
+  return KW_OK;
 }
 
 kw_status kw_comm_exchange_wait(kw_ctx* ctx, int slot)

@@ -13,15 +13,18 @@
 //               pressure sum — the gradients never exist in HBM as separate arrays
 //
 // vs. the reference order (14 library FFTs + 7 element-wise kernels, each a full HBM round trip).
-// Internal spectral scratch is private to the pipeline: rows are padded to a multiple of 16 complex (128 B) so every
-// tile access is line-aligned; kappa/nabla operators are imported once into the same padded layout.
-// Supported: Nx, Ny, Nz powers of two in [16, 1024] (k-Wave's recommended grid sizes), Ny*Nz % 32 == 0; anything else
-// uses the rocFFT path (kw_fft.hip + kw_solver_kernels.hip).
+// Internal spectral scratch is private to the pipeline: rows are whole 16-complex tiles (128-B segments) — for even Nx
+// exactly Nx/2 bins, the x-Nyquist bin of every row living in a compact side array behind them (tile_coord); kappa /
+// nabla operators are imported once into the per-thread run layout their z-pass reads (load_op_run).
+// Supported: each of Nx, Ny, Nz one of the lengths of KW_FUSED_LENGTHS (2^a 3^b 5^c with a two-factor split into 4- to
+// 32-point register DFTs, 16 ... 1024; axes independent); anything else uses the rocFFT path (kw_fft.hip +
+// kw_solver_kernels.hip).  Multi-GPU: Z-slabs, see "pipelined slab schedule" below and kw_comm.hip.
 #include "kw_fft_device.h"
 #include "kw_internal.h"
 
 #include <cmath>
 #include <cstdlib>
+#include <cstring>
 #include <vector>
 
 using namespace kwfft;
@@ -1820,6 +1823,15 @@ template<int MODE> kw_status launch_zfused(kw_ctx* ctx, int narr, ZArgs a)
                                            { "k_zfused_absorb[1]", "k_zfused_absorb[2]", "k_zfused_absorb[3]" },
                                            { "k_zfused_source", "k_zfused_source", "k_zfused_source" } };
   KW_PROF(ctx, names[MODE][narr - 1]);
+  if (f.pipelined)
+  { // the transposed spectra live in r[] (callers name the arrays by their s[] slots)
+    for (int i = 0; i < 3; i++)
+      for (int j = 0; j < 3; j++)
+      {
+        if (a.in[i] == f.s[j]) a.in[i] = f.r[j];
+        if (a.out[i] == f.s[j]) a.out[i] = f.r[j];
+      }
+  }
   a.tw      = f.tw[2];
   a.divider = c.fft_divider;
   a.nxc     = f.nxm;
@@ -1896,6 +1908,12 @@ kw_status launch_xinv_impl(kw_ctx* ctx, int ncomp, XinvArgs a, uint32_t z0, uint
 kw_status xstart_bytes(kw_ctx* ctx, int slot, void* send, void* recv, size_t bytes_per_peer)
 {
   const auto& f = ctx->fused;
+  if (f.exchange_piece != nullptr)
+  {
+    const int rc = f.exchange_piece(f.exchange_user, send, recv, bytes_per_peer, 0, bytes_per_peer, slot);
+    if (rc != 0) { kw_set_error("slab exchange: the caller's piece callback failed (status %d)", rc); return KW_ERR_COMM; }
+    return KW_OK;
+  }
   if (f.exchange_start == nullptr && f.exchange == nullptr) return kw_comm_exchange_start(ctx, slot, send, recv, bytes_per_peer);
   const int rc = (f.exchange_start != nullptr) ? f.exchange_start(f.exchange_user, send, recv, bytes_per_peer, slot)
                                                : f.exchange(f.exchange_user, send, recv, bytes_per_peer);
@@ -1924,12 +1942,141 @@ kw_status xwait(kw_ctx* ctx, int slot)
 kw_status xwait_one(kw_ctx* ctx, int slot)
 {
   const auto& f = ctx->fused;
-  if (f.exchange_start == nullptr && f.exchange == nullptr) return kw_comm_exchange_wait(ctx, slot);
-  if (f.exchange_start != nullptr)
+  if (f.exchange_piece == nullptr && f.exchange_start == nullptr && f.exchange == nullptr) return kw_comm_exchange_wait(ctx, slot);
+  if (f.exchange_piece != nullptr ? f.exchange_wait != nullptr : f.exchange_start != nullptr)
   {
     const int rc = f.exchange_wait(f.exchange_user, slot);
     if (rc != 0) { kw_set_error("slab exchange: the caller's wait callback failed (status %d)", rc); return KW_ERR_COMM; }
   }
+  return KW_OK;
+}
+
+// ---- pipelined slab schedule (fused_plan::pipelined) -------------------------------------------------------------
+// Buffer roles: s[] plane layout [nz local][ny][P] (x / y passes), t[] per-peer chunks [peer][nz local][nyl][PX] (packed
+// y-pass output = forward send; backward receive = packed y-inverse input), r[] transposed [nz global][nyl][PX] (forward
+// receive = z-pass in / out = backward send).  An exchange moves the planes of one chunk (or of all chunks) of one
+// array: per peer q the bytes at (q * nz local + z0) * nyl * PX of both layouts, plus the same planes of the side array.
+enum { X_FWD = 0, X_BACK = 1 };
+constexpr int KW_ZSHIFT_SLOT = KW_COMM_SLOTS - 1;
+inline int pslot(int dir, int a, int c) { return (dir * 3 + a) * KW_XCHUNKS_MAX + c; }
+
+kw_status xpieces_start(kw_ctx* ctx, int slot, float2* send, float2* recv, uint32_t z0, uint32_t nzp)
+{
+  const auto& f = ctx->fused;
+  const size_t all = static_cast<size_t>(ctx->c.nz) * f.nyl, first = static_cast<size_t>(z0) * f.nyl, rows = static_cast<size_t>(nzp) * f.nyl;
+  const size_t rb = f.PX * sizeof(float2);
+  const kw_comm_piece pc[2] = { { send, recv, all * rb, first * rb, rows * rb },
+                                { send + f.side_off, recv + f.side_off, all * sizeof(float2), first * sizeof(float2), rows * sizeof(float2) } };
+  const int n = (f.side_off != 0) ? 2 : 1;
+  if (f.exchange_piece == nullptr) return kw_comm_exchange_start_pieces(ctx, slot, pc, n);
+  for (int i = 0; i < n; i++)
+  {
+    const int rc = f.exchange_piece(f.exchange_user, const_cast<void*>(pc[i].send), pc[i].recv, pc[i].stride, pc[i].offset,
+                                    pc[i].bytes, slot + i * KW_COMM_SLOTS);
+    if (rc != 0) { kw_set_error("slab exchange: the caller's piece callback failed (status %d)", rc); return KW_ERR_COMM; }
+  }
+  return KW_OK;
+}
+kw_status xpieces_wait(kw_ctx* ctx, int slot)
+{
+  const auto& f = ctx->fused;
+  if (f.exchange_piece == nullptr) return kw_comm_exchange_wait(ctx, slot);
+  if (f.exchange_wait == nullptr) return KW_OK; // blocking piece callback
+  for (int i = 0; i < ((f.side_off != 0) ? 2 : 1); i++)
+  {
+    const int rc = f.exchange_wait(f.exchange_user, slot + i * KW_COMM_SLOTS);
+    if (rc != 0) { kw_set_error("slab exchange: the caller's wait callback failed (status %d)", rc); return KW_ERR_COMM; }
+  }
+  return KW_OK;
+}
+// chunks [c0, c0 + nc) of array a in one exchange
+kw_status pstart(kw_ctx* ctx, int dir, int a, int c0, int nc)
+{
+  auto& f = ctx->fused;
+  const uint32_t nzc = ctx->c.nz / f.xchunks;
+  KW_TRY(xpieces_start(ctx, pslot(dir, a, c0), dir == X_FWD ? f.t[a] : f.r[a], dir == X_FWD ? f.r[a] : f.t[a], c0 * nzc, nc * nzc));
+  for (int c = c0; c < c0 + nc; c++) f.xcover[dir][a][c] = static_cast<int8_t>(c0);
+  f.xwaited[dir][a][c0] = false;
+  return KW_OK;
+}
+kw_status pwait(kw_ctx* ctx, int dir, int a, int c)
+{
+  auto& f = ctx->fused;
+  const int c0 = f.xcover[dir][a][c];
+  if (c0 < 0) { kw_set_error("slab pipeline: chunk %d of array %d awaited before its exchange was started", c, a); return KW_ERR_STATE; }
+  if (!f.xwaited[dir][a][c0])
+  {
+    KW_TRY(xpieces_wait(ctx, pslot(dir, a, c0)));
+    f.xwaited[dir][a][c0] = true;
+  }
+  return KW_OK;
+}
+kw_status pwait_all(kw_ctx* ctx, int dir, int a)
+{
+  for (uint32_t c = 0; c < ctx->fused.xchunks; c++) KW_TRY(pwait(ctx, dir, a, static_cast<int>(c)));
+  return KW_OK;
+}
+// forward exchanges a producer started for a consumer that never came (e.g. a run that ended in between): order the
+// buffers' reuse after them
+kw_status drain_ahead(kw_ctx* ctx)
+{
+  auto& f = ctx->fused;
+  for (int a = 0; a < f.fwd_ahead; a++) KW_TRY(pwait_all(ctx, X_FWD, a));
+  f.fwd_ahead = 0;
+  return KW_OK;
+}
+// forward half up to "exchanges started": from real arrays (x-forward first), from chained x-spectra in s[], or nothing
+// to do when the producer's tail already sent them chunk by chunk
+kw_status pforward_start(kw_ctx* ctx, int narr, const float* const* in)
+{
+  auto& f = ctx->fused;
+  if (in == nullptr && f.fwd_ahead == narr) return KW_OK;
+  if (f.fwd_ahead != 0) KW_TRY(drain_ahead(ctx));
+  for (int a = 0; a < narr; a++)
+  {
+    if (in != nullptr) KW_TRY(launch_xfwd(ctx, 1, in + a, f.s + a));
+    KW_TRY(launch_ypass(ctx, -1, 1, f.s + a, f.t + a, false, true));
+    KW_TRY(pstart(ctx, X_FWD, a, 0, static_cast<int>(f.xchunks)));
+  }
+  return KW_OK;
+}
+// forward + z-pass per array + backward exchanges started chunk-major (chunk 0 of every array first: the tail's first
+// chunk is complete after narr chunk transfers, the rest travel while it computes)
+template<int MODE> kw_status pslab_chain(kw_ctx* ctx, int narr, const float* const* in, ZArgs z)
+{
+  auto& f = ctx->fused;
+  const int C = static_cast<int>(f.xchunks);
+  KW_TRY(pforward_start(ctx, narr, in));
+  for (int a = 0; a < narr; a++)
+  {
+    KW_TRY(pwait_all(ctx, X_FWD, a));
+    z.arr0 = a;
+    KW_TRY(launch_zfused<MODE>(ctx, 1, z));
+    KW_TRY(pstart(ctx, X_BACK, a, 0, 1));
+  }
+  f.fwd_ahead = 0;
+  for (int c = 1; c < C; c++)
+    for (int a = 0; a < narr; a++) KW_TRY(pstart(ctx, X_BACK, a, c, 1));
+  return KW_OK;
+}
+// plane-local tail per chunk: backward receive -> y-inverse -> x-inverse + epilogue -> (chained) y-forward -> forward send
+template<int EPI, bool CHAIN, int TERMS = 0>
+kw_status pslab_tail(kw_ctx* ctx, int narr, int ncomp, const XinvArgs& x, int nchain)
+{
+  auto& f = ctx->fused;
+  const uint32_t C = f.xchunks, nzc = ctx->c.nz / C;
+  for (uint32_t c = 0; c < C; c++)
+  {
+    for (int a = 0; a < narr; a++) KW_TRY(pwait(ctx, X_BACK, a, static_cast<int>(c)));
+    KW_TRY(launch_ypass(ctx, +1, narr, f.t, f.s, true, false, c * nzc, nzc));
+    KW_TRY((launch_xinv<EPI, CHAIN, TERMS>(ctx, ncomp, x, c * nzc, nzc)));
+    if (CHAIN)
+    {
+      KW_TRY(launch_ypass(ctx, -1, nchain, f.s, f.t, false, true, c * nzc, nzc));
+      for (int i = 0; i < nchain; i++) KW_TRY(pstart(ctx, X_FWD, i, static_cast<int>(c), 1));
+    }
+  }
+  if (CHAIN) f.fwd_ahead = nchain;
   return KW_OK;
 }
 
@@ -1938,6 +2085,7 @@ kw_status xwait_one(kw_ctx* ctx, int slot)
 template<int MODE> kw_status slab_chain(kw_ctx* ctx, int narr, const float* const* in, ZArgs z)
 {
   auto& f = ctx->fused;
+  if (f.pipelined) return pslab_chain<MODE>(ctx, narr, in, z); // (the caller's tail is pslab_tail)
   for (int a = 0; a < narr; a++)
   {
     if (in != nullptr) KW_TRY(launch_xfwd(ctx, 1, in + a, f.s + a));
@@ -1966,6 +2114,13 @@ kw_status forward_xy(kw_ctx* ctx, int narr, const float* const* in, int s0 = 0)
   auto& f = ctx->fused;
   const int y_done = f.y_done;
   f.y_done = 0;
+  if (f.slab && f.pipelined)
+  { // (s0 == 0 on slabs) — ends with the transposed spectra in r[]
+    KW_TRY(pforward_start(ctx, narr, in));
+    for (int i = 0; i < narr; i++) KW_TRY(pwait_all(ctx, X_FWD, i));
+    f.fwd_ahead = 0;
+    return KW_OK;
+  }
   if (in != nullptr) KW_TRY(launch_xfwd(ctx, narr, in, f.s + s0)); // nullptr: x-spectra were chained into S[] already
   else if (y_done >= s0 + narr) return KW_OK;                      // ... and so was their y-pass (chunked producer)
   if (!f.slab) return launch_ypass(ctx, -1, narr, f.s + s0, f.s + s0, false, false);
@@ -2007,6 +2162,42 @@ template<int EPI, bool CHAIN> kw_status gradient_tail(kw_ctx* ctx, XinvArgs x, c
   auto& f = ctx->fused;
   x.mulx[0] = ddx;
   const float2* mul[3] = { ddy, nullptr, nullptr };
+  if (f.slab && f.pipelined)
+  { // Q (array 0) and G_z (array 2) come back chunk by chunk; the three components leave again as their rows are done
+    const uint32_t C = f.xchunks, nzc = ctx->c.nz / C;
+    for (uint32_t ch = 0; ch < C; ch++)
+    {
+      KW_TRY(pstart(ctx, X_BACK, 0, static_cast<int>(ch), 1));
+      KW_TRY(pstart(ctx, X_BACK, 2, static_cast<int>(ch), 1));
+    }
+    float2* yin[2]  = { f.t[0], f.t[0] };
+    float2* yout[2] = { f.s[1], f.s[0] };
+    for (uint32_t ch = 0; ch < C; ch++)
+    {
+      const int c = static_cast<int>(ch);
+      KW_TRY(pwait(ctx, X_BACK, 0, c));
+      KW_TRY(launch_ypass(ctx, +1, 2, yin, yout, true, false, ch * nzc, nzc, mul, false));
+      x.comp0 = 0;
+      KW_TRY((launch_xinv<EPI, CHAIN>(ctx, 2, x, ch * nzc, nzc)));
+      if (CHAIN)
+      {
+        KW_TRY(launch_ypass(ctx, -1, 2, f.s, f.t, false, true, ch * nzc, nzc));
+        KW_TRY(pstart(ctx, X_FWD, 0, c, 1));
+        KW_TRY(pstart(ctx, X_FWD, 1, c, 1));
+      }
+      KW_TRY(pwait(ctx, X_BACK, 2, c));
+      KW_TRY(launch_ypass(ctx, +1, 1, f.t + 2, f.s + 2, true, false, ch * nzc, nzc));
+      x.comp0 = 2;
+      KW_TRY((launch_xinv<EPI, CHAIN>(ctx, 1, x, ch * nzc, nzc)));
+      if (CHAIN)
+      {
+        KW_TRY(launch_ypass(ctx, -1, 1, f.s + 2, f.t + 2, false, true, ch * nzc, nzc));
+        KW_TRY(pstart(ctx, X_FWD, 2, c, 1));
+      }
+    }
+    if (CHAIN) f.fwd_ahead = 3;
+    return KW_OK;
+  }
   if (f.slab)
   {
     KW_TRY(xstart(ctx, 0, f.s[0], f.t[0]));
@@ -2032,6 +2223,12 @@ kw_status inverse_y(kw_ctx* ctx, int narr, int s0 = 0)
 {
   auto& f = ctx->fused;
   if (!f.slab) return launch_ypass(ctx, +1, narr, f.s + s0, f.s + s0, false, false);
+  if (f.pipelined)
+  { // whole arrays: r[] -> t[] -> y-inverse into s[]
+    for (int i = 0; i < narr; i++) KW_TRY(pstart(ctx, X_BACK, s0 + i, 0, static_cast<int>(f.xchunks)));
+    for (int i = 0; i < narr; i++) KW_TRY(pwait_all(ctx, X_BACK, s0 + i));
+    return launch_ypass(ctx, +1, narr, f.t + s0, f.s + s0, true, false);
+  }
   for (int i = 0; i < narr; i++) KW_TRY(xstart(ctx, s0 + i, f.s[s0 + i], f.t[s0 + i]));
   for (int i = 0; i < narr; i++) KW_TRY(xwait(ctx, s0 + i));
   return launch_ypass(ctx, +1, narr, f.t + s0, f.s + s0, true, false);
@@ -2058,6 +2255,11 @@ kw_status alloc_scratch(kw_ctx* ctx, void* const s[3], void* const t[3])
     }
     KW_HIP(hipMemsetAsync(f.s[i], 0, elems * sizeof(float2), ctx->stream));
     if (f.t[i]) KW_HIP(hipMemsetAsync(f.t[i], 0, elems * sizeof(float2), ctx->stream));
+    if (f.pipelined)
+    { // the transposed set is always the library's own
+      KW_HIP(hipMalloc(reinterpret_cast<void**>(&f.r[i]), elems * sizeof(float2)));
+      KW_HIP(hipMemsetAsync(f.r[i], 0, elems * sizeof(float2), ctx->stream));
+    }
   }
   return KW_OK;
 }
@@ -2078,7 +2280,7 @@ kw_status create_impl(kw_ctx* ctx, void* const s[3], void* const t[3])
   kw_fused_destroy(ctx);
   auto& f = ctx->fused;
   f.slab = slab.slab; f.nranks = slab.nranks; f.rank = slab.rank; f.exchange = slab.exchange; f.exchange_user = slab.exchange_user;
-  f.exchange_start = slab.exchange_start; f.exchange_wait = slab.exchange_wait;
+  f.exchange_start = slab.exchange_start; f.exchange_wait = slab.exchange_wait; f.exchange_piece = slab.exchange_piece;
   KW_HIP(hipSetDevice(ctx->device));
   const kw_constants& c = ctx->c;
   f.nz_global = (f.slab) ? slab.nz_global : c.nz;
@@ -2102,6 +2304,26 @@ kw_status create_impl(kw_ctx* ctx, void* const s[3], void* const t[3])
   {
     const char* e = getenv("KW_SLAB_UNPADDED");
     f.PX = (f.slab && f.side_off == 0 && e != nullptr && e[0] != '0') ? c.nx_complex : f.P;
+  }
+  memset(f.xcover, -1, sizeof(f.xcover));
+  {
+    // Pipelined schedule: whenever the exchange can move plane chunks (the library's RCCL path, or a piece callback).
+    // KW_SLAB_PIPELINE=0 keeps the whole-array schedule; KW_SLAB_CHUNKS sets the chunk count (default: 2 where the
+    // per-peer chunk stays above 2 MB, else 1; chunks are whole planes and whole x tiles).
+    const char* e  = getenv("KW_SLAB_PIPELINE");
+    const bool can = f.slab && (f.exchange_piece != nullptr || (f.exchange == nullptr && f.exchange_start == nullptr));
+    f.pipelined    = can && !(e != nullptr && e[0] == '0');
+    const char* ec = getenv("KW_SLAB_CHUNKS");
+    uint32_t nch   = (ec != nullptr && atoi(ec) > 0) ? static_cast<uint32_t>(atoi(ec)) : 2u;
+    if (nch > KW_XCHUNKS_MAX) nch = KW_XCHUNKS_MAX;
+    if (ec == nullptr)
+    { // every exchange costs the launching thread ~40 us (measured: tools/slab_host_time.py): chunk only while a chunk
+      // keeps a link busy for longer than that — 2 MB per peer at ~50 GB/s
+      const size_t per_peer = static_cast<size_t>(c.nz) * f.nyl * c.nx_complex * sizeof(float2);
+      while (nch > 1 && per_peer / nch < (2u << 20)) nch--;
+    }
+    while (nch > 1 && (c.nz % nch != 0 || (c.nz / nch * c.ny) % (2 * nl_x(c.nx)) != 0)) nch--;
+    f.xchunks = f.pipelined ? nch : 1u;
   }
   KW_TRY(alloc_scratch(ctx, s, t));
   const uint32_t lens[3] = { c.nx, c.ny, f.nz_global };
@@ -2209,6 +2431,16 @@ kw_status kw_fused_set_slab_async(kw_ctx* ctx, kw_exchange_start_fn start, kw_ex
   return KW_OK;
 }
 
+kw_status kw_fused_set_slab_pieces(kw_ctx* ctx, kw_exchange_piece_fn start, kw_exchange_wait_fn wait)
+{
+  KW_CHECK_CTX(ctx);
+  KW_REQUIRE(start != nullptr || wait == nullptr);
+  if (ctx->fused.ready) { kw_set_error("kw_fused_set_slab_pieces: must be called before kw_fused_create"); return KW_ERR_STATE; }
+  ctx->fused.exchange_piece = start;
+  if (start != nullptr) { ctx->fused.exchange_start = nullptr; ctx->fused.exchange_wait = wait; }
+  return KW_OK;
+}
+
 kw_status kw_fused_supported(kw_ctx* ctx, int* out)
 {
   KW_CHECK_CONSTS(ctx);
@@ -2229,9 +2461,12 @@ kw_status kw_fused_destroy(kw_ctx* ctx)
 {
   KW_CHECK_CTX(ctx);
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+  (void)kw_comm_sync(ctx); // forward exchanges started ahead by the last stage may still be on the communication stream
   auto& f = ctx->fused;
   for (int i = 0; i < 3; i++)
   {
+    if (f.r[i]) (void)hipFree(f.r[i]);
+    f.r[i] = nullptr;
     if (f.owns_scratch)
     {
       if (f.s[i]) (void)hipFree(f.s[i]);
@@ -2422,6 +2657,11 @@ kw_status kw_fused_density(kw_ctx* ctx, int nonlinear, const float* ux, const fl
       if (chain_terms) KW_TRY((plane_local_tail<EPI_DENSITY, true, (T) == 0 ? 1 : (T)>(ctx, 3, 1, x, (T) == 3 ? 1 : 2))); \
       else KW_TRY((plane_local_tail<EPI_DENSITY, false, (T)>(ctx, 3, 1, x, 0)));                                       \
     }                                                                                                                  \
+    else if (ctx->fused.pipelined)                                                                                     \
+    {                                                                                                                  \
+      if (chain_terms) KW_TRY((pslab_tail<EPI_DENSITY, true, (T) == 0 ? 1 : (T)>(ctx, 3, 1, x, (T) == 3 ? 1 : 2)));    \
+      else KW_TRY((pslab_tail<EPI_DENSITY, false, (T)>(ctx, 3, 1, x, 0)));                                             \
+    }                                                                                                                  \
     else if (chain_terms) KW_TRY((launch_xinv<EPI_DENSITY, true, (T) == 0 ? 1 : (T)>(ctx, 1, x)));                      \
     else KW_TRY((launch_xinv<EPI_DENSITY, false, (T)>(ctx, 1, x)));                                                    \
   } while (0)
@@ -2462,6 +2702,7 @@ kw_status kw_fused_velocity_gradient(kw_ctx* ctx, const float* ux, const float* 
   XinvArgs x{};
   float* du[3] = { duxdx, duydy, duzdz };
   for (int i = 0; i < 3; i++) { x.in[i] = S[i]; x.out[i] = du[i]; }
+  if (ctx->fused.slab && ctx->fused.pipelined) return pslab_tail<EPI_STORE, false>(ctx, 3, 3, x, 0);
   return launch_xinv<EPI_STORE>(ctx, 3, x);
 }
 
@@ -2513,6 +2754,11 @@ kw_status kw_fused_absorption_pressure(kw_ctx* ctx, float* p, const float* vel_g
     if (chain_p) KW_TRY((plane_local_tail<EPI_PSUM, true>(ctx, 2, 1, x, 1)));
     else KW_TRY((plane_local_tail<EPI_PSUM, false>(ctx, 2, 1, x, 0)));
   }
+  else if (ctx->fused.slab && ctx->fused.pipelined)
+  {
+    if (chain_p) KW_TRY((pslab_tail<EPI_PSUM, true>(ctx, 2, 1, x, 1)));
+    else KW_TRY((pslab_tail<EPI_PSUM, false>(ctx, 2, 1, x, 0)));
+  }
   else if (chain_p) KW_TRY((launch_xinv<EPI_PSUM, true>(ctx, 1, x)));
   else KW_TRY(launch_xinv<EPI_PSUM>(ctx, 1, x));
   return KW_OK;
@@ -2541,8 +2787,8 @@ kw_status kw_fused_shift_velocity(kw_ctx* ctx, int axis, const float* in, float*
     for (uint32_t q = 0; q < P; q++)
       KW_HIP(hipMemcpy2DAsync(snd + q * chunk, nyl * row, in + static_cast<size_t>(q) * nyl * c.nx, c.ny * row, nyl * row, nzl,
                               hipMemcpyDeviceToDevice, ctx->stream));
-    KW_TRY(xstart_bytes(ctx, 1, snd, rcv, chunk * sizeof(float)));
-    KW_TRY(xwait_one(ctx, 1));
+    KW_TRY(xstart_bytes(ctx, KW_ZSHIFT_SLOT, snd, rcv, chunk * sizeof(float)));
+    KW_TRY(xwait_one(ctx, KW_ZSHIFT_SLOT));
     ZArgs z{};
     z.in[0]   = reinterpret_cast<const float2*>(rcv);
     z.out[0]  = reinterpret_cast<float2*>(rcv);
@@ -2560,8 +2806,8 @@ kw_status kw_fused_shift_velocity(kw_ctx* ctx, int axis, const float* in, float*
 #define M(LEN) LAUNCH((k_zfused<LEN, Z_SHIFT>), grid, dim3(Geo<LEN>::THREADS), z)
     KW_LEN_SWITCH(f.nz_global, M)
 #undef M
-    KW_TRY(xstart_bytes(ctx, 1, rcv, snd, chunk * sizeof(float)));
-    KW_TRY(xwait_one(ctx, 1));
+    KW_TRY(xstart_bytes(ctx, KW_ZSHIFT_SLOT, rcv, snd, chunk * sizeof(float)));
+    KW_TRY(xwait_one(ctx, KW_ZSHIFT_SLOT));
     for (uint32_t q = 0; q < P; q++)
       KW_HIP(hipMemcpy2DAsync(out + static_cast<size_t>(q) * nyl * c.nx, c.ny * row, snd + q * chunk, nyl * row, nyl * row, nzl,
                               hipMemcpyDeviceToDevice, ctx->stream));

@@ -20,7 +20,8 @@ struct kw_fft_plan
 };
 
 struct kw_comm_state; // kw_comm.hip: RCCL communicator + communication stream + per-slot events
-#define KW_COMM_SLOTS 3
+#define KW_COMM_SLOTS 32 /* 2 directions x 3 arrays x KW_XCHUNKS_MAX plane chunks, + spare (z-shift staging) */
+#define KW_XCHUNKS_MAX 4
 
 struct kw_ctx
 {
@@ -65,6 +66,17 @@ struct kw_ctx
     void*          exchange_user = nullptr;
     kw_exchange_start_fn exchange_start = nullptr; // optional split-phase pair (overlap with compute)
     kw_exchange_wait_fn  exchange_wait  = nullptr;
+    kw_exchange_piece_fn exchange_piece = nullptr; // strided pieces (plane chunks of an array): enables the pipelined schedule
+    // Pipelined slab schedule (library's RCCL path or a piece callback): a third buffer set r[] holds the transposed
+    // spectra (forward receive = z-pass in / out = backward send), so that the plane-local tail of a stage — backward
+    // receive t[] -> y-inverse -> s[] -> x-inverse + epilogue -> chained x / y forward -> t[] -> forward send — runs per
+    // chunk of planes while the other chunks are on the wire.
+    bool     pipelined = false;
+    uint32_t xchunks   = 1;                        // plane chunks per array of the pipelined tail
+    float2*  r[3]      = {nullptr, nullptr, nullptr};
+    int      fwd_ahead = 0;                        // arrays whose forward exchange into r[] was started by the producer's tail
+    int8_t   xcover[2][3][KW_XCHUNKS_MAX] = {};    // [dir][array][chunk] -> first chunk of the started exchange covering it, -1 none
+    bool     xwaited[2][3][KW_XCHUNKS_MAX] = {};   // [dir][array][first chunk]: already waited for
   } fused;
   kw_comm_state* comm = nullptr; // multi-GPU exchange (kw_comm_init)
   // profiling (kw_profile_enable)
@@ -99,7 +111,11 @@ struct kw_prof_scope
 kw_status kw_comm_exchange_start(kw_ctx* ctx, int slot, const void* send, void* recv, size_t bytes_per_peer);
 kw_status kw_comm_exchange_start2(kw_ctx* ctx, int slot, const void* send, void* recv, size_t bytes_per_peer, const void* send2,
                                   void* recv2, size_t bytes_per_peer2);
+// general form: n pieces, each "bytes at send + q*stride + offset go to rank q and land at recv + sender*stride + offset"
+struct kw_comm_piece { const void* send; void* recv; size_t stride, offset, bytes; };
+kw_status kw_comm_exchange_start_pieces(kw_ctx* ctx, int slot, const kw_comm_piece* pieces, int n);
 kw_status kw_comm_exchange_wait(kw_ctx* ctx, int slot);
+kw_status kw_comm_sync(kw_ctx* ctx); // host waits for the communication stream (no-op without a communicator)
 
 // thread-local error text (kw_last_error)
 void kw_set_error(const char* fmt, ...) __attribute__((format(printf, 1, 2)));

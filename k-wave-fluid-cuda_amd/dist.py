@@ -100,6 +100,7 @@ class SlabExchange:
     CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t)
     CB_START = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int)
     CB_WAIT = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int)
+    CB_PIECE = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_int)
 
     def __init__(self, nranks: int, device_index: int = 0):
         import torch
@@ -122,6 +123,9 @@ class SlabExchange:
         self.works: Dict[int, object] = {}
         self.start_callback = self.CB_START(self._guard(self._start)) if self.backend == "nccl" else None
         self.wait_callback = self.CB_WAIT(self._guard(self._wait)) if self.backend == "nccl" else None
+        # strided pieces (plane chunks of an array), host-staged: lets the pipeline run its pipelined slab schedule
+        # with several ranks on one GPU (tests of the schedule the library's own RCCL path runs)
+        self.piece_callback = self.CB_PIECE(self._guard(self._piece)) if self.backend != "nccl" else None
 
     def _guard(self, fn):
         """A callback returns 0 / non-zero to the C++ step loop (which then stops with KW_ERR_COMM instead of running
@@ -191,6 +195,26 @@ class SlabExchange:
         self.host_seconds += dt
         self.wait_seconds += dt
 
+    def _piece(self, user, send, recv, stride, offset, nbytes, slot):
+        """kw_exchange_piece_fn, blocking: per peer q the bytes at send + q * stride + offset go to rank q and arrive
+        at recv + sender * stride + offset."""
+        self.calls += 1
+        torch, dist, hip = self.torch, self.dist, capi.load()
+        n = nbytes * self.nranks
+        key = ("piece", n)
+        if key not in self._host:
+            self._host[key] = (torch.empty(n // 4, dtype=torch.float32).pin_memory() if torch.cuda.is_available()
+                               else torch.empty(n // 4, dtype=torch.float32),
+                               torch.empty(n // 4, dtype=torch.float32))
+        hin, hout = self._host[key]
+        for q in range(self.nranks):
+            capi.check(hip.kw_memcpy_d2h(self.ctx, C.c_void_p(hin.data_ptr() + q * nbytes),
+                                         C.c_void_p(send + q * stride + offset), nbytes))
+        dist.all_to_all_single(hout, hin)
+        for q in range(self.nranks):
+            capi.check(hip.kw_memcpy_h2d(self.ctx, C.c_void_p(recv + q * stride + offset),
+                                         C.c_void_p(hout.data_ptr() + q * nbytes), nbytes))
+
     def _exchange(self, user, send, recv, bytes_per_peer):
         self.calls += 1
         torch, dist = self.torch, self.dist
@@ -251,6 +275,7 @@ class DistSolver:
             scratch = self.exchange.alloc_scratch(pitch * ny * nzl * 8)
         self.sim = HostSolver(pr_local, slab_ranks=nranks, slab_rank=rank, nz_global=nz_global,
                               exchange_fn=self.exchange.callback,
+                              exchange_piece_fn=self.exchange.piece_callback if exchange == "host" else None,
                               exchange_start_fn=self.exchange.start_callback if exchange == "torch" else None,
                               exchange_wait_fn=self.exchange.wait_callback if exchange == "torch" else None,
                               scratch=scratch, device_idx=device_index, **opts)

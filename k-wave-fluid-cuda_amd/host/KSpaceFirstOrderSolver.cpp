@@ -71,6 +71,8 @@ void KSpaceFirstOrderSolver::initializeFftPlans()
                               static_cast<uint32_t>(opt.nzGlobal), opt.exchangeFn, opt.exchangeUser));
   if (mParameters.isSlabDecomposed() && opt.exchangeStartFn != nullptr)
     kwCheck(kw_fused_set_slab_async(ctx, opt.exchangeStartFn, opt.exchangeWaitFn));
+  if (mParameters.isSlabDecomposed() && opt.exchangePieceFn != nullptr)
+    kwCheck(kw_fused_set_slab_pieces(ctx, opt.exchangePieceFn, opt.exchangeStartFn != nullptr ? nullptr : opt.exchangeWaitFn));
   if (opt.fusedKernels || mParameters.isSlabDecomposed()) kwCheck(kw_fused_supported(ctx, &fusedOk));
   mFused = (fusedOk != 0);
   if (mParameters.isSlabDecomposed() && !mFused)

@@ -75,6 +75,7 @@ class Parameters
     void*  exchangeUser = nullptr;
     kw_exchange_start_fn exchangeStartFn = nullptr; // optional split-phase pair: transposes overlap with compute
     kw_exchange_wait_fn  exchangeWaitFn  = nullptr;
+    kw_exchange_piece_fn exchangePieceFn = nullptr; // optional strided form (plane chunks): pipelined slab schedule
     void*  scratch[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}; // optional caller-owned pipeline scratch
   };
 

@@ -43,6 +43,7 @@ Parameters::Options kwh_convert_options(const kwh_options* o)
   opt.exchangeUser = o->exchange_user;
   opt.exchangeStartFn = reinterpret_cast<kw_exchange_start_fn>(o->exchange_start_fn);
   opt.exchangeWaitFn  = reinterpret_cast<kw_exchange_wait_fn>(o->exchange_wait_fn);
+  opt.exchangePieceFn = reinterpret_cast<kw_exchange_piece_fn>(o->exchange_piece_fn);
   for (int i = 0; i < 6; i++) opt.scratch[i] = o->scratch[i];
   return opt;
 }

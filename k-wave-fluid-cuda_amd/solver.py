@@ -42,7 +42,7 @@ class Options(C.Structure):
                 ("exchange_start_fn", C.c_void_p), ("exchange_wait_fn", C.c_void_p), ("scratch", C.c_void_p * 6),
                 ("i_avg", C.c_int32), ("q_term", C.c_int32), ("q_term_c", C.c_int32), ("u_c", C.c_int32),
                 ("frequency", C.c_float), ("only_post_processing", C.c_int32), ("comm_unique_id", C.c_void_p),
-                ("complex_40bit", C.c_int32), ("reserved_", C.c_int32)]
+                ("complex_40bit", C.c_int32), ("reserved_", C.c_int32), ("exchange_piece_fn", C.c_void_p)]
 
 
 _hlib: Optional[C.CDLL] = None
@@ -136,7 +136,7 @@ class HostSolver:
         if fn is not None:
             self._keep.append(fn)  # keep the ctypes callback alive
             o.exchange_fn = C.cast(fn, C.c_void_p)
-        for key in ("exchange_start_fn", "exchange_wait_fn"):
+        for key in ("exchange_start_fn", "exchange_wait_fn", "exchange_piece_fn"):
             fn = opts.pop(key, None)
             if fn is not None:
                 self._keep.append(fn)
