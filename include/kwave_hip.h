@@ -321,7 +321,7 @@ KW_API kw_status kw_fused_set_slab_async(kw_ctx* ctx, kw_exchange_start_fn start
 /* Strided form, for a caller-owned transport that can move PIECES of the arrays: for every peer q, `bytes` bytes at
  * send + q * stride_bytes + offset_bytes go to rank q and land at recv + (sender) * stride_bytes + offset_bytes
  * (stride == bytes, offset 0 is the plain all-to-all above).  start returns after beginning the exchange (or after
- * completing it, with wait == NULL); wait(user, slot) orders the context's stream after it; slot < 64.  With this form —
+ * completing it, with wait == NULL); wait(user, slot) orders the context's stream after it; slot < 256.  With this form —
  * as with the library's own RCCL path — the pipeline runs its pipelined schedule: the plane-local tail of every stage
  * (y-inverse, x-inverse + epilogue, chained forward x / y) works per chunk of planes while the other chunks are on the
  * wire, and the forward transposes of the next stage leave as soon as their planes are done (KW_SLAB_CHUNKS, default 2;

@@ -102,14 +102,14 @@ void release(kw_comm_state* st)
 } // namespace
 
 // ---- used by the pipeline (kw_fused.hip) ----------------------------------------------------------------------------
-// One all-to-all of up to four strided pieces (the rows of a chunk of planes and, behind them, the same planes of the
-// x-Nyquist side array): every peer's part of every piece goes out in the same RCCL group, so the set costs one launch
+// One all-to-all of up to eight strided pieces (per array the rows of a chunk of planes and, behind them, the same
+// planes of the x-Nyquist side array; up to three arrays): every peer's part of every piece goes out in the same RCCL group, so the set costs one launch
 // of the communication kernel.
 kw_status kw_comm_exchange_start_pieces(kw_ctx* ctx, int slot, const kw_comm_piece* pieces, int n)
 {
   kw_comm_state* st = ctx->comm;
   if (st == nullptr) { kw_set_error("kw_comm: no communicator (kw_comm_init has not been called)"); return KW_ERR_STATE; }
-  KW_REQUIRE(slot >= 0 && slot < KW_COMM_SLOTS && pieces != nullptr && n >= 1 && n <= 4);
+  KW_REQUIRE(slot >= 0 && slot < KW_COMM_SLOTS && pieces != nullptr && n >= 1 && n <= 8);
   for (int i = 0; i < n; i++)
     KW_REQUIRE(pieces[i].send != nullptr && pieces[i].recv != nullptr && pieces[i].bytes % sizeof(float) == 0 &&
                pieces[i].offset + pieces[i].bytes <= pieces[i].stride);

@@ -1960,14 +1960,22 @@ enum { X_FWD = 0, X_BACK = 1 };
 constexpr int KW_ZSHIFT_SLOT = KW_COMM_SLOTS - 1;
 inline int pslot(int dir, int a, int c) { return (dir * 3 + a) * KW_XCHUNKS_MAX + c; }
 
-kw_status xpieces_start(kw_ctx* ctx, int slot, float2* send, float2* recv, uint32_t z0, uint32_t nzp)
+// planes [z0, z0 + nzp) of the arrays arrs[0..na) in one exchange
+kw_status xpieces_start(kw_ctx* ctx, int slot, int dir, const int* arrs, int na, uint32_t z0, uint32_t nzp)
 {
   const auto& f = ctx->fused;
   const size_t all = static_cast<size_t>(ctx->c.nz) * f.nyl, first = static_cast<size_t>(z0) * f.nyl, rows = static_cast<size_t>(nzp) * f.nyl;
   const size_t rb = f.PX * sizeof(float2);
-  const kw_comm_piece pc[2] = { { send, recv, all * rb, first * rb, rows * rb },
-                                { send + f.side_off, recv + f.side_off, all * sizeof(float2), first * sizeof(float2), rows * sizeof(float2) } };
-  const int n = (f.side_off != 0) ? 2 : 1;
+  kw_comm_piece pc[6];
+  int n = 0;
+  for (int i = 0; i < na; i++)
+  {
+    float2* send = (dir == X_FWD) ? f.t[arrs[i]] : f.r[arrs[i]];
+    float2* recv = (dir == X_FWD) ? f.r[arrs[i]] : f.t[arrs[i]];
+    pc[n++] = kw_comm_piece{ send, recv, all * rb, first * rb, rows * rb };
+    if (f.side_off != 0)
+      pc[n++] = kw_comm_piece{ send + f.side_off, recv + f.side_off, all * sizeof(float2), first * sizeof(float2), rows * sizeof(float2) };
+  }
   if (f.exchange_piece == nullptr) return kw_comm_exchange_start_pieces(ctx, slot, pc, n);
   for (int i = 0; i < n; i++)
   {
@@ -1977,37 +1985,49 @@ kw_status xpieces_start(kw_ctx* ctx, int slot, float2* send, float2* recv, uint3
   }
   return KW_OK;
 }
-kw_status xpieces_wait(kw_ctx* ctx, int slot)
+kw_status xpieces_wait(kw_ctx* ctx, int slot, int npieces)
 {
   const auto& f = ctx->fused;
   if (f.exchange_piece == nullptr) return kw_comm_exchange_wait(ctx, slot);
   if (f.exchange_wait == nullptr) return KW_OK; // blocking piece callback
-  for (int i = 0; i < ((f.side_off != 0) ? 2 : 1); i++)
+  for (int i = 0; i < npieces; i++)
   {
     const int rc = f.exchange_wait(f.exchange_user, slot + i * KW_COMM_SLOTS);
     if (rc != 0) { kw_set_error("slab exchange: the caller's wait callback failed (status %d)", rc); return KW_ERR_COMM; }
   }
   return KW_OK;
 }
-// chunks [c0, c0 + nc) of array a in one exchange
-kw_status pstart(kw_ctx* ctx, int dir, int a, int c0, int nc)
+// chunks [c0, c0 + nc) of the arrays arrs[0..na) in one exchange
+kw_status pstart_multi(kw_ctx* ctx, int dir, const int* arrs, int na, int c0, int nc)
 {
   auto& f = ctx->fused;
   const uint32_t nzc = ctx->c.nz / f.xchunks;
-  KW_TRY(xpieces_start(ctx, pslot(dir, a, c0), dir == X_FWD ? f.t[a] : f.r[a], dir == X_FWD ? f.r[a] : f.t[a], c0 * nzc, nc * nzc));
-  for (int c = c0; c < c0 + nc; c++) f.xcover[dir][a][c] = static_cast<int8_t>(c0);
-  f.xwaited[dir][a][c0] = false;
+  const int slot = pslot(dir, arrs[0], c0);
+  KW_TRY(xpieces_start(ctx, slot, dir, arrs, na, c0 * nzc, nc * nzc));
+  for (int i = 0; i < na; i++)
+    for (int c = c0; c < c0 + nc; c++) f.xslot[dir][arrs[i]][c] = static_cast<int8_t>(slot);
+  f.slot_waited[slot] = false;
+  f.slot_pieces[slot] = static_cast<int8_t>(na * (f.side_off != 0 ? 2 : 1));
+  return KW_OK;
+}
+kw_status pstart(kw_ctx* ctx, int dir, int a, int c0, int nc) { return pstart_multi(ctx, dir, &a, 1, c0, nc); }
+// the arrays [a0, a0 + na): one exchange when batching, else one each
+kw_status pstart_arrays(kw_ctx* ctx, int dir, int a0, int na, int c0, int nc)
+{
+  const int arrs[3] = { a0, a0 + 1, a0 + 2 };
+  if (ctx->fused.xbatch) return pstart_multi(ctx, dir, arrs, na, c0, nc);
+  for (int i = 0; i < na; i++) KW_TRY(pstart(ctx, dir, a0 + i, c0, nc));
   return KW_OK;
 }
 kw_status pwait(kw_ctx* ctx, int dir, int a, int c)
 {
   auto& f = ctx->fused;
-  const int c0 = f.xcover[dir][a][c];
-  if (c0 < 0) { kw_set_error("slab pipeline: chunk %d of array %d awaited before its exchange was started", c, a); return KW_ERR_STATE; }
-  if (!f.xwaited[dir][a][c0])
+  const int slot = f.xslot[dir][a][c];
+  if (slot < 0) { kw_set_error("slab pipeline: chunk %d of array %d awaited before its exchange was started", c, a); return KW_ERR_STATE; }
+  if (!f.slot_waited[slot])
   {
-    KW_TRY(xpieces_wait(ctx, pslot(dir, a, c0)));
-    f.xwaited[dir][a][c0] = true;
+    KW_TRY(xpieces_wait(ctx, slot, f.slot_pieces[slot]));
+    f.slot_waited[slot] = true;
   }
   return KW_OK;
 }
@@ -2032,6 +2052,12 @@ kw_status pforward_start(kw_ctx* ctx, int narr, const float* const* in)
   auto& f = ctx->fused;
   if (in == nullptr && f.fwd_ahead == narr) return KW_OK;
   if (f.fwd_ahead != 0) KW_TRY(drain_ahead(ctx));
+  if (f.xbatch)
+  { // small messages: multi-array kernels, one exchange for the lot
+    if (in != nullptr) KW_TRY(launch_xfwd(ctx, narr, in, f.s));
+    KW_TRY(launch_ypass(ctx, -1, narr, f.s, f.t, false, true));
+    return pstart_arrays(ctx, X_FWD, 0, narr, 0, static_cast<int>(f.xchunks));
+  }
   for (int a = 0; a < narr; a++)
   {
     if (in != nullptr) KW_TRY(launch_xfwd(ctx, 1, in + a, f.s + a));
@@ -2047,6 +2073,14 @@ template<int MODE> kw_status pslab_chain(kw_ctx* ctx, int narr, const float* con
   auto& f = ctx->fused;
   const int C = static_cast<int>(f.xchunks);
   KW_TRY(pforward_start(ctx, narr, in));
+  if (f.xbatch)
+  {
+    for (int a = 0; a < narr; a++) KW_TRY(pwait_all(ctx, X_FWD, a));
+    f.fwd_ahead = 0;
+    z.arr0 = 0;
+    KW_TRY(launch_zfused<MODE>(ctx, narr, z));
+    return pstart_arrays(ctx, X_BACK, 0, narr, 0, C);
+  }
   for (int a = 0; a < narr; a++)
   {
     KW_TRY(pwait_all(ctx, X_FWD, a));
@@ -2073,7 +2107,7 @@ kw_status pslab_tail(kw_ctx* ctx, int narr, int ncomp, const XinvArgs& x, int nc
     if (CHAIN)
     {
       KW_TRY(launch_ypass(ctx, -1, nchain, f.s, f.t, false, true, c * nzc, nzc));
-      for (int i = 0; i < nchain; i++) KW_TRY(pstart(ctx, X_FWD, i, static_cast<int>(c), 1));
+      KW_TRY(pstart_arrays(ctx, X_FWD, 0, nchain, static_cast<int>(c), 1));
     }
   }
   if (CHAIN) f.fwd_ahead = nchain;
@@ -2162,6 +2196,25 @@ template<int EPI, bool CHAIN> kw_status gradient_tail(kw_ctx* ctx, XinvArgs x, c
   auto& f = ctx->fused;
   x.mulx[0] = ddx;
   const float2* mul[3] = { ddy, nullptr, nullptr };
+  if (f.slab && f.pipelined && f.xbatch)
+  { // small messages: Q and G_z come back in one exchange, one multi-array launch per pass, one exchange forward
+    const int back[2] = { 0, 2 };
+    KW_TRY(pstart_multi(ctx, X_BACK, back, 2, 0, static_cast<int>(f.xchunks)));
+    KW_TRY(pwait_all(ctx, X_BACK, 0));
+    KW_TRY(pwait_all(ctx, X_BACK, 2));
+    float2* yin[3]  = { f.t[0], f.t[0], f.t[2] };
+    float2* yout[3] = { f.s[1], f.s[0], f.s[2] };
+    KW_TRY(launch_ypass(ctx, +1, 3, yin, yout, true, false, 0, 0, mul, false));
+    x.comp0 = 0;
+    KW_TRY((launch_xinv<EPI, CHAIN>(ctx, 3, x)));
+    if (CHAIN)
+    {
+      KW_TRY(launch_ypass(ctx, -1, 3, f.s, f.t, false, true));
+      KW_TRY(pstart_arrays(ctx, X_FWD, 0, 3, 0, static_cast<int>(f.xchunks)));
+      f.fwd_ahead = 3;
+    }
+    return KW_OK;
+  }
   if (f.slab && f.pipelined)
   { // Q (array 0) and G_z (array 2) come back chunk by chunk; the three components leave again as their rows are done
     const uint32_t C = f.xchunks, nzc = ctx->c.nz / C;
@@ -2225,7 +2278,7 @@ kw_status inverse_y(kw_ctx* ctx, int narr, int s0 = 0)
   if (!f.slab) return launch_ypass(ctx, +1, narr, f.s + s0, f.s + s0, false, false);
   if (f.pipelined)
   { // whole arrays: r[] -> t[] -> y-inverse into s[]
-    for (int i = 0; i < narr; i++) KW_TRY(pstart(ctx, X_BACK, s0 + i, 0, static_cast<int>(f.xchunks)));
+    KW_TRY(pstart_arrays(ctx, X_BACK, s0, narr, 0, static_cast<int>(f.xchunks)));
     for (int i = 0; i < narr; i++) KW_TRY(pwait_all(ctx, X_BACK, s0 + i));
     return launch_ypass(ctx, +1, narr, f.t + s0, f.s + s0, true, false);
   }
@@ -2305,7 +2358,7 @@ kw_status create_impl(kw_ctx* ctx, void* const s[3], void* const t[3])
     const char* e = getenv("KW_SLAB_UNPADDED");
     f.PX = (f.slab && f.side_off == 0 && e != nullptr && e[0] != '0') ? c.nx_complex : f.P;
   }
-  memset(f.xcover, -1, sizeof(f.xcover));
+  memset(f.xslot, -1, sizeof(f.xslot));
   {
     // Pipelined schedule: whenever the exchange can move plane chunks (the library's RCCL path, or a piece callback).
     // KW_SLAB_PIPELINE=0 keeps the whole-array schedule; KW_SLAB_CHUNKS sets the chunk count (default: 2 where the
@@ -2324,6 +2377,12 @@ kw_status create_impl(kw_ctx* ctx, void* const s[3], void* const t[3])
     }
     while (nch > 1 && (c.nz % nch != 0 || (c.nz / nch * c.ny) % (2 * nl_x(c.nx)) != 0)) nch--;
     f.xchunks = f.pipelined ? nch : 1u;
+    // Below 4 MB per peer and array the exchanges are latency- and launch-bound: all arrays of a stage then travel in
+    // one exchange per direction (6 per step instead of 13) and the passes run as multi-array launches.  KW_SLAB_BATCH=0/1.
+    const char* eb = getenv("KW_SLAB_BATCH");
+    const size_t per_peer = static_cast<size_t>(c.nz) * f.nyl * c.nx_complex * sizeof(float2);
+    f.xbatch = f.pipelined && ((eb != nullptr) ? (eb[0] == '1') : (per_peer < (4u << 20)));
+    if (f.xbatch) f.xchunks = 1u;
   }
   KW_TRY(alloc_scratch(ctx, s, t));
   const uint32_t lens[3] = { c.nx, c.ny, f.nz_global };

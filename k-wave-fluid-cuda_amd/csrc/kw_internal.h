@@ -75,8 +75,10 @@ struct kw_ctx
     uint32_t xchunks   = 1;                        // plane chunks per array of the pipelined tail
     float2*  r[3]      = {nullptr, nullptr, nullptr};
     int      fwd_ahead = 0;                        // arrays whose forward exchange into r[] was started by the producer's tail
-    int8_t   xcover[2][3][KW_XCHUNKS_MAX] = {};    // [dir][array][chunk] -> first chunk of the started exchange covering it, -1 none
-    bool     xwaited[2][3][KW_XCHUNKS_MAX] = {};   // [dir][array][first chunk]: already waited for
+    bool     xbatch    = false;                    // small messages: all arrays of a stage travel in ONE exchange per direction
+    int8_t   xslot[2][3][KW_XCHUNKS_MAX] = {};     // [dir][array][chunk] -> slot of the started exchange that carries it, -1 none
+    bool     slot_waited[KW_COMM_SLOTS] = {};      // the compute stream already waits for that exchange
+    int8_t   slot_pieces[KW_COMM_SLOTS] = {};      // pieces of the exchange started on that slot (callback transports wait per piece)
   } fused;
   kw_comm_state* comm = nullptr; // multi-GPU exchange (kw_comm_init)
   // profiling (kw_profile_enable)

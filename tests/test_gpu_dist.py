@@ -56,7 +56,7 @@ def test_slab_ranks_match_oracle(orc, syn, tmp_path, world, dims, source, mode):
     for f in ("p", "ux", "uz", "rhoy"):
         assert rel_l2(res[f], o.field(f)) < TOL, f
     assert rel_l2(res["series"], np.array(series)) < TOL
-    assert int(res["exchanges"][0]) > 10 * steps  # the all-to-all really ran (14 per absorbing step)
+    assert int(res["exchanges"][0]) >= 6 * (steps - 1)  # the all-to-all really ran (6 exchanges per step when batched, 13 or more otherwise)
     o.close()
 
 
@@ -80,7 +80,7 @@ def test_slab_path_over_rccl_single_rank(orc, syn, tmp_path, dims, source, mode,
     for f in ("p", "ux", "uz", "rhoy"):
         assert rel_l2(res[f], o.field(f)) < TOL, f
     assert rel_l2(res["series"], np.array(series)) < TOL
-    assert int(res["exchanges"][0]) > 10 * steps
+    assert int(res["exchanges"][0]) >= 6 * (steps - 1)
     o.close()
 
 
@@ -224,7 +224,7 @@ def test_native_slab_driver_without_interpreter(syn, tmp_path):
                        env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
     assert r.returncode == 0, r.stdout[-2000:]
     words = r.stdout.split()
-    assert int(words[words.index("exchanges") + 1]) >= 13 * (nt - 1) and words[-1] == "1", r.stdout
+    assert int(words[words.index("exchanges") + 1]) >= 6 * (nt - 1) and words[-1] == "1", r.stdout
     for name in ("p", "p_max", "p_final", "ux_final", "uz_final"):
         a, b = h5io.read_dataset(slab, name), h5io.read_dataset(one, name)
         assert a.shape == b.shape and rel_l2(a, b) < TOL, name
@@ -286,16 +286,19 @@ def test_bench_moves_to_the_torch_transport_when_the_library_cannot_bind_rccl():
 
 @pytest.mark.parametrize("world,exchange,env", [
     (2, None, {"KW_SLAB_PIPELINE": "0"}),   # whole-array schedule (blocking callback), as every torch-transport run
-    (2, None, {"KW_SLAB_CHUNKS": "1"}),     # pipelined buffer roles, one chunk
-    (2, None, {"KW_SLAB_CHUNKS": "4"}),     # 4 plane chunks of 4 planes per rank
-    (4, None, {"KW_SLAB_CHUNKS": "3"}),     # 3 does not divide the 8 local planes: falls to 2
-    (1, "native", {"KW_SLAB_CHUNKS": "4"}), # RCCL with itself, strided pieces
+    (2, None, {"KW_SLAB_BATCH": "0", "KW_SLAB_CHUNKS": "1"}),     # per-array pipelining, one chunk
+    (2, None, {"KW_SLAB_BATCH": "0", "KW_SLAB_CHUNKS": "4"}),     # 4 plane chunks of 4 planes per rank
+    (4, None, {"KW_SLAB_BATCH": "0", "KW_SLAB_CHUNKS": "3"}),     # 3 does not divide the 8 local planes: falls to 2
+    (4, None, {"KW_SLAB_BATCH": "1"}),      # small messages (the default at these sizes): one exchange per stage and direction
+    (1, "native", {"KW_SLAB_BATCH": "0", "KW_SLAB_CHUNKS": "4"}), # RCCL with itself, strided pieces
+    (1, "native", {"KW_SLAB_BATCH": "1"}),
     (1, "native", {"KW_SLAB_PIPELINE": "0"}),
 ])
 @pytest.mark.parametrize("source,mode", [("p0", 0), ("u_source", 2)])
 def test_slab_schedules_agree(orc, syn, tmp_path, world, exchange, env, source, mode):
     """The pipelined slab schedule (plane-chunked tails, forward transposes started by the producer, third buffer set) at
-    several chunk counts and the whole-array schedule against the oracle: same problem, same answers.  With a velocity
+    several chunk counts, its batched form for small messages and the whole-array schedule against the oracle: same
+    problem, same answers.  With a velocity
     source nothing is chained between the velocity and the density stage (fresh forward transforms), with p0 everything
     is."""
     dims, steps = (32, 64, 32), 14
