@@ -115,15 +115,40 @@ def cpu_baseline(pr, n, budget_s=20.0):
                       f"in-repo FFT (no FFTW/MKL); manual Table C.3: 224.5 ms/step on 2x12-core Haswell + MKL"}
 
 
+def _code_only(text):
+    """C++ source without comments and blank lines (string and character literals kept as they are)"""
+    out, i, n = [], 0, len(text)
+    while i < n:
+        c = text[i]
+        if c in "\"'":
+            j = i + 1
+            while j < n and text[j] != c:
+                j += 2 if text[j] == "\\" else 1
+            out.append(text[i:j + 1])
+            i = j + 1
+        elif text.startswith("//", i):
+            while i < n and text[i] != "\n":
+                i += 1
+        elif text.startswith("/*", i):
+            i = text.find("*/", i + 2)
+            i = n if i < 0 else i + 2
+        else:
+            out.append(c)
+            i += 1
+    return "\n".join(line.rstrip() for line in "".join(out).splitlines() if line.strip())
+
+
 def kernel_source_hash():
-    """sha256 over the device sources: PMC counters committed under profiles/ are only quoted for the build they were
-    collected with"""
+    """sha256 over the device sources' code (comments and blank lines do not count): PMC counters committed under
+    profiles/ are only quoted for the kernels they were collected with"""
     import glob
     import hashlib
     h = hashlib.sha256()
     for f in sorted(glob.glob(os.path.join(ROOT, "k-wave-fluid-cuda_amd", "csrc", "*"))):
+        if os.path.isdir(f):
+            continue
         h.update(os.path.basename(f).encode())
-        h.update(open(f, "rb").read())
+        h.update(_code_only(open(f, "r", errors="replace").read()).encode())
     return h.hexdigest()[:16]
 
 

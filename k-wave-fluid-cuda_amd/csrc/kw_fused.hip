@@ -1498,34 +1498,34 @@ template<int L, bool TAIL = false> __global__ __launch_bounds__(GeoX<L>::THREADS
 // (rows = nyl local ky, nzg planes: the transposed operators of slab mode have the same form)
 // nxc: columns of the source rows; nxm <= nxc: columns that go into the row tiles (nxc - 1 when the x-Nyquist column is
 // kept apart: k_import_reduced_side stores that one)
-template<typename IDX>
-__device__ __forceinline__ void import_reduced_elems(float* __restrict__ dst, const float* __restrict__ src, uint32_t nxc,
-                                                     uint32_t nxm, uint32_t P, uint32_t nyl, uint32_t nzg, IDX total,
-                                                     uint32_t r1, uint32_t vec, uint32_t split)
+// One block per (ky, kx tile): the 16 x nzg values of the tile are gathered as 64-B row pieces (16 kx of one kz) into
+// LDS and leave as the tile's contiguous run in destination order.  (Set-up only.  In a rocprof table the first launch of
+// this kernel is charged ~58 ms — it is the first dispatch out of this file's code object; the others take ~56 us.)
+__global__ __launch_bounds__(256) void k_import_reduced(float* __restrict__ dst, const float* __restrict__ src, uint32_t nxc,
+                                                        uint32_t nxm, uint32_t P, uint32_t nyl, uint32_t nzg, uint32_t r1,
+                                                        uint32_t vec, uint32_t split)
 {
-  const uint32_t nt = P / NLMAX, nq = nzg / (r1 * vec);
-  for (IDX e = static_cast<IDX>(blockIdx.x) * blockDim.x + threadIdx.x; e < total; e += static_cast<IDX>(gridDim.x) * blockDim.x)
+  __shared__ float tile[NLMAX * 1024];
+  const uint32_t nt = P / NLMAX, t = blockIdx.x % nt, ky = blockIdx.x / nt;
+  const uint32_t n = NLMAX * nzg;
+  for (uint32_t i = threadIdx.x; i < n; i += blockDim.x)
   {
-    IDX            r  = e;
-    const uint32_t r4 = static_cast<uint32_t>(r % vec); r /= vec;
-    const uint32_t c  = static_cast<uint32_t>(r % NLMAX); r /= NLMAX;
-    const uint32_t j  = static_cast<uint32_t>(r % r1); r /= r1;
-    const uint32_t q  = static_cast<uint32_t>(r % nq); r /= nq;
-    const uint32_t t  = static_cast<uint32_t>(r % nt);
-    const uint32_t ky = static_cast<uint32_t>(r / nt);
-    const uint32_t ri = q * vec + r4; // position in the thread's run
-    const uint32_t kz = split ? 2u * j + (ri & 1u) + 2u * r1 * (ri >> 1) : j + r1 * ri;
-    const uint32_t kx = t * NLMAX + c;
-    dst[e] = (kx < nxm) ? src[(static_cast<size_t>(kz) * nyl + ky) * nxc + kx] : 0.f;
+    const uint32_t kz = i / NLMAX, kx = t * NLMAX + i % NLMAX;
+    tile[i] = (kx < nxm) ? src[(static_cast<size_t>(kz) * nyl + ky) * nxc + kx] : 0.f;
   }
-}
-__global__ void k_import_reduced(float* __restrict__ dst, const float* __restrict__ src, uint32_t nxc, uint32_t nxm, uint32_t P,
-                                 uint32_t nyl, uint32_t nzg, size_t total, uint32_t r1, uint32_t vec, uint32_t split)
-{ // 64-bit divisions cost ~25 ms per 256^3 operator: index in 32 bits whenever the array allows (up to 1024^3 it does)
-  if (total + static_cast<size_t>(gridDim.x) * blockDim.x <= 0xffffffffull)
-    import_reduced_elems<uint32_t>(dst, src, nxc, nxm, P, nyl, nzg, static_cast<uint32_t>(total), r1, vec, split);
-  else
-    import_reduced_elems<size_t>(dst, src, nxc, nxm, P, nyl, nzg, total, r1, vec, split);
+  __syncthreads();
+  float* __restrict__ out = dst + static_cast<size_t>(blockIdx.x) * n;
+  for (uint32_t p = threadIdx.x; p < n; p += blockDim.x)
+  {
+    uint32_t r = p;
+    const uint32_t v  = r % vec; r /= vec;
+    const uint32_t c  = r % NLMAX; r /= NLMAX;
+    const uint32_t j  = r % r1;
+    const uint32_t q  = r / r1;
+    const uint32_t ri = q * vec + v; // position in the thread's run
+    const uint32_t kz = split ? 2u * j + (ri & 1u) + 2u * r1 * (ri >> 1) : j + r1 * ri;
+    out[p] = tile[kz * NLMAX + c];
+  }
 }
 // the side column (kx = nxc - 1) in the same per-thread run layout, its 16-wide tiles running over ky:
 // dst[ky tile][q][j][c][V] <- src[kz][ky = 16 * tile + c][nxc - 1]
@@ -2362,7 +2362,7 @@ kw_status create_impl(kw_ctx* ctx, void* const s[3], void* const t[3])
   {
     // Pipelined schedule: whenever the exchange can move plane chunks (the library's RCCL path, or a piece callback).
     // KW_SLAB_PIPELINE=0 keeps the whole-array schedule; KW_SLAB_CHUNKS sets the chunk count (default: 2 where the
-    // per-peer chunk stays above 2 MB, else 1; chunks are whole planes and whole x tiles).
+    // per-peer chunk stays above 4 MB, else 1; chunks are whole planes and whole x tiles).
     const char* e  = getenv("KW_SLAB_PIPELINE");
     const bool can = f.slab && (f.exchange_piece != nullptr || (f.exchange == nullptr && f.exchange_start == nullptr));
     f.pipelined    = can && !(e != nullptr && e[0] == '0');
@@ -2370,10 +2370,10 @@ kw_status create_impl(kw_ctx* ctx, void* const s[3], void* const t[3])
     uint32_t nch   = (ec != nullptr && atoi(ec) > 0) ? static_cast<uint32_t>(atoi(ec)) : 2u;
     if (nch > KW_XCHUNKS_MAX) nch = KW_XCHUNKS_MAX;
     if (ec == nullptr)
-    { // every exchange costs the launching thread ~40 us (measured: tools/slab_host_time.py): chunk only while a chunk
-      // keeps a link busy for longer than that — 2 MB per peer at ~50 GB/s
+    { // every exchange costs the launching thread ~44 us (measured: tools/slab_host_time.py): chunk only while a chunk
+      // keeps a link busy for well longer than that — 4 MB per peer, ~70 us at ~60 GB/s
       const size_t per_peer = static_cast<size_t>(c.nz) * f.nyl * c.nx_complex * sizeof(float2);
-      while (nch > 1 && per_peer / nch < (2u << 20)) nch--;
+      while (nch > 1 && per_peer / nch < (4u << 20)) nch--;
     }
     while (nch > 1 && (c.nz % nch != 0 || (c.nz / nch * c.ny) % (2 * nl_x(c.nx)) != 0)) nch--;
     f.xchunks = f.pipelined ? nch : 1u;
@@ -2585,8 +2585,11 @@ kw_status kw_fused_import_reduced(kw_ctx* ctx, float* dst_padded, const float* s
   const uint32_t vec = static_cast<uint32_t>(op_vec(static_cast<int>(split ? 2 * r2 : r2)));
   const auto& f = ctx->fused;
   const size_t main_total = static_cast<size_t>(c.ny) * c.nz * f.P; // (f.P = row pitch of the main part: nxm rounded up to 16)
-  LAUNCH(k_import_reduced, dim3(ctx->cu_count * 8), dim3(256), dst_padded, src, c.nx_complex, f.nxm, f.P, f.nyl, f.nz_global,
-         main_total, r1, vec, split ? 1u : 0u);
+  KW_REQUIRE(f.nz_global <= 1024);
+  // columns beyond the imported ones and the unused tail of the array read as zero
+  KW_HIP(hipMemsetAsync(dst_padded, 0, static_cast<size_t>(f.Palloc) * c.ny * c.nz * sizeof(float), ctx->stream)); // = kw_fused_reduced_elems
+  LAUNCH(k_import_reduced, dim3(f.nyl * (f.P / NLMAX)), dim3(256), dst_padded, src, c.nx_complex, f.nxm, f.P, f.nyl, f.nz_global,
+         r1, vec, split ? 1u : 0u);
   if (f.side_off != 0)
   { // ceil(nyl / 16) tiles of 16 ky x nz values
     const size_t side_total = static_cast<size_t>((f.nyl + NLMAX - 1) / NLMAX) * NLMAX * f.nz_global;

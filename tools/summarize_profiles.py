@@ -145,8 +145,11 @@ def main():
         m = re.match(r"(k_xfwd<256)", t["kernel"])
         if m:
             by.setdefault("k_xfwd<256>", t)
+    # the loop's kernels only: not the set-up (operator import, p0 source, initial velocity, first x-forward) and not
+    # bench.py's copy-bandwidth probe
     per_step = sum(t["traffic_bytes"] * t["launches"] for t in table if t["kernel"].startswith("k_") and
-                   not t["kernel"].startswith(("k_import", "k_add_initial", "k_xinv<256, 2"))) / max(steps or 1, 1)
+                   not t["kernel"].startswith(("k_import", "k_add_initial", "k_xinv<256, 2", "k_stream_copy", "k_probe",
+                                               "k_xinv<256, 4, false", "k_xfwd"))) / max(steps or 1, 1)
 
     def per_array(kernel, arrays_per_step):
         t = by.get(kernel)
