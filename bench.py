@@ -197,6 +197,10 @@ def run_distributed(args):
     The data path is the device library's own RCCL exchange (--exchange native: kw_comm_init, ncclSend/ncclRecv groups
     on a communication stream); the process group (gloo) only carries the communicator id, the barriers and the
     max-over-ranks of the timings.  --exchange torch: torch.distributed.all_to_all_single as a callback (nccl group)."""
+    # the process-group and RCCL libraries print banners on stdout: everything but the result line goes to stderr
+    sys.stdout.flush()
+    result_fd = os.dup(1)
+    os.dup2(2, 1)
     import torch
     import torch.distributed as dist
     import kwave_amd  # noqa: F401
@@ -312,7 +316,8 @@ def run_distributed(args):
                             "frac": round(b_global / (sec / K) / 1e9 / (HBM_PEAK_GBS * world), 4), "traffic": None}}
         if c4 is not None:
             out["config"]["c4_512"] = c4
-        print(json.dumps(out))
+        sys.stdout.flush()
+        os.write(result_fd, (json.dumps(out) + "\n").encode())
     dist.destroy_process_group()
     return 0
 

@@ -110,3 +110,40 @@ def test_two_solvers_live_in_one_process(orc, syn):
     o.step(14)
     assert rel_l2(fa["p"], o.field("p")) < TOL
     o.close()
+
+
+def test_two_solvers_on_two_threads(syn):
+    """The parameter set is bound per thread and per entry point: two solvers stepped concurrently from two host threads
+    (ctypes releases the GIL inside kwh_run) give what each gives alone."""
+    import threading
+    pa = syn.make_problem(64, 32, 32, heterogeneous=True, nonlinear=True, absorbing=True, source="p0", pml_size=4,
+                          sensor="random", nt=40)
+    pb = syn.make_problem(32, 48, 16, heterogeneous=True, nonlinear=False, absorbing=True, source="u_source", nt_src=12,
+                          pml_size=4, sensor="random", nt=40)
+
+    def solo(pr):
+        g = gpu(pr, p_raw=1)
+        for _ in range(30):
+            g.run(1)
+        g.finish()
+        out = (g.field("p"), g.stream("p_raw") if "p_raw" in g.stream_names() else g.stream(g.stream_names()[0]))
+        g.close()
+        return out
+
+    ref = [solo(pa), solo(pb)]
+    got, errs = [None, None], []
+
+    def worker(i, pr):
+        try:
+            got[i] = solo(pr)
+        except BaseException as e:  # noqa: BLE001
+            errs.append(e)
+
+    th = [threading.Thread(target=worker, args=(i, pr)) for i, pr in enumerate((pa, pb))]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errs, errs
+    for i in range(2):
+        assert np.array_equal(got[i][0], ref[i][0]) and np.array_equal(got[i][1], ref[i][1]), i
