@@ -147,11 +147,26 @@ def build_native_drivers(force: bool = False) -> str:
     return SLAB_SELFTEST_BIN
 
 
+MOCK_RCCL_LIB = os.path.join(LIB_DIR, "libmock_rccl.so")
+
+
+def build_test_mocks(force: bool = False) -> str:
+    """tests/native/mock_rccl.cpp: test infrastructure — a stand-in for librccl whose ranks are threads sharing one GPU
+    (KW_RCCL_LIB), so that the library's own exchange path can be driven with several ranks on a one-GPU box."""
+    src = os.path.join(ROOT, "tests", "native", "mock_rccl.cpp")
+    if not os.path.exists(src):
+        return ""
+    if force or _newer(MOCK_RCCL_LIB, [src]):
+        _run([HIPCC, "--offload-arch=gfx950", "-O1", "-std=c++17", "-fPIC", "-shared", "-pthread", "-o", MOCK_RCCL_LIB, src])
+    return MOCK_RCCL_LIB
+
+
 def build_all(force: bool = False, verbose: bool = False):
     build_hip(force, verbose)
     build_host(force)
     build_host_h5(force)
     build_native_drivers(force)
+    build_test_mocks(force)
 
 
 if __name__ == "__main__":

@@ -171,6 +171,8 @@ def _full_size_reference(syn, orc, dims, steps):
     (2, "gloo", (512, 512, 512)),   # 2 ranks share the one GPU (host-staged all-to-all)
     (1, "native", (512, 512, 512)), # the device library's RCCL path exchanging with itself
     (4, "gloo", (256, 512, 512)),   # 128 ky rows / 128 planes per rank: the 2 x 256 split y / z kernels with 4 peer chunks
+    (8, "mock", (512, 512, 512)),   # the 8-GPU decomposition itself (64 planes, 64 ky rows per rank, two plane chunks) on the
+                                    # library's own exchange path: 8 thread-ranks on the one GPU, mock_rccl.cpp as the wire
 ])
 def test_config4_slab_at_full_size(orc, syn, tmp_path, world, backend, dims):
     """BASELINE config 4: 512^3 heterogeneous absorbing nonlinear medium as Z-slabs (KSpaceFirstOrderSolver.cpp:885-935
@@ -183,8 +185,17 @@ def test_config4_slab_at_full_size(orc, syn, tmp_path, world, backend, dims):
            "--master-addr", "127.0.0.1", "--master-port", str(29790 + world),
            os.path.join(HERE, "dist_worker_gpu.py"), "--dims", *map(str, dims), "--steps", str(steps), "--source", "p0",
            "--backend", "gloo", "--pml", "10", "--per-rank", "--out", out] + (["--exchange", "native"] if backend == "native" else [])
-    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900,
-                       env=dict(os.environ, OMP_NUM_THREADS="4", HSA_ENABLE_IPC_MODE_LEGACY="0"))
+    env = dict(os.environ, OMP_NUM_THREADS="4", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    if backend == "mock":
+        import kwave_amd  # noqa: F401
+        from kwave_amd import capi
+        mock = os.path.join(capi.PKG, "lib", "libmock_rccl.so")
+        if not os.path.exists(mock):
+            pytest.skip("mock exchange library not built")
+        cmd = [sys.executable, os.path.join(HERE, "mock_ranks_worker.py"), "--ranks", str(world), "--dims", *map(str, dims),
+               "--steps", str(steps), "--source", "p0", "--pml", "10", "--per-rank", "--out", out]
+        env["KW_RCCL_LIB"] = mock
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900, env=env)
     assert r.returncode == 0, r.stdout[-4000:]
     parts = [np.load(f"{out}.rank{k}.npz") for k in range(world)]
     for f in ("p", "ux", "uz", "rhoy"):
@@ -314,4 +325,44 @@ def test_slab_schedules_agree(orc, syn, tmp_path, world, exchange, env, source, 
     for f in ("p", "ux", "uz", "rhoy"):
         assert rel_l2(res[f], o.field(f)) < TOL, (f, env)
     assert rel_l2(res["series"], np.array(series)) < TOL
+    o.close()
+
+
+@pytest.mark.parametrize("ranks,dims,source,mode,env", [
+    (4, (32, 64, 32), "p0", 0, {}),                                              # small messages: the batched schedule
+    (4, (32, 64, 32), "u_source", 2, {"KW_SLAB_BATCH": "0", "KW_SLAB_CHUNKS": "2"}),   # per-array pipelining, plane chunks
+    (8, (48, 64, 64), "p0", 0, {"KW_SLAB_BATCH": "0", "KW_SLAB_CHUNKS": "4"}),   # 8 ranks, 2-plane chunks, 8 ky rows each
+    (8, (32, 64, 32), "p_source", 1, {}),
+    (2, (64, 32, 16), "p0", 0, {"KW_SLAB_PIPELINE": "0"}),                       # whole-array schedule on the native path
+])
+def test_native_exchange_with_many_ranks_on_one_gpu(orc, syn, tmp_path, ranks, dims, source, mode, env):
+    """The device library's OWN exchange path (kw_comm.hip: groups of ncclSend / ncclRecv over strided pieces, events
+    between the compute and the communication stream) with 2 / 4 / 8 ranks: the ranks are threads of one process, each
+    with its own solver, and RCCL is replaced by tests/native/mock_rccl.cpp (same matching rules, device copies as the
+    wire) because the real one refuses two ranks on a device.  What the real multi-GPU run adds to this is the wire."""
+    import kwave_amd  # noqa: F401
+    from kwave_amd import capi
+    mock = os.path.join(capi.PKG, "lib", "libmock_rccl.so")
+    if not os.path.exists(mock):
+        pytest.skip("mock exchange library not built")
+    steps = 12
+    out = str(tmp_path / "mock.npz")
+    cmd = [sys.executable, os.path.join(HERE, "mock_ranks_worker.py"), "--ranks", str(ranks), "--dims", *map(str, dims),
+           "--steps", str(steps), "--source", source, "--mode", str(mode), "--out", out]
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600,
+                       env=dict(os.environ, OMP_NUM_THREADS="2", KW_RCCL_LIB=mock, **env))
+    assert r.returncode == 0, r.stdout[-4000:]
+    res = np.load(out)
+    nx, ny, nz = dims
+    pr = syn.make_problem(nx, ny, nz, heterogeneous=True, nonlinear=True, absorbing=True, source=source,
+                          source_mode=mode, source_many=1, nt=steps, pml_size=4, sensor="random")
+    o = orc.OracleSim(pr)
+    series = []
+    for _ in range(steps):
+        o.step()
+        series.append(o.field("p").reshape(-1)[o.sensor_index].copy())
+    for f in ("p", "ux", "uz", "rhoy"):
+        assert rel_l2(res[f], o.field(f)) < TOL, (f, ranks, env)
+    assert rel_l2(res["series"], np.array(series)) < TOL
+    assert int(res["exchanges"][0]) >= 6 * (steps - 1)
     o.close()
