@@ -1684,13 +1684,14 @@ template<int L> __global__ __launch_bounds__(GeoX<L>::THREADS) void k_probe_xinv
 
 // ---- host side ------------------------------------------------------------------------------------------------------
 // line lengths with a two-factor register decomposition L = R1 * R2, R1, R2 in {4 ... 32} with at most one odd prime
-// power (3, 9, 27, 5, 25) each: 2^m, 3 * 2^m, 9 * 2^m, 27 * 2^m, 81 * 4, 5 * 2^m, 15 * 2^m, 25 * 2^m, 75 * 2^m, 125 * 4
+// power (3, 9, 27, 5, 25) each: 2^m, 3 * 2^m, 9 * 2^m, 27 * 2^m, 81 * 4, 5 * 2^m, 15 * 2^m, 25 * 2^m, 75 * 2^m, 125 * 4,
+// 45 * 2^m (180, 360), 135 * 4 (540); the x kernels need L % 4 == 0 and whole float4 counts per thread
 #ifdef KW_FUSED_ONLY /* tuning builds: one line length only (-DKW_FUSED_ONLY=256), compiles in seconds */
 #define KW_FUSED_LENGTHS(X) X(KW_FUSED_ONLY)
 #else
-#define KW_FUSED_LENGTHS(X) X(16) X(32) X(48) X(64) X(72) X(80) X(96) X(100) X(108) X(120) X(128) X(144) X(160) X(192)  \
-  X(200) X(216) X(240) X(256) X(288) X(300) X(320) X(324) X(384) X(400) X(432) X(480) X(500) X(512) X(576) X(600) X(640) \
-  X(648) X(768) X(1024)
+#define KW_FUSED_LENGTHS(X) X(16) X(32) X(48) X(64) X(72) X(80) X(96) X(100) X(108) X(120) X(128) X(144) X(160) X(180)  \
+  X(192) X(200) X(216) X(240) X(256) X(288) X(300) X(320) X(324) X(360) X(384) X(400) X(432) X(480) X(500) X(512) X(540) \
+  X(576) X(600) X(640) X(648) X(768) X(1024)
 #endif
 bool supported_len(uint32_t n)
 {

@@ -150,6 +150,8 @@ def test_fused_line_length_512(orc, syn, dims):
     (16, 432, 16), (16, 16, 432), (648, 16, 16), (16, 648, 16), (16, 16, 648),                    # 27 * 2^m, 81 * 4
     (300, 16, 16), (16, 300, 16), (16, 16, 300), (500, 16, 16), (16, 500, 16), (16, 16, 500), (600, 16, 16),
     (16, 600, 16), (16, 16, 600),                                                                 # 75 * 2^m, 125 * 4
+    (180, 16, 16), (16, 180, 16), (16, 16, 180), (360, 16, 16), (16, 360, 16), (16, 16, 360), (540, 16, 16),
+    (16, 540, 16), (16, 16, 540), (90 * 2, 360, 16),                                               # 45 * 2^m, 135 * 4
     (400, 100, 100), (500, 100, 108),       # Ny * Nz a multiple of 16 but not of 32: 16-row x tiles from Nx = 400 on
 ])
 def test_fused_line_lengths_mixed_radix(orc, syn, dims):
