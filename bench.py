@@ -430,7 +430,7 @@ def main():
 
     out = {"metric": "time-steps/sec on 256^3 heterogeneous grid; achieved HBM GB/s vs roofline",
            "value": round(steps_per_s, 2), "unit": "time-steps/s", "n_gpus": 1, "steps": K, "warmup": W,
-           "ms_per_step": round(ms / K, 4), "higher_is_better": True, "scaling": "weak",
+           "ms_per_step": round(ms / K, 4), "higher_is_better": True, "scaling": "weak" if args.weak else "strong",
            "vs_baseline": round(steps_per_s / BASELINE_STEPS_PER_S_256, 2) if n == 256 else None,
            "dtype": "f32", "data": "synthetic",
            "config": {"workload": f"{n}^3 heterogeneous (c0,rho0,BonA,alpha_coeff arrays), power-law absorption + "
