@@ -322,10 +322,11 @@ KW_API kw_status kw_fused_set_slab_async(kw_ctx* ctx, kw_exchange_start_fn start
  * send + q * stride_bytes + offset_bytes go to rank q and land at recv + (sender) * stride_bytes + offset_bytes
  * (stride == bytes, offset 0 is the plain all-to-all above).  start returns after beginning the exchange (or after
  * completing it, with wait == NULL); wait(user, slot) orders the context's stream after it; slot < 256.  With this form —
- * as with the library's own RCCL path — the pipeline runs its pipelined schedule: the plane-local tail of every stage
- * (y-inverse, x-inverse + epilogue, chained forward x / y) works per chunk of planes while the other chunks are on the
- * wire, and the forward transposes of the next stage leave as soon as their planes are done (KW_SLAB_CHUNKS, default 2;
- * KW_SLAB_PIPELINE=0: whole-array schedule). */
+ * as with the library's own RCCL path — the pipeline runs its pipelined schedule: a third buffer set for the transposed
+ * spectra, the forward transposes of the next stage started by the producing stage, small messages batched into one
+ * exchange per stage and direction, and with KW_SLAB_CHUNKS=2..4 the plane-local tail of every stage (y-inverse,
+ * x-inverse + epilogue, chained forward x / y) run per chunk of planes while the other chunks are on the wire
+ * (KW_SLAB_PIPELINE=0: whole-array schedule). */
 typedef int (*kw_exchange_piece_fn)(void* user, void* send, void* recv, size_t stride_bytes, size_t offset_bytes, size_t bytes,
                                     int slot);
 KW_API kw_status kw_fused_set_slab_pieces(kw_ctx* ctx, kw_exchange_piece_fn start, kw_exchange_wait_fn wait);

@@ -2362,20 +2362,17 @@ kw_status create_impl(kw_ctx* ctx, void* const s[3], void* const t[3])
   memset(f.xslot, -1, sizeof(f.xslot));
   {
     // Pipelined schedule: whenever the exchange can move plane chunks (the library's RCCL path, or a piece callback).
-    // KW_SLAB_PIPELINE=0 keeps the whole-array schedule; KW_SLAB_CHUNKS sets the chunk count (default: 2 where the
-    // per-peer chunk stays above 4 MB, else 1; chunks are whole planes and whole x tiles).
+    // KW_SLAB_PIPELINE=0 keeps the whole-array schedule; KW_SLAB_CHUNKS sets the chunk count (chunks are whole planes
+    // and whole x tiles).
     const char* e  = getenv("KW_SLAB_PIPELINE");
     const bool can = f.slab && (f.exchange_piece != nullptr || (f.exchange == nullptr && f.exchange_start == nullptr));
     f.pipelined    = can && !(e != nullptr && e[0] == '0');
+    // Plane chunks are off by default (KW_SLAB_CHUNKS=1): a step on 8 GPUs is bound by the links, and every exchange
+    // group has a fixed cost on the wire (~30 us measured with RCCL on one rank) and on the launching thread (~44 us);
+    // with the links modelled (tools/emulate_rank.py) two chunks gain 3-4 % at a 10 us fixed cost and lose 6 % at 30 us.
     const char* ec = getenv("KW_SLAB_CHUNKS");
-    uint32_t nch   = (ec != nullptr && atoi(ec) > 0) ? static_cast<uint32_t>(atoi(ec)) : 2u;
+    uint32_t nch   = (ec != nullptr && atoi(ec) > 0) ? static_cast<uint32_t>(atoi(ec)) : 1u;
     if (nch > KW_XCHUNKS_MAX) nch = KW_XCHUNKS_MAX;
-    if (ec == nullptr)
-    { // every exchange costs the launching thread ~44 us (measured: tools/slab_host_time.py): chunk only while a chunk
-      // keeps a link busy for well longer than that — 4 MB per peer, ~70 us at ~60 GB/s
-      const size_t per_peer = static_cast<size_t>(c.nz) * f.nyl * c.nx_complex * sizeof(float2);
-      while (nch > 1 && per_peer / nch < (4u << 20)) nch--;
-    }
     while (nch > 1 && (c.nz % nch != 0 || (c.nz / nch * c.ny) % (2 * nl_x(c.nx)) != 0)) nch--;
     f.xchunks = f.pipelined ? nch : 1u;
     // Below 4 MB per peer and array the exchanges are latency- and launch-bound: all arrays of a stage then travel in

@@ -10,9 +10,19 @@
 // sender's stream waits for the receiver's "copied" event before the group counts as finished on it.
 //
 //   selected with KW_RCCL_LIB=<this library>  (kw_comm.hip binds RCCL at run time)
+//
+// Emulation mode (MOCK_RCCL_EMULATE=1; tools/emulate_rank.py): ONE rank of an N-rank run alone on the GPU.  Every peer is
+// looped back to the rank itself (values become meaningless, sizes and buffers are the real ones): a group then costs
+//   the launching thread   MOCK_GROUP_HOST_US  (default 44: what an RCCL group was measured to cost),
+//   the communication stream   a delay of  latency + (bytes to the busiest peer) / MOCK_LINK_GBS  (default 10 us, 60 GB/s:
+//                              every peer has its own xGMI link, so the links run in parallel), then
+//   local HBM              one device copy of what the rank sends (a real transfer also reads and writes it locally).
+// A timeline of one rank's kernels against modelled wire time — for choosing between the slab schedules, not a result.
 #include <hip/hip_runtime.h>
 
+#include <chrono>
 #include <condition_variable>
+#include <cstdlib>
 #include <cstdint>
 #include <cstring>
 #include <map>
@@ -51,16 +61,73 @@ uint64_t                g_next_world = 1;
 struct Op { bool send; const void* sptr; void* rptr; size_t bytes; int peer; mockComm* comm; hipStream_t stream; };
 thread_local std::vector<Op> t_ops;
 thread_local int             t_depth = 0;
+
+bool   emulate() { static const bool e = getenv("MOCK_RCCL_EMULATE") != nullptr && getenv("MOCK_RCCL_EMULATE")[0] == '1'; return e; }
+double env_or(const char* name, double dflt) { const char* v = getenv(name); return (v != nullptr && v[0] != 0) ? atof(v) : dflt; }
+
+__global__ void k_wire_delay(unsigned long long ticks)
+{ // holds the communication stream for the modelled transfer time without touching memory
+  const unsigned long long t0 = wall_clock64();
+  while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(64);
+}
 } // namespace
 
 struct mockComm { World* w; int rank; };
 
 namespace
 {
+ncclResult_t flush_emulated(const std::vector<Op>& ops)
+{
+  static const double host_us = env_or("MOCK_GROUP_HOST_US", 44.0), link_gbs = env_or("MOCK_LINK_GBS", 60.0),
+                      latency_us = env_or("MOCK_LINK_LATENCY_US", 10.0);
+  static int clock_khz = 0;
+  if (clock_khz == 0)
+  {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&clock_khz, hipDeviceAttributeWallClockRate, dev) != hipSuccess || clock_khz <= 0)
+      clock_khz = 100000; // 100 MHz
+  }
+  if (ops.empty()) return 0;
+  const auto t_enter = std::chrono::steady_clock::now();
+  std::map<int, size_t> to_peer;
+  for (const Op& o : ops) if (o.send && o.peer != o.comm->rank) to_peer[o.peer] += o.bytes;
+  size_t busiest = 0;
+  for (const auto& kv : to_peer) busiest = kv.second > busiest ? kv.second : busiest;
+  double wire_us = (busiest == 0) ? 0.0 : latency_us + static_cast<double>(busiest) / (link_gbs * 1e3);
+  if (wire_us > 20000.0) wire_us = 20000.0;
+  hipStream_t stream = ops[0].stream;
+  if (wire_us > 0.0)
+    hipLaunchKernelGGL(k_wire_delay, dim3(1), dim3(1), 0, stream, static_cast<unsigned long long>(wire_us * clock_khz / 1000.0));
+  // the i-th send to a peer pairs with the i-th receive from it: loop it back (the local HBM traffic of a real
+  // transfer).  The per-peer parts of one piece are evenly spaced (peer * stride): one strided copy per piece.
+  std::map<int, std::vector<const Op*>> sends, recvs;
+  for (const Op& o : ops) (o.send ? sends : recvs)[o.peer].push_back(&o);
+  const int    npeers  = static_cast<int>(sends.size());
+  const size_t npieces = sends.empty() ? 0 : sends.begin()->second.size();
+  for (size_t i = 0; i < npieces; i++)
+  {
+    const Op* s0 = sends.begin()->second[i];
+    const Op* r0 = recvs.begin()->second.size() > i ? recvs.begin()->second[i] : nullptr;
+    if (r0 == nullptr || r0->bytes != s0->bytes) return 2;
+    size_t pitch = s0->bytes;
+    if (npeers > 1)
+    {
+      auto it = sends.begin(); ++it;
+      pitch = static_cast<size_t>(static_cast<const char*>(it->second[i]->sptr) - static_cast<const char*>(s0->sptr));
+    }
+    if (hipMemcpy2DAsync(r0->rptr, pitch, s0->sptr, pitch, s0->bytes, static_cast<size_t>(npeers), hipMemcpyDeviceToDevice,
+                         stream) != hipSuccess) return 1;
+  }
+  // what the real library costs the launching thread, the calls above included
+  while (std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_enter).count() < host_us) {}
+  return 0;
+}
+
 ncclResult_t flush()
 {
   std::vector<Op> ops;
   ops.swap(t_ops);
+  if (emulate()) return flush_emulated(ops);
   std::vector<std::tuple<int, int, uint64_t>> my_sends;
   { // 1. post every send with its "data ready" event
     std::unique_lock<std::mutex> lk(g_mu);
@@ -134,7 +201,7 @@ ncclResult_t ncclCommInitRank(ncclComm_t* comm, int nranks, ncclUniqueId id, int
   if (w.nranks != nranks || rank < 0 || rank >= nranks) return 4;
   w.joined++;
   g_cv.notify_all();
-  g_cv.wait(lk, [&] { return w.joined >= w.nranks; }); // collective, like the real one
+  if (!emulate()) g_cv.wait(lk, [&] { return w.joined >= w.nranks; }); // collective, like the real one
   *comm = new mockComm{&w, rank};
   return 0;
 }
