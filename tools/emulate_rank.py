@@ -32,7 +32,7 @@ def main():
     from kwave_amd import capi, synthetic
     from kwave_amd.dist import partition_problem, slab_range
     from kwave_amd.solver import HostSolver
-    n, P, r = a.grid, a.ranks, a.rank
+    n, P, r = a.grid, a.ranks, min(a.rank, a.ranks - 1)
     z0, z1 = slab_range(n, r, P)
     pr = synthetic.make_problem(n, n, n, heterogeneous=True, nonlinear=True, absorbing=True, source="p0", nt=a.steps + 12,
                                 zslab=(z0, z1))
