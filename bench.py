@@ -269,6 +269,20 @@ def run_distributed(args):
         sim.close()
         return sec, per_step
 
+    def schedule_of(grid):
+        """which slab schedule the device library picks for this grid (the rules of kw_fused.hip's create_impl)"""
+        nx, ny, nz = grid
+        if state["exchange"] != "native" or os.environ.get("KW_SLAB_PIPELINE", "1")[:1] == "0":
+            return "whole-array exchanges, per-array pipelining (callback transport or KW_SLAB_PIPELINE=0)"
+        per_peer = (nz // world) * (ny // world) * (nx // 2 + 1) * 8
+        batch = os.environ.get("KW_SLAB_BATCH")
+        if (batch[:1] == "1") if batch else (per_peer < (4 << 20)):
+            return f"batched: one exchange per stage and direction ({per_peer / 2 ** 20:.1f} MiB per peer and array)"
+        chunks = max(1, int(os.environ.get("KW_SLAB_CHUNKS", "1") or 1))
+        return (f"per-array pipelining, forward transposes started by the producing stage, "
+                f"{'whole-array exchanges' if chunks == 1 else str(chunks) + ' plane chunks'} "
+                f"({per_peer / 2 ** 20:.1f} MiB per peer and array)")
+
     c4 = None
     if args.weak:
         if world not in WEAK_DIMS:
@@ -286,6 +300,7 @@ def run_distributed(args):
             c4 = {"grid": [512, 512, 512], "steps": k5, "warmup": w5, "n_gpus": world,
                   "steps_per_s": round(k5 / sec5, 3), "steps_per_s_1gpu": round(one, 3),
                   "speedup_vs_1gpu": round((k5 / sec5) / one, 3) if one > 0 else None, "exchanges_per_step": ex5,
+                  "slab_schedule": schedule_of((512, 512, 512)),
                   "note": "BASELINE config 4 (north_star: >= 3.5x at 8 GPUs vs 1 on 512^3); 1-GPU figure measured by "
                           "rank 0 alone in this run (non-slab fused path)"}
     sec, ex = slab_run(grid, K, W)
@@ -310,7 +325,7 @@ def run_distributed(args):
                           "global_steps_per_s": round(global_rate, 2),
                           "value_definition": "N x global time-steps/s (each GPU owns one 256^3-voxel block)" if args.weak
                           else "global time-steps/s of this grid on N GPUs",
-                          "exchanges_per_step": ex},
+                          "exchanges_per_step": ex, "slab_schedule": schedule_of(grid)},
                "roofline": {"bound": "hbm", "kernel": "step (all ranks)", "peak": HBM_PEAK_GBS * world, "unit": "GB/s",
                             "achieved": round(b_global / (sec / K) / 1e9, 1),
                             "frac": round(b_global / (sec / K) / 1e9 / (HBM_PEAK_GBS * world), 4), "traffic": None}}
