@@ -366,3 +366,16 @@ def test_native_exchange_with_many_ranks_on_one_gpu(orc, syn, tmp_path, ranks, d
     assert rel_l2(res["series"], np.array(series)) < TOL
     assert int(res["exchanges"][0]) >= 6 * (steps - 1)
     o.close()
+
+
+def test_rank_emulation_tool_runs():
+    """tools/emulate_rank.py (one rank of an N-GPU run, links modelled by the mock exchange library): the tool behind the
+    schedule defaults of DESIGN §5 keeps running."""
+    import kwave_amd  # noqa: F401
+    from kwave_amd import capi
+    if not os.path.exists(os.path.join(capi.PKG, "lib", "libmock_rccl.so")):
+        pytest.skip("mock exchange library not built")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "emulate_rank.py"), "--grid", "64", "--ranks", "4", "--steps", "5"],
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300, env=dict(os.environ))
+    assert r.returncode == 0, r.stdout[-2000:]
+    assert "ms/step" in r.stdout and "exchange groups/step" in r.stdout
