@@ -11,7 +11,7 @@ from kwave_amd import capi  # noqa: E402
 
 dev = capi.Device()
 g = C.c_double()
-for mb in (256, 1024, 2048):
-    capi.check(dev.L.kw_measure_copy_bandwidth(dev.ctx, C.c_size_t(mb << 20), 10, C.byref(g)))
+for mb in ([int(x) for x in sys.argv[1:]] or [256, 1024, 2048]):
+    capi.check(dev.L.kw_measure_copy_bandwidth(dev.ctx, C.c_size_t(mb << 20), 50 if mb < 256 else 10, C.byref(g)))
     print(f"{mb} MiB each way: {g.value:.1f} GB/s")
 dev.close()
