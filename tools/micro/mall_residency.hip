@@ -81,5 +81,34 @@ int main()
            warm, 2.0 * scratch_bytes / warm / 1e3, t_plain, 4.0 * stream_bytes / t_plain / 1e3, after_plain, t_nt,
            4.0 * stream_bytes / t_nt / 1e3, after_nt);
   }
+  // out of place, ping-pong between two buffers of the same size: one array (67.6 MB each) and three (203 MB each)
+  v4f* s2;
+  hipMalloc(&s2, scratch_bytes);
+  hipMemset(s2, 0, scratch_bytes);
+  for (size_t bytes : { scratch_bytes / 3, scratch_bytes })
+  {
+    const size_t n = bytes / 16;
+    const dim3 g(static_cast<unsigned>((n + 1023) / 1024));
+    float best = 1e30f;
+    for (int rep = 0; rep < 6; rep++)
+    {
+      hipEventRecord(e0);
+      hipLaunchKernelGGL(k_stream<false>, g, blk, 0, 0, (rep & 1) ? s2 : s, (rep & 1) ? s2 : s, (rep & 1) ? s2 : s, (rep & 1) ? s : s2, n);
+      hipEventRecord(e1);
+      const float t = timed(e0, e1);
+      if (rep >= 2 && t < best) best = t;
+    }
+    float best_in = 1e30f;
+    for (int rep = 0; rep < 6; rep++)
+    {
+      hipEventRecord(e0);
+      hipLaunchKernelGGL(k_touch, g, blk, 0, 0, s, n);
+      hipEventRecord(e1);
+      const float t = timed(e0, e1);
+      if (rep >= 2 && t < best_in) best_in = t;
+    }
+    printf("%.1f MB: ping-pong between two buffers %.1f us (%.0f GB/s) | in place %.1f us (%.0f GB/s)\n", bytes / 1e6, best,
+           2.0 * bytes / best / 1e3, best_in, 2.0 * bytes / best_in / 1e3);
+  }
   return 0;
 }
