@@ -7,7 +7,8 @@ Every rank reads its own planes of the grid-sized input arrays (and the small da
 rank 0 writes the output file from the gathered pieces: sampled series / aggregates in the order of the global sensor
 mask, whole-domain streams and final fields with the slabs stacked along z, and the scalars of the reference's output
 file (Parameters.cpp:559-647).  The reference is single-GPU; the flags are the subset of its command line
-(CommandLineParameters.cpp:264-292) that the slab path carries: index sensor masks, p / u raw and aggregated streams.
+(CommandLineParameters.cpp:264-292) that the slab path carries: index sensor masks, p / u raw and aggregated streams,
+compression and intensity streams, checkpoint / restart (one checkpoint file per rank).
 """
 from __future__ import annotations
 
@@ -42,7 +43,13 @@ def main(argv=None) -> int:
     ap.add_argument("--frequency", type=float, default=0.0)
     ap.add_argument("--mos", type=int, default=1)
     ap.add_argument("--harmonics", type=int, default=1)
+    ap.add_argument("--checkpoint_file", default=None,
+                    help="restart point of the run (CommandLineParameters.cpp:304-312): every rank keeps its slab in <file>.rank<r>of<P>")
+    ap.add_argument("--checkpoint_timesteps", type=int, default=0, help="stop and checkpoint after this many steps of this launch")
+    ap.add_argument("--checkpoint_interval", type=float, default=0.0, help="stop and checkpoint after this many seconds of this launch")
     a = ap.parse_args(argv)
+    if (a.checkpoint_timesteps or a.checkpoint_interval) and not a.checkpoint_file:
+        raise SystemExit("Error: --checkpoint_timesteps / --checkpoint_interval need --checkpoint_file.")
     a.p_raw |= a.p
     a.u_raw |= a.u
 
@@ -71,7 +78,52 @@ def main(argv=None) -> int:
         raise SystemExit("Error: The beginning of data sampling is out of the simulation time span <1, Nt>.")
     sim = DistSolver(loc, rank, world, nz, device_index=dev, sampling_start=a.start - 1, benchmark_steps=a.benchmark, **opts)
     nt = a.benchmark or int(np.asarray(pr["Nt"]).ravel()[0])
-    sim.run(nt)
+
+    # ---- checkpoint / restart (KSpaceFirstOrderSolver.cpp:186-228, 1176-1224 per slab): the seven state arrays, the
+    # time index and the stream accumulators of this rank's slab, one file per rank, written beside its target and
+    # renamed; a launch that finds the files of ALL ranks continues from them, and removes them once the run is complete
+    import pickle
+    import time
+    ckpt = f"{a.checkpoint_file}.rank{rank}of{world}" if a.checkpoint_file else None
+
+    def all_ranks(flag: bool) -> bool:
+        t = torch.tensor([1 if flag else 0], dtype=torch.int32)
+        if a.backend == "nccl":
+            t = t.cuda()
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        return bool(t.item())
+
+    if ckpt and all_ranks(os.path.exists(ckpt)):
+        with open(ckpt, "rb") as fh:
+            st = pickle.load(fh)
+        if st.get("grid") != (int(np.asarray(pr["Nx"]).ravel()[0]), int(np.asarray(pr["Ny"]).ravel()[0]), nz, world, nt):
+            raise SystemExit(f"Error: {ckpt} belongs to another run (grid, rank count or Nt differ).")
+        sim.sim.restore_state(st["state"])
+    t_launch = time.time()
+    done_here = 0
+    while sim.t < nt:
+        leg = min(nt - sim.t, 20)
+        if a.checkpoint_timesteps:
+            leg = min(leg, a.checkpoint_timesteps - done_here)
+        sim.run(leg)
+        done_here += leg
+        stop = bool(a.checkpoint_timesteps and done_here >= a.checkpoint_timesteps)
+        if a.checkpoint_interval:
+            sim.sync()
+            stop = stop or (time.time() - t_launch >= a.checkpoint_interval)
+        if not all_ranks(not stop) and sim.t < nt:   # any rank out of time: every rank stops here
+            sim.sync()
+            state = {"grid": (int(np.asarray(pr["Nx"]).ravel()[0]), int(np.asarray(pr["Ny"]).ravel()[0]), nz, world, nt),
+                     "state": sim.sim.checkpoint_state()}
+            with open(ckpt + ".partial", "wb") as fh:
+                pickle.dump(state, fh, protocol=4)
+            os.replace(ckpt + ".partial", ckpt)
+            dist.barrier()
+            if rank == 0:
+                print(f"time steps: {sim.t} of {nt}, checkpoint: {a.checkpoint_file}.rank*of{world}")
+            sim.close()
+            dist.destroy_process_group()
+            return 0
     sim.finish()
 
     piece = {"pos": info.get("sensor_positions", np.zeros(0, dtype=np.int64)), "streams": {}, "fields": {}}
@@ -114,6 +166,8 @@ def main(argv=None) -> int:
         assert all(v.size == plane * nz for k, v in out.items() if k.endswith(("_final", "_all")))
         h5io.write_file(out, a.output, "output", f"k-Wave output written by kwave_amd.run_slab ({world} slab ranks)")
         print(f"time steps: {sim.t}, ranks: {world}, output: {a.output}")
+    if ckpt and os.path.exists(ckpt):
+        os.remove(ckpt)  # the run is complete (main.cpp:239-241 removes the checkpoint file likewise)
     sim.close()
     dist.barrier()
     dist.destroy_process_group()

@@ -379,3 +379,42 @@ def test_rank_emulation_tool_runs():
                        stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300, env=dict(os.environ))
     assert r.returncode == 0, r.stdout[-2000:]
     assert "ms/step" in r.stdout and "exchange groups/step" in r.stdout
+
+
+def test_file_driven_slab_run_restarts_from_its_checkpoints(syn, tmp_path):
+    """kwave_amd.run_slab --checkpoint_file / --checkpoint_timesteps: a run cut into three launches (every rank keeps its
+    slab's state arrays, time index and stream accumulators in its own checkpoint file) writes the output file of the
+    uninterrupted run, bit for bit (KSpaceFirstOrderSolver.cpp:186-228, 1176-1224 on the decomposed grid)."""
+    import kwave_amd  # noqa: F401
+    from kwave_amd import h5io
+    if not os.path.exists(h5io.H5_LIB_PATH):
+        pytest.skip("HDF5 component not built")
+    nt, world = 18, 2
+    pr = syn.make_problem(32, 48, 32, heterogeneous=True, nonlinear=True, absorbing=True, source="p_source", source_mode=2,
+                          source_many=1, nt=nt, pml_size=4, sensor="random")
+    path_in, whole, legs, ckpt = (str(tmp_path / n) for n in ("in.h5", "whole.h5", "legs.h5", "ckpt"))
+    h5io.write_input_file(pr, path_in)
+    flags = ["--p_raw", "--p_max", "--u_rms", "--p_final", "--u_final", "--p_min_all"]
+
+    def launch(out, extra):
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr",
+               "127.0.0.1", "--master-port", "29761", "-m", "kwave_amd.run_slab", "-i", path_in, "-o", out, "-s", "2",
+               "--backend", "gloo"] + flags + extra
+        r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600,
+                           cwd=os.path.dirname(HERE), env=dict(os.environ, OMP_NUM_THREADS="4", HSA_ENABLE_IPC_MODE_LEGACY="0"))
+        assert r.returncode == 0, r.stdout[-4000:]
+        return r.stdout
+
+    launch(whole, [])
+    extra = ["--checkpoint_file", ckpt, "--checkpoint_timesteps", "7"]
+    out1 = launch(legs, extra)
+    assert "time steps: 7 of 18" in out1 and not os.path.exists(legs)
+    assert all(os.path.exists(f"{ckpt}.rank{r}of{world}") for r in range(world))
+    out2 = launch(legs, extra)
+    assert "time steps: 14 of 18" in out2 and not os.path.exists(legs)
+    out3 = launch(legs, extra)
+    assert "time steps: 18" in out3 and os.path.exists(legs)
+    assert not any(os.path.exists(f"{ckpt}.rank{r}of{world}") for r in range(world))
+    for name in ("p", "p_max", "ux_rms", "uz_rms", "p_final", "uy_final", "p_min_all", "t_index", "Nt"):
+        a, b = h5io.read_dataset(legs, name), h5io.read_dataset(whole, name)
+        assert a.shape == b.shape and np.array_equal(a, b), name
