@@ -42,6 +42,8 @@ KWH_API int kwh_h5_read(const char* path, const char* name, void* dst, uint64_t 
 KWH_API int kwh_h5_dataset_exists(const char* path, const char* name, int32_t* exists);
 /* planes [z0, z0 + n_planes) of a 3-D float dataset: the part of a grid-sized input array one slab rank needs */
 KWH_API int kwh_h5_read_planes(const char* path, const char* name, uint64_t z0, uint64_t n_planes, float* dst);
+/* one cuboid of a corner-mask stream into an existing output file: "<group>/<index>", dims (nx, ny, nz, nt); nt = 0: aggregate */
+KWH_API int kwh_h5_append_cuboid(const char* path, const char* group, uint64_t index, const uint64_t dims[4], const float* data);
 /* file of any type ("input", "output") from in-memory datasets; kwh_write_input_file is this with type "input" */
 KWH_API int kwh_write_file(const char* path, const char* file_type, const char* description, const kwh_dataset* sets,
                            size_t n, const int32_t* is_complex);

@@ -88,8 +88,29 @@ def partition_problem(pr: Dict[str, np.ndarray], rank: int, nranks: int, arrays_
             s_sel, s_loc = local_index(a)
             out[name] = s_loc.reshape(1, 1, -1)
             info["sensor_positions"] = s_sel
+        elif name == "sensor_mask_corners":
+            # cuboids [x0 y0 z0 x1 y1 z1] (1-based, inclusive): this rank keeps the part of every cuboid inside its slab,
+            # z re-based; info["cuboids"] = (cuboid, first plane, end plane) of each kept part within its cuboid
+            rows, kept = [], []
+            for c, (x0, y0, cz0, x1, y1, cz1) in enumerate(a.reshape(-1, 6).astype(np.int64)):
+                lo, hi = max(cz0, z0 + 1), min(cz1, z1)
+                if lo <= hi:
+                    rows.append([x0, y0, lo - z0, x1, y1, hi - z0])
+                    kept.append((c, int(lo - cz0), int(hi - cz0 + 1)))
+            info["cuboids"] = kept
+            info["cuboid_shapes"] = [(int(r[5] - r[2] + 1), int(r[4] - r[1] + 1), int(r[3] - r[0] + 1)) for r in a.reshape(-1, 6).astype(np.int64)]
+            if rows:
+                out[name] = np.array(rows, dtype=U64).reshape(1, len(rows), 6)
+            else:  # no part of any cuboid here: this rank samples nothing
+                out["sensor_mask_index"] = np.zeros((1, 1, 0), dtype=U64)
+                out["sensor_mask_type"] = np.array([[[0]]], dtype=U64)
+        elif name == "sensor_mask_type" and "sensor_mask_type" in out:
+            pass  # set above: a rank without any cuboid part runs with an empty index mask
         else:
             out[name] = a
+    if "sensor_mask_corners" in pr and not info.get("cuboids"):
+        out["sensor_mask_type"] = np.array([[[0]]], dtype=U64)
+        out.pop("sensor_mask_corners", None)
     return out, info
 
 

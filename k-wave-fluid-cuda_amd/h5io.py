@@ -185,6 +185,17 @@ def write_file(datasets: Dict[str, np.ndarray], path: str, file_type: str = "out
     _h5check(L.kwh_write_file(path.encode(), file_type.encode(), description.encode(), sets, len(datasets), cplx))
 
 
+def append_cuboid(path: str, group: str, index: int, data: np.ndarray, series: bool) -> None:
+    """Add dataset "<group>/<index>" (1-based) to an existing output file: data shaped (steps, nz, ny, nx) for a series,
+    (nz, ny, nx) for an aggregate — the per-cuboid layout of a corner sensor mask (CuboidOutputStream.cpp:95-140)."""
+    L = load_h5()
+    L.kwh_h5_append_cuboid.argtypes = [C.c_char_p, C.c_char_p, C.c_uint64, C.POINTER(C.c_uint64 * 4), C.c_void_p]
+    a = np.ascontiguousarray(data, dtype=np.float32)
+    nz, ny, nx = a.shape[-3:]
+    dims = (C.c_uint64 * 4)(nx, ny, nz, a.shape[0] if series else 0)
+    _h5check(L.kwh_h5_append_cuboid(path.encode(), group.encode(), index, C.byref(dims), a.ctypes.data))
+
+
 def read_attribute(path: str, dataset: str, attr: str) -> str:
     buf = C.create_string_buffer(256)
     _h5check(load_h5().kwh_h5_read_attribute(path.encode(), dataset.encode(), attr.encode(), buf, 256))

@@ -422,6 +422,22 @@ KWH_API int kwh_write_file(const char* path, const char* file_type, const char* 
   KWH_CATCH
 }
 
+/* add one cuboid of a corner-mask stream to an existing output file: dataset "<group>/<index>" with dims (nx, ny, nz, nt)
+ * — nt = 0 for an aggregate — in the layout of kwh_write_output_file (CuboidOutputStream.cpp:95-140); the group is
+ * created with its first cuboid.  Used by the multi-GPU runner, whose rank 0 assembles the cuboids from the slabs. */
+KWH_API int kwh_h5_append_cuboid(const char* path, const char* group, uint64_t index, const uint64_t dims[4], const float* data)
+{
+  KWH_TRY
+  if (!path || !group || !dims || !data || index == 0) throw std::invalid_argument("kwh_h5_append_cuboid: invalid argument");
+  Hdf5File f;
+  f.open(path, false);
+  f.setOutputLayout(true, 0);
+  if (!f.datasetExists(group)) f.createGroup(group);
+  f.writeCuboid(std::string(group) + "/" + std::to_string(index), DimensionSizes(dims[0], dims[1], dims[2], dims[3]), data);
+  f.close();
+  KWH_CATCH
+}
+
 KWH_API int kwh_h5_dataset_exists(const char* path, const char* name, int32_t* exists)
 {
   KWH_TRY

@@ -7,7 +7,7 @@ Every rank reads its own planes of the grid-sized input arrays (and the small da
 rank 0 writes the output file from the gathered pieces: sampled series / aggregates in the order of the global sensor
 mask, whole-domain streams and final fields with the slabs stacked along z, and the scalars of the reference's output
 file (Parameters.cpp:559-647).  The reference is single-GPU; the flags are the subset of its command line
-(CommandLineParameters.cpp:264-292) that the slab path carries: index sensor masks, p / u raw and aggregated streams,
+(CommandLineParameters.cpp:264-292) that the slab path carries: index and corner (cuboid) sensor masks, p / u raw and aggregated streams,
 compression and intensity streams, checkpoint / restart (one checkpoint file per rank).
 """
 from __future__ import annotations
@@ -69,8 +69,6 @@ def main(argv=None) -> int:
     nz = int(h5io.read_dataset(a.input, "Nz").ravel()[0])
     z0, z1 = slab_range(nz, rank, world)
     pr = h5io.read_problem(a.input, zslab=(z0, z1))
-    if "sensor_mask_corners" in pr:
-        raise SystemExit("run_slab: corner (cuboid) sensor masks are not supported in slab mode")
     loc, info = partition_problem(pr, rank, world, arrays_are_local=True)
     opts = {f.lower(): 1 for f in STREAM_FLAGS if getattr(a, f)}
     opts.update(period=a.period, frequency=a.frequency, mos=a.mos, harmonics=a.harmonics)
@@ -126,7 +124,9 @@ def main(argv=None) -> int:
             return 0
     sim.finish()
 
-    piece = {"pos": info.get("sensor_positions", np.zeros(0, dtype=np.int64)), "streams": {}, "fields": {}}
+    corners = "sensor_mask_corners" in pr
+    piece = {"pos": info.get("sensor_positions", np.zeros(0, dtype=np.int64)), "streams": {}, "fields": {},
+             "cuboids": info.get("cuboids", [])}
     for name in sim.stream_names():
         piece["streams"][name] = sim.stream(name)
     if a.p_final:
@@ -147,10 +147,30 @@ def main(argv=None) -> int:
         out["Nt"] = np.array([[[nt]]], dtype=np.uint64)
         out["t_index"] = np.array([[[sim.t]]], dtype=np.uint64)
         nsens = int(np.asarray(pr["sensor_mask_index"]).size) if "sensor_mask_index" in pr else 0
-        for name in piece["streams"]:
-            parts = [g["streams"][name] for g in gathered]
+        names = sorted({n for g in gathered for n in g["streams"]})
+        cuboid_sets = {}   # corner masks: stream -> [(cuboid, array (steps, nz, ny, nx) or (nz, ny, nx)), ...]
+        for name in names:
+            parts = [g["streams"].get(name) for g in gathered]
             if name.endswith("_all"):      # whole-domain aggregate: the slabs stacked along z
                 out[name] = np.concatenate([p.reshape(-1, ny, nx) for p in parts], axis=0)
+                continue
+            if corners:
+                # every rank holds, per stored step, its parts of the cuboids back to back (x fastest, then y, then z):
+                # a cuboid is its parts stacked along z
+                shapes = info["cuboid_shapes"]
+                steps = max((np.asarray(p).shape[0] if np.asarray(p).ndim == 2 else 1) for p, g in zip(parts, gathered)
+                            if p is not None and g["cuboids"])
+                series = any(np.asarray(p).ndim == 2 for p in parts if p is not None)
+                full = [np.zeros((steps,) + shp, dtype=np.float32) for shp in shapes]
+                for p, g in zip(parts, gathered):
+                    if p is None or not g["cuboids"]:
+                        continue
+                    rows, off = np.asarray(p).reshape(steps, -1), 0
+                    for c, zlo, zhi in g["cuboids"]:
+                        n = (zhi - zlo) * shapes[c][1] * shapes[c][2]
+                        full[c][:, zlo:zhi] = rows[:, off:off + n].reshape(steps, zhi - zlo, shapes[c][1], shapes[c][2])
+                        off += n
+                cuboid_sets[name] = [(c, a if series else a[0], series) for c, a in enumerate(full)]
                 continue
             # per sensor point and stored step: one value, or 2 * harmonics coefficients of a compression frame
             shapes = [(np.asarray(p).shape[0] if np.asarray(p).ndim == 2 else 1) for p, g in zip(parts, gathered) if g["pos"].size]
@@ -165,6 +185,9 @@ def main(argv=None) -> int:
             out[name] = np.concatenate([g["fields"][name].reshape(-1, ny, nx) for g in gathered], axis=0)
         assert all(v.size == plane * nz for k, v in out.items() if k.endswith(("_final", "_all")))
         h5io.write_file(out, a.output, "output", f"k-Wave output written by kwave_amd.run_slab ({world} slab ranks)")
+        for name, sets in cuboid_sets.items():
+            for c, arr, series in sets:
+                h5io.append_cuboid(a.output, name, c + 1, arr, series)
         print(f"time steps: {sim.t}, ranks: {world}, output: {a.output}")
     if ckpt and os.path.exists(ckpt):
         os.remove(ckpt)  # the run is complete (main.cpp:239-241 removes the checkpoint file likewise)

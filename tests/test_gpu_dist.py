@@ -418,3 +418,53 @@ def test_file_driven_slab_run_restarts_from_its_checkpoints(syn, tmp_path):
     for name in ("p", "p_max", "ux_rms", "uz_rms", "p_final", "uy_final", "p_min_all", "t_index", "Nt"):
         a, b = h5io.read_dataset(legs, name), h5io.read_dataset(whole, name)
         assert a.shape == b.shape and np.array_equal(a, b), name
+
+
+@pytest.mark.parametrize("world,first_slab_only", [(2, False), (4, False), (4, True)])
+def test_file_driven_slab_run_with_a_corner_sensor_mask(syn, tmp_path, world, first_slab_only):
+    """sensor_mask_type = corners on a Z-slab decomposition: every rank samples the parts of the cuboids inside its slab
+    (a cuboid may span several slabs, a rank may hold none), rank 0 stacks them along z into the reference's layout — one
+    group per stream, one 4-D / 3-D dataset per cuboid (CuboidOutputStream.cpp:95-140) — equal to the single-GPU file."""
+    import kwave_amd  # noqa: F401
+    from kwave_amd import h5io
+    if not os.path.exists(h5io.H5_LIB_PATH):
+        pytest.skip("HDF5 component not built")
+    nt, start = 14, 2
+    pr = syn.make_problem(32, 48, 32, heterogeneous=True, nonlinear=True, absorbing=True, source="p0", nt=nt, pml_size=4)
+    pr = {k: v for k, v in pr.items() if k != "sensor_mask_index"}
+    # cuboid 1 (around the source) crosses the slab boundaries of both decompositions, cuboid 2 is one voxel, cuboid 3
+    # sits in the first slab
+    corners = np.array([[10, 18, 6, 20, 28, 26], [16, 24, 17, 16, 24, 17], [12, 20, 1, 18, 26, 6]], dtype=np.uint64)
+    if first_slab_only:  # every cuboid inside the first of four slabs: three ranks sample nothing
+        corners = np.array([[10, 18, 2, 20, 28, 8], [16, 24, 5, 16, 24, 5], [12, 20, 1, 18, 26, 6]], dtype=np.uint64)
+    pr["sensor_mask_type"] = np.array([[[1]]], dtype=np.uint64)
+    pr["sensor_mask_corners"] = corners.reshape(1, 3, 6)
+    path_in, one, many = (str(tmp_path / n) for n in ("in.h5", "one.h5", f"slab{world}.h5"))
+    h5io.write_input_file(pr, path_in)
+    flags = dict(p_raw=1, p_max=1, u_rms=1, p_final=1, p_min_all=1)
+    fs = h5io.FileSolver(path_in, sampling_start=start - 1, **flags)
+    fs.run(nt)
+    fs.finish()
+    fs.write_output(one)
+    fs.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr",
+           "127.0.0.1", "--master-port", str(29770 + world), "-m", "kwave_amd.run_slab", "-i", path_in, "-o", many,
+           "-s", str(start), "--backend", "gloo"] + ["--" + f for f in flags]
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600,
+                       cwd=os.path.dirname(HERE), env=dict(os.environ, OMP_NUM_THREADS="4", HSA_ENABLE_IPC_MODE_LEGACY="0"))
+    assert r.returncode == 0, r.stdout[-4000:]
+    for name in ("p_final", "p_min_all"):
+        assert rel_l2(h5io.read_dataset(many, name), h5io.read_dataset(one, name)) < TOL, name
+    # Samples far from the wave are round-off of the field around them: two fp32 runs agree to 1e-5 of the stream's
+    # scale there, not of the samples' own size (the launch-per-kernel and the fused path of ONE GPU differ by 2e-4 of
+    # the samples' norm on voxels inside the PML) — tolerance against the largest sample of the stream, and the plain
+    # relative norm on the cuboid around the source, which a misplaced plane or row would break by orders of magnitude.
+    for name in ("p", "p_max", "ux_rms", "uz_rms"):
+        ref = {c: h5io.read_dataset(one, f"{name}/{c}") for c in (1, 2, 3)}
+        scale = max(np.abs(v).max() for v in ref.values())
+        for c in (1, 2, 3):
+            ds = f"{name}/{c}"
+            assert h5io.dataset_info_4d(many, ds) == h5io.dataset_info_4d(one, ds), ds
+            got = h5io.read_dataset(many, ds)
+            assert got.shape == ref[c].shape and np.abs(got - ref[c]).max() <= 2 * TOL * scale, ds
+        assert rel_l2(h5io.read_dataset(many, f"{name}/1"), ref[1]) < 10 * TOL, name
