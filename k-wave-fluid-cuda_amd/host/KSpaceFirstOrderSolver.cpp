@@ -425,7 +425,8 @@ void KSpaceFirstOrderSolver::computeQTerm(OutputStreamContainer::OutputStreamIdx
   RealMatrix* grid[3] = {&getTemp1RealND(), &getTemp2RealND(), &getTemp3RealND()};
   HipFftComplexMatrix& tempShift = fft(MI::kTempHipFftShift);
   const float  pi2 = static_cast<float>(M_PI) * 2.0f;
-  const size_t n[3] = {dims.nx, dims.ny, dims.nz};
+  const DimensionSizes global = mParameters.getGlobalDimensionSizes(); // z lines have the global length in slab mode
+  const size_t n[3] = {dims.nx, dims.ny, global.nz};
   const float  d[3] = {mParameters.getDx(), mParameters.getDy(), mParameters.getDz()};
   const int    axes = mParameters.isSimulation3D() ? 3 : 2;
   for (int a = 0; a < axes; a++)
@@ -443,6 +444,22 @@ void KSpaceFirstOrderSolver::computeQTerm(OutputStreamContainer::OutputStreamIdx
     {
       const ssize_t shift = ssize_t((i + (n[a] / 2)) % n[a] - (n[a] / 2));
       k[i] = FloatComplex(0.0f, 1.0f) * (pi2 / d[a]) * (float(shift) / float(n[a]));
+    }
+    if (mFused)
+    { // one kernel per axis on the hand-written passes (and through the exchange for z lines that cross slabs): the
+      // half-length i*k extended to the full-length Hermitian filter R2C -> multiply -> C2R amounts to, 1/N folded in
+      std::vector<FloatComplex> full(n[a], FloatComplex(0.0f, 0.0f));
+      const float divider = 1.0f / static_cast<float>(n[a]);
+      for (size_t i = 1; i < (n[a] + 1) / 2; i++)
+      {
+        full[i]        = k[i] * divider;
+        full[n[a] - i] = std::conj(full[i]);
+      } // (bins 0 and N/2: i*k is imaginary there, C2R keeps the real part: zero)
+      DeviceBuffer df(ctx, n[a] * sizeof(FloatComplex));
+      kwCheck(kw_memcpy_h2d(ctx, df.ptr, full.data(), n[a] * sizeof(FloatComplex)));
+      kwCheck(kw_fused_shift_velocity(ctx, a, grid[a]->getDeviceData(), grid[a]->getDeviceData(), df.f()));
+      kwCheck(kw_sync(ctx)); // df goes out of scope
+      continue;
     }
     DeviceBuffer dk(ctx, nc * sizeof(FloatComplex));
     kwCheck(kw_memcpy_h2d(ctx, dk.ptr, k.data(), nc * sizeof(FloatComplex)));

@@ -62,8 +62,6 @@ void Parameters::init(const InputProvider& in, const Options& options)
     if (mOptions.nzGlobal != z * mOptions.slabRanks || mOptions.slabRank >= mOptions.slabRanks || y % mOptions.slabRanks != 0)
       throw std::invalid_argument("Z-slab decomposition: Nz_global must equal slabRanks * local Nz and Ny must divide by slabRanks");
     mGlobalDimensionSizes.nz = mOptions.nzGlobal;
-    if (mOptions.storeQTerm || mOptions.storeQTermC)
-      throw std::invalid_argument("Z-slab decomposition: the Q-term streams (divergence of the intensity over the whole grid) need a single GPU");
   }
   if (!isSimulation3D())
   { // 2-D (Nz == 1): what this build carries over from the 3-D path; the rest says so instead of computing nonsense

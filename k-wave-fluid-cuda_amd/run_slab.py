@@ -20,7 +20,8 @@ import numpy as np
 
 STREAM_FLAGS = ("p_raw", "p_rms", "p_max", "p_min", "p_max_all", "p_min_all", "p_final",
                 "u_raw", "u_rms", "u_max", "u_min", "u_max_all", "u_min_all", "u_final",
-                "u_non_staggered_raw", "p_c", "u_c", "u_non_staggered_c", "I_avg_c", "I_avg", "no_overlap")
+                "u_non_staggered_raw", "p_c", "u_c", "u_non_staggered_c", "I_avg_c", "I_avg", "Q_term", "Q_term_c",
+                "no_overlap")
 OUTPUT_SCALARS = ("Nx", "Ny", "Nz", "Nt", "dt", "dx", "dy", "dz", "c_ref", "pml_x_size", "pml_y_size", "pml_z_size",
                   "pml_x_alpha", "pml_y_alpha", "pml_z_alpha", "p_source_flag", "p0_source_flag", "transducer_source_flag",
                   "ux_source_flag", "uy_source_flag", "uz_source_flag", "nonuniform_grid_flag", "absorbing_flag",

@@ -45,8 +45,8 @@ def main():
     extra = {}
     if a.config5:
         dt = float(np.asarray(loc["dt"]).ravel()[0])
-        extra = dict(u_non_staggered_raw=1, p_c=1, u_non_staggered_c=1, i_avg_c=1, i_avg=1, period=1.0 / (1.0e6 * dt) / 2.0,
-                     mos=1, harmonics=2)
+        extra = dict(u_non_staggered_raw=1, p_c=1, u_non_staggered_c=1, i_avg_c=1, i_avg=1, q_term=1, q_term_c=1,
+                     period=1.0 / (1.0e6 * dt) / 2.0, mos=1, harmonics=2)
     sim = DistSolver(loc, rank, P, nz, device_index=dev, exchange=a.exchange, p_raw=1, p_max=1, **extra)
     sim.run(a.steps)
     sim.finish()

@@ -245,7 +245,8 @@ def test_native_slab_driver_without_interpreter(syn, tmp_path):
 def test_slab_config5_streams_match_the_single_gpu_run(syn, tmp_path, world, dims, exchange):
     """Non-staggered velocity, compression and intensity streams on a Z-slab decomposition (computeShiftedVelocity,
     KSpaceFirstOrderSolver.cpp:2714-2735): the x and y half-cell shifts are slab-local, the z shift sends the real array
-    through the exchange both ways.  Reference: the same streams of the single-GPU run."""
+    through the exchange both ways — and so does the z derivative of the Q-term (Q = -div(I_avg), :1783-2080), which runs
+    on the same one-kernel-per-axis transform.  Reference: the same streams of the single-GPU run."""
     import kwave_amd  # noqa: F401
     from kwave_amd.solver import HostSolver
     steps = 36
@@ -254,8 +255,8 @@ def test_slab_config5_streams_match_the_single_gpu_run(syn, tmp_path, world, dim
     pr = syn.make_problem(nx, ny, nz, heterogeneous=True, nonlinear=True, absorbing=True, source="p_source", source_mode=1,
                           source_many=1, nt=steps, pml_size=4, sensor="random")
     dt = float(pr["dt"].ravel()[0])
-    g = HostSolver(pr, p_raw=1, p_max=1, u_non_staggered_raw=1, p_c=1, u_non_staggered_c=1, i_avg_c=1, i_avg=1,
-                   period=1.0 / (1.0e6 * dt) / 2.0, mos=1, harmonics=2)
+    g = HostSolver(pr, p_raw=1, p_max=1, u_non_staggered_raw=1, p_c=1, u_non_staggered_c=1, i_avg_c=1, i_avg=1, q_term=1,
+                   q_term_c=1, period=1.0 / (1.0e6 * dt) / 2.0, mos=1, harmonics=2)
     g.run(steps)
     g.finish()
     assert rel_l2(res["uz_shifted"], g.field("uz_shifted")) < TOL
@@ -274,7 +275,7 @@ def test_slab_config5_streams_match_the_single_gpu_run(syn, tmp_path, world, dim
         scale = np.abs(np.asarray(g.stream(ref_name))).max()
         assert scale > 0 and np.abs(a - b).max() < 2e-5 * scale, name
         checked += 1
-    assert checked >= 12  # ux/uy/uz non-staggered raw + _c, p_c, Ix/Iy/Iz_avg_c, Ix/Iy/Iz_avg
+    assert checked >= 14  # ux/uy/uz non-staggered raw + _c, p_c, Ix/Iy/Iz_avg_c, Ix/Iy/Iz_avg, Q_term, Q_term_c
     g.close()
 
 
