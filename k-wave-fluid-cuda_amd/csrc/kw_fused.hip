@@ -400,6 +400,7 @@ struct ZArgs
   uint32_t      lstride, bstride; // Z_SHIFT: element stride along a line, offset per blockIdx.y (both in complex units)
   uint32_t      side_off;    // element offset of the x-Nyquist side array in the scratch arrays (0: none; see tile_coord)
   uint32_t      op_side_off; // float offset of the side column's values in the imported operators
+  uint32_t      axis_of[3];  // VGRAD: derivative axis of array i (0 ddx[kx], 1 ddy[ky], 2 along the line: dd[2][k]); 3-D: 0 1 2
 };
 
 // inverse along the line, started from the step-B register layout (thread (c,k1) holds X[k1 + R1*k2]); result:
@@ -558,7 +559,7 @@ template<int L, int MODE> __global__ __launch_bounds__(Geo<L>::THREADS, big_line
       {
         if (MODE == Z_PGRAD || MODE == Z_VGRAD)
         {
-          const uint32_t axis = (MODE == Z_PGRAD) ? (o == 0 ? 3u : 2u) : arr;
+          const uint32_t axis = (MODE == Z_PGRAD) ? (o == 0 ? 3u : 2u) : a.axis_of[arr];
           if (axis == 3)
           {
 #pragma unroll
@@ -814,7 +815,7 @@ template<int L, int MODE> __global__ __launch_bounds__(Geo<L / 2>::THREADS) void
 #pragma unroll 1
   for (int o = 0; o < NOUT; o++)
   {
-    const uint32_t axis = (MODE == Z_PGRAD) ? (o == 0 ? 3u : 2u) : arr;
+    const uint32_t axis = (MODE == Z_PGRAD) ? (o == 0 ? 3u : 2u) : a.axis_of[arr];
     float2 ra[R1], rb[R1];
 #pragma unroll
     for (int half = 0; half < 2; half++)
@@ -1836,6 +1837,9 @@ template<int MODE> kw_status launch_zfused(kw_ctx* ctx, int narr, ZArgs a)
   a.tw      = f.tw[2];
   a.divider = c.fft_divider;
   a.nxc     = f.nxm;
+  // 2-D (Nz == 1): the "z" pass runs along y — the y-derivative is the one along the line, there is no third array
+  a.axis_of[0] = 0; a.axis_of[1] = f.two_d ? 2u : 1u; a.axis_of[2] = 2;
+  if (f.two_d) a.dd[2] = a.dd[1]; // ... whose derivative vector is ddy
   a.side_off    = f.side_off;
   a.op_side_off = f.side_off; // the imported operators hold the side column's values behind the P * ny * nz of the row tiles
   const uint32_t side_tile = (f.side_off != 0) ? 1u : 0u;
@@ -2158,6 +2162,7 @@ kw_status forward_xy(kw_ctx* ctx, int narr, const float* const* in, int s0 = 0)
   }
   if (in != nullptr) KW_TRY(launch_xfwd(ctx, narr, in, f.s + s0)); // nullptr: x-spectra were chained into S[] already
   else if (y_done >= s0 + narr) return KW_OK;                      // ... and so was their y-pass (chunked producer)
+  if (f.two_d) return KW_OK;                                        // the y transform is inside the fused pass
   if (!f.slab) return launch_ypass(ctx, -1, narr, f.s + s0, f.s + s0, false, false);
   KW_TRY(launch_ypass(ctx, -1, narr, f.s + s0, f.t + s0, false, true));
   for (int i = 0; i < narr; i++) KW_TRY(xstart(ctx, s0 + i, f.t[s0 + i], f.s[s0 + i]));
@@ -2196,6 +2201,11 @@ template<int EPI, bool CHAIN> kw_status gradient_tail(kw_ctx* ctx, XinvArgs x, c
 {
   auto& f = ctx->fused;
   x.mulx[0] = ddx;
+  if (f.two_d)
+  { // 2-D: the fused pass along y left Q in S[0] (d/dx: x ddx(kx) in the x-inverse) and G_y in S[2]; two components
+    x.in[1] = f.s[2];
+    return launch_xinv<EPI, CHAIN>(ctx, 2, x);
+  }
   const float2* mul[3] = { ddy, nullptr, nullptr };
   if (f.slab && f.pipelined && f.xbatch)
   { // small messages: Q and G_z come back in one exchange, one multi-array launch per pass, one exchange forward
@@ -2276,6 +2286,7 @@ template<int EPI, bool CHAIN> kw_status gradient_tail(kw_ctx* ctx, XinvArgs x, c
 kw_status inverse_y(kw_ctx* ctx, int narr, int s0 = 0)
 {
   auto& f = ctx->fused;
+  if (f.two_d) return KW_OK;
   if (!f.slab) return launch_ypass(ctx, +1, narr, f.s + s0, f.s + s0, false, false);
   if (f.pipelined)
   { // whole arrays: r[] -> t[] -> y-inverse into s[]
@@ -2339,13 +2350,19 @@ kw_status create_impl(kw_ctx* ctx, void* const s[3], void* const t[3])
   const kw_constants& c = ctx->c;
   f.nz_global = (f.slab) ? slab.nz_global : c.nz;
   f.nyl       = c.ny / f.nranks;
+  f.two_d     = (!f.slab && c.nz == 1);
+  if (f.two_d)
+  { // 2-D: the z-pass kernels run along y — one "row" per plane, lines of Ny elements with stride P
+    f.nz_global = c.ny;
+    f.nyl       = 1;
+  }
   f.Palloc    = (c.nx_complex + NLMAX - 1) / NLMAX * NLMAX;
   {
     // x-Nyquist column apart (see tile_coord) whenever it is the one bin beyond whole tiles.  On slabs the exchange then
     // moves two pieces per peer — the row chunk [nz local][nyl][Nx/2] and the side chunk [nz local][nyl] — i.e. exactly
     // the Nx/2 + 1 bins per row, in aligned rows.  KW_FUSED_SIDE=0 keeps the column in the (padded) rows (A/B).
     const char* e   = getenv("KW_FUSED_SIDE");
-    const bool side = (e == nullptr || e[0] != '0') && (c.nx_complex % NLMAX == 1u) && (c.nx_complex > NLMAX);
+    const bool side = (e == nullptr || e[0] != '0') && (c.nx_complex % NLMAX == 1u) && (c.nx_complex > NLMAX) && !f.two_d;
     f.nxm      = side ? c.nx_complex - 1u : c.nx_complex;
     f.P        = side ? f.nxm : f.Palloc;
     f.side_off = side ? f.P * c.ny * c.nz : 0u;
@@ -2507,6 +2524,7 @@ kw_status kw_fused_supported(kw_ctx* ctx, int* out)
   const uint32_t nzg    = (f.slab) ? f.nz_global : c.nz;
   // (the x kernels work on tiles of 2 * NL rows; a row count Ny * Nz that is no whole number of tiles ends in one masked tile)
   bool ok = supported_len(c.nx) && supported_len(c.ny) && supported_len(nzg);
+  if (!f.slab && c.nz == 1) ok = supported_len(c.nx) && supported_len(c.ny); // 2-D: x-pass, fused y-pass, x-pass
   if (f.slab) ok = ok && (nzg == c.nz * f.nranks) && (c.ny % f.nranks == 0);
   const uint64_t P64 = (c.nx_complex + NLMAX - 1) / NLMAX * NLMAX;
   ok = ok && (P64 * c.ny * c.nz < (1ull << 32)) && (static_cast<uint64_t>(c.nx) * c.ny * c.nz < (1ull << 32));
@@ -2676,6 +2694,9 @@ kw_status kw_fused_density(kw_ctx* ctx, int nonlinear, const float* ux, const fl
   for (int i = 0; i < 3; i++) { z.in[i] = S[i]; z.out[i] = S[i]; }
   z.op[0] = kappa_padded;
   z.dd[0] = (const float2*)ddx; z.dd[1] = (const float2*)ddy; z.dd[2] = (const float2*)ddz;
+  // 2-D: u_z is identically zero; its spectrum travels as zeros (chained stages leave G_y of the velocity stage in S[2])
+  if (ctx->fused.two_d && u_in_scratch)
+    KW_HIP(hipMemsetAsync(S[2], 0, static_cast<size_t>(ctx->fused.Palloc) * ctx->c.ny * sizeof(float2), ctx->stream));
   if (ctx->fused.slab)
   {
     KW_TRY(slab_chain<Z_VGRAD>(ctx, 3, u_in_scratch ? nullptr : in3, z));
@@ -2695,7 +2716,7 @@ kw_status kw_fused_density(kw_ctx* ctx, int nonlinear, const float* ux, const fl
     KW_TRY(forward_xy(ctx, 3, u_in_scratch ? nullptr : in3));
     KW_TRY(launch_zfused<Z_VGRAD>(ctx, 3, z));
   }
-  const bool tail_chunked = (!ctx->fused.slab && !ctx->fused.per_array);
+  const bool tail_chunked = (!ctx->fused.slab && !ctx->fused.per_array && !ctx->fused.two_d);
   XinvArgs x{};
   float* rho[3] = { rx, ry, rz };
   const float* pml[3] = { pmlx, pmly, pmlz };
@@ -2752,6 +2773,8 @@ kw_status kw_fused_velocity_gradient(kw_ctx* ctx, const float* ux, const float* 
   for (int i = 0; i < 3; i++) { z.in[i] = S[i]; z.out[i] = S[i]; }
   z.op[0] = kappa_padded;
   z.dd[0] = (const float2*)ddx; z.dd[1] = (const float2*)ddy; z.dd[2] = (const float2*)ddz;
+  if (ctx->fused.two_d && u_in_scratch)
+    KW_HIP(hipMemsetAsync(S[2], 0, static_cast<size_t>(ctx->fused.Palloc) * ctx->c.ny * sizeof(float2), ctx->stream));
   if (ctx->fused.slab) KW_TRY(slab_chain<Z_VGRAD>(ctx, 3, u_in_scratch ? nullptr : in3, z));
   else
   {
@@ -2809,7 +2832,7 @@ kw_status kw_fused_absorption_pressure(kw_ctx* ctx, float* p, const float* vel_g
   x.m0[0] = first; x.m0[1] = c2;
   x.m1[0] = tau;   x.m1[1] = eta;
   x.fout[0] = S[0]; // chained: x-spectrum of the new p
-  if (!ctx->fused.slab && !ctx->fused.per_array)
+  if (!ctx->fused.slab && !ctx->fused.per_array && !ctx->fused.two_d)
   {
     if (chain_p) KW_TRY((plane_local_tail<EPI_PSUM, true>(ctx, 2, 1, x, 1)));
     else KW_TRY((plane_local_tail<EPI_PSUM, false>(ctx, 2, 1, x, 0)));

@@ -71,6 +71,7 @@ struct kw_ctx
     // spectra (forward receive = z-pass in / out = backward send), so that the plane-local tail of a stage — backward
     // receive t[] -> y-inverse -> s[] -> x-inverse + epilogue -> chained x / y forward -> t[] -> forward send — runs per
     // chunk of planes while the other chunks are on the wire.
+    bool     two_d = false;                        // Nz == 1: x-pass, fused pass along y (in the z-pass kernels' role), x-pass; no y-pass
     bool     pipelined = false;
     uint32_t xchunks   = 1;                        // plane chunks per array of the pipelined tail
     float2*  r[3]      = {nullptr, nullptr, nullptr};

@@ -66,10 +66,13 @@ def test_oracle_2d_c_vs_numpy(orc, syn, kw):
     dict(heterogeneous=True, nonlinear=True, absorbing=False, source="p_source", source_mode=2),
     dict(heterogeneous=True, nonlinear=True, absorbing=True, source="u_source", source_mode=0),
 ])
-def test_gpu_2d_matches_oracle(orc, syn, kw):
+@pytest.mark.parametrize("fused", [True, False])
+def test_gpu_2d_matches_oracle(orc, syn, kw, fused):
+    """fused: x-pass, fused pass along y (forward y transform, spectral multiply, inverse y transform in one kernel),
+    x-inverse + epilogue; not fused: rocFFT + one kernel per reference kernel"""
     from kwave_amd.solver import HostSolver
     pr = problem2d(syn, **kw)
-    g = HostSolver(pr, p_raw=1, p_max=1, u_raw=1, u_rms=1, p_final=1)
+    g = HostSolver(pr, p_raw=1, p_max=1, u_raw=1, u_rms=1, p_final=1, fused_kernels=fused)
     o = orc.OracleSim(pr)
     series = []
     for _ in range(30):
@@ -159,3 +162,20 @@ def test_gpu_2d_from_file(syn, tmp_path):
         h5io.dataset_info(path_out, "uz_final")
     fs.close()
     mem.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dims", [(256, 512), (500, 240), (100, 72), (1024, 16)])
+def test_gpu_2d_fused_pass_on_other_line_lengths(orc, syn, dims):
+    """the fused 2-D pipeline on 512-point y lines (2 x 256 split kernels), mixed-radix lengths and a masked last x tile"""
+    from kwave_amd.solver import HostSolver
+    pr = problem2d(syn, dims[0], dims[1], heterogeneous=True, nonlinear=True, absorbing=True, source="p0", nt=16)
+    g = HostSolver(pr, p_raw=1)
+    o = orc.OracleSim(pr)
+    o.step(14)
+    g.run(14)
+    for f in ("p", "ux", "uy", "rhox", "rhoy"):
+        assert rel_l2(g.field(f), o.field(f)) < TOL, (f, dims)
+    assert not g.field("uz").any() and not g.field("rhoz").any()
+    g.close()
+    o.close()
