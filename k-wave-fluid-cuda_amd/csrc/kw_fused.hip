@@ -2106,8 +2106,19 @@ kw_status pslab_tail(kw_ctx* ctx, int narr, int ncomp, const XinvArgs& x, int nc
   const uint32_t C = f.xchunks, nzc = ctx->c.nz / C;
   for (uint32_t c = 0; c < C; c++)
   {
-    for (int a = 0; a < narr; a++) KW_TRY(pwait(ctx, X_BACK, a, static_cast<int>(c)));
-    KW_TRY(launch_ypass(ctx, +1, narr, f.t, f.s, true, false, c * nzc, nzc));
+    if (f.xbatch || narr == 1 || !f.tail_per_array)
+    {
+      for (int a = 0; a < narr; a++) KW_TRY(pwait(ctx, X_BACK, a, static_cast<int>(c)));
+      KW_TRY(launch_ypass(ctx, +1, narr, f.t, f.s, true, false, c * nzc, nzc));
+    }
+    else
+    { // every array's y-inverse as soon as that array is back: only the last one stays between the wire and the epilogue
+      for (int a = 0; a < narr; a++)
+      {
+        KW_TRY(pwait(ctx, X_BACK, a, static_cast<int>(c)));
+        KW_TRY(launch_ypass(ctx, +1, 1, f.t + a, f.s + a, true, false, c * nzc, nzc));
+      }
+    }
     KW_TRY((launch_xinv<EPI, CHAIN, TERMS>(ctx, ncomp, x, c * nzc, nzc)));
     if (CHAIN)
     {
@@ -2394,6 +2405,8 @@ kw_status create_impl(kw_ctx* ctx, void* const s[3], void* const t[3])
     f.xchunks = f.pipelined ? nch : 1u;
     // Below 4 MB per peer and array the exchanges are latency- and launch-bound: all arrays of a stage then travel in
     // one exchange per direction (6 per step instead of 13) and the passes run as multi-array launches.  KW_SLAB_BATCH=0/1.
+    const char* et = getenv("KW_SLAB_TAIL_PER_ARRAY");
+    f.tail_per_array = !(et != nullptr && et[0] == '0');
     const char* eb = getenv("KW_SLAB_BATCH");
     const size_t per_peer = static_cast<size_t>(c.nz) * f.nyl * c.nx_complex * sizeof(float2);
     f.xbatch = f.pipelined && ((eb != nullptr) ? (eb[0] == '1') : (per_peer < (4u << 20)));

@@ -76,6 +76,7 @@ struct kw_ctx
     uint32_t xchunks   = 1;                        // plane chunks per array of the pipelined tail
     float2*  r[3]      = {nullptr, nullptr, nullptr};
     int      fwd_ahead = 0;                        // arrays whose forward exchange into r[] was started by the producer's tail
+    bool     tail_per_array = true;                // pipelined tail: one y-inverse launch per array, as each comes back (A/B: KW_SLAB_TAIL_PER_ARRAY=0)
     bool     xbatch    = false;                    // small messages: all arrays of a stage travel in ONE exchange per direction
     int8_t   xslot[2][3][KW_XCHUNKS_MAX] = {};     // [dir][array][chunk] -> slot of the started exchange that carries it, -1 none
     bool     slot_waited[KW_COMM_SLOTS] = {};      // the compute stream already waits for that exchange

@@ -16,7 +16,8 @@
 //   the launching thread   MOCK_GROUP_HOST_US  (default 44: what an RCCL group was measured to cost),
 //   the communication stream   a delay of  latency + (bytes to the busiest peer) / MOCK_LINK_GBS  (default 10 us, 60 GB/s:
 //                              every peer has its own xGMI link, so the links run in parallel), then
-//   local HBM              one device copy of what the rank sends (a real transfer also reads and writes it locally).
+//   local HBM              one device copy of what the rank sends (a real transfer also reads and writes it locally,
+//                              while the links are busy: the delay is shortened by the copy's expected duration).
 // A timeline of one rank's kernels against modelled wire time — for choosing between the slab schedules, not a result.
 #include <hip/hip_runtime.h>
 
@@ -95,6 +96,17 @@ ncclResult_t flush_emulated(const std::vector<Op>& ops)
   for (const auto& kv : to_peer) busiest = kv.second > busiest ? kv.second : busiest;
   double wire_us = (busiest == 0) ? 0.0 : latency_us + static_cast<double>(busiest) / (link_gbs * 1e3);
   if (wire_us > 20000.0) wire_us = 20000.0;
+  // on a node the transfer's local reads and writes happen WHILE the links are busy; here they are a device copy
+  // behind the delay on the same stream: the delay is shortened by the copy's expected duration (2 bytes moved per
+  // byte sent at ~4 TB/s) so that delay + copy models the transfer (MOCK_COPY_SERIAL=1: plain sum, pessimistic)
+  static const bool serial = getenv("MOCK_COPY_SERIAL") != nullptr && getenv("MOCK_COPY_SERIAL")[0] == '1';
+  if (!serial && wire_us > 0.0)
+  {
+    size_t sent = 0;
+    for (const Op& o : ops) if (o.send) sent += o.bytes;
+    const double copy_us = 2.0 * static_cast<double>(sent) / 4.0e6;
+    wire_us = (wire_us - copy_us > latency_us) ? wire_us - copy_us : latency_us;
+  }
   hipStream_t stream = ops[0].stream;
   if (wire_us > 0.0)
     hipLaunchKernelGGL(k_wire_delay, dim3(1), dim3(1), 0, stream, static_cast<unsigned long long>(wire_us * clock_khz / 1000.0));
