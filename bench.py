@@ -196,7 +196,10 @@ def run_distributed(args):
 
     The data path is the device library's own RCCL exchange (--exchange native: kw_comm_init, ncclSend/ncclRecv groups
     on a communication stream); the process group (gloo) only carries the communicator id, the barriers and the
-    max-over-ranks of the timings.  --exchange torch: torch.distributed.all_to_all_single as a callback (nccl group)."""
+    max-over-ranks of the timings.  The same grids are then timed over the library's device-initiated transport
+    (kw_comm_init_p2p: mapped peer buffers, one store kernel per exchange) and reported beside it in config.p2p — a
+    failure there is reported, not fatal.  --exchange p2p: that transport only (ranks may share a GPU: rehearsal on a
+    one-GPU box).  --exchange torch: torch.distributed.all_to_all_single as a callback (nccl group)."""
     # the process-group and RCCL libraries print banners on stdout: everything but the result line goes to stderr
     sys.stdout.flush()
     result_fd = os.dup(1)
@@ -223,20 +226,22 @@ def run_distributed(args):
         dist.all_reduce(t, op=op)
         return float(t.item())
 
-    def open_solver(loc, nz):
+    def open_solver(loc, nz, exchange=None):
         """DistSolver on every rank with the same transport.  If the device library's communicator cannot be created
         on some rank (say, an RCCL build the library cannot bind), ALL ranks move to torch.distributed's RCCL group as
         the callback transport — still RCCL over xGMI, still the HIP pipeline; the line reports which one ran."""
         sim, err = None, None
+        extra = {"rccl_library": args.rccl_library} if (args.rccl_library and (exchange or state["exchange"]) == "native") else {}
         try:
-            sim = DistSolver(loc, rank, world, nz, device_index=local_rank, exchange=state["exchange"], p_raw=1, p_max=1)
+            sim = DistSolver(loc, rank, world, nz, device_index=local_rank, exchange=exchange or state["exchange"], p_raw=1, p_max=1,
+                             **extra)
         except Exception as e:  # noqa: BLE001 - decided collectively below
             err = e
         if reduce(0.0 if err is not None else 1.0, dist.ReduceOp.MIN) > 0.5:
             return sim
         if sim is not None:
             sim.close()
-        if state["exchange"] != "native":
+        if exchange is not None or state["exchange"] != "native":
             raise err if err is not None else RuntimeError("slab solver could not be created on another rank")
         print(f"[bench rank {rank}] native RCCL exchange unavailable ({err!r}); using the torch.distributed transport",
               file=sys.stderr, flush=True)
@@ -246,7 +251,7 @@ def run_distributed(args):
         dist.init_process_group("nccl")
         return DistSolver(loc, rank, world, nz, device_index=local_rank, exchange="torch", p_raw=1, p_max=1)
 
-    def slab_run(grid, k, w):
+    def slab_run(grid, k, w, exchange=None):
         """k timed steps of the config-3 workload on `grid`, Z-slabs over all ranks; (seconds, exchanges per step)"""
         nx, ny, nz = grid
         z0, z1 = slab_range(nz, rank, world)
@@ -254,16 +259,33 @@ def run_distributed(args):
                                     nt=w + k + 8, zslab=(z0, z1))
         loc, _ = partition_problem(pr, rank, world, arrays_are_local=True)
         del pr
-        sim = open_solver(loc, nz)
-        sim.run(w)
-        sim.sync()
-        torch.cuda.synchronize()
+        sim = open_solver(loc, nz, exchange)
+
+        def together(fn):
+            """fn() on every rank, then agreement: a rank whose exchange failed (a transport time-out, say) must not leave
+            the others alone in the next collective of the process group"""
+            err = None
+            try:
+                fn()
+            except Exception as e:  # noqa: BLE001
+                err = e
+            if reduce(0.0 if err is not None else 1.0, dist.ReduceOp.MIN) < 0.5:
+                sim.close()
+                raise err if err is not None else RuntimeError("the slab run failed on another rank")
+
+        together(lambda: (sim.run(w), sim.sync(), torch.cuda.synchronize()))
         dist.barrier()
-        t0 = time.perf_counter()
-        sim.run(k)
-        sim.sync()
-        torch.cuda.synchronize()
-        sec = reduce(time.perf_counter() - t0, dist.ReduceOp.MAX)
+        took = {}
+
+        def timed():
+            t0 = time.perf_counter()
+            sim.run(k)
+            sim.sync()
+            torch.cuda.synchronize()
+            took["sec"] = time.perf_counter() - t0
+
+        together(timed)
+        sec = reduce(took["sec"], dist.ReduceOp.MAX)
         dist.barrier()
         per_step = sim.exchanges // max(k + w, 1)
         sim.close()
@@ -271,14 +293,15 @@ def run_distributed(args):
 
     def schedule_of(grid):
         """which slab schedule the device library picks for this grid (the rules of kw_fused.hip's create_impl)"""
+        from kwave_amd import capi
         nx, ny, nz = grid
-        if state["exchange"] != "native" or os.environ.get("KW_SLAB_PIPELINE", "1")[:1] == "0":
-            return "whole-array exchanges, per-array pipelining (callback transport or KW_SLAB_PIPELINE=0)"
+        tn = capi.make_tuning()  # the defaults (+ KW_TUNING, which HostSolver applies the same way)
+        if state["exchange"] not in ("native", "p2p") or not tn.slab_pipeline:
+            return "whole-array exchanges, per-array pipelining (callback transport or slab_pipeline=0)"
         per_peer = (nz // world) * (ny // world) * (nx // 2 + 1) * 8
-        batch = os.environ.get("KW_SLAB_BATCH")
-        if (batch[:1] == "1") if batch else (per_peer < (4 << 20)):
+        if (tn.slab_batch == 1) if tn.slab_batch >= 0 else (per_peer < (4 << 20)):
             return f"batched: one exchange per stage and direction ({per_peer / 2 ** 20:.1f} MiB per peer and array)"
-        chunks = max(1, int(os.environ.get("KW_SLAB_CHUNKS", "1") or 1))
+        chunks = max(1, int(tn.slab_chunks))
         return (f"per-array pipelining, forward transposes started by the producing stage, "
                 f"{'whole-array exchanges' if chunks == 1 else str(chunks) + ' plane chunks'} "
                 f"({per_peer / 2 ** 20:.1f} MiB per peer and array)")
@@ -306,6 +329,20 @@ def run_distributed(args):
     sec, ex = slab_run(grid, K, W)
     nx, ny, nz = grid
     global_rate = K / sec
+    # the same grids over the device-initiated transport, beside the default's numbers (never instead of them)
+    p2p = None
+    if state["exchange"] == "native" and state["fallback"] is None and not args.no_p2p:
+        p2p = {"transport": "kw_comm_init_p2p: mapped peer buffers (hipIpc), one store kernel per exchange on the communication stream"}
+        try:
+            sec_p, ex_p = slab_run(grid, K, W, exchange="p2p")
+            p2p.update(steps_per_s=round(K / sec_p, 2), ms_per_step=round(1e3 * sec_p / K, 4), exchanges_per_step=ex_p)
+            if c4 is not None:
+                sec5p, _ = slab_run((512, 512, 512), c4["steps"], c4["warmup"], exchange="p2p")
+                p2p["c4_512_steps_per_s"] = round(c4["steps"] / sec5p, 3)
+                if c4["steps_per_s_1gpu"]:
+                    p2p["c4_512_speedup_vs_1gpu"] = round(c4["steps"] / sec5p / c4["steps_per_s_1gpu"], 3)
+        except Exception as e:  # noqa: BLE001 - reported in the line
+            p2p["error"] = repr(e)[:400]
     if rank == 0:
         b_step, _ = alg_bytes(256)
         voxels = nx * ny * nz
@@ -320,7 +357,9 @@ def run_distributed(args):
                                       f"({voxels // world} voxels per GPU), one all-to-all transpose per 3-D FFT",
                           "grid": [nx, ny, nz], "parallelism": f"zslab{world}",
                           "exchange": "RCCL inside libkwave_hip.so (ncclSend/ncclRecv groups on a communication stream)"
-                          if state["exchange"] == "native" else "torch.distributed.all_to_all_single (RCCL) callback",
+                          if state["exchange"] == "native" else
+                          "P2P inside libkwave_hip.so (mapped peer buffers, one store kernel per exchange on a communication stream)"
+                          if state["exchange"] == "p2p" else "torch.distributed.all_to_all_single (RCCL) callback",
                           "exchange_fallback": state["fallback"],
                           "global_steps_per_s": round(global_rate, 2),
                           "value_definition": "N x global time-steps/s (each GPU owns one 256^3-voxel block)" if args.weak
@@ -331,6 +370,8 @@ def run_distributed(args):
                             "frac": round(b_global / (sec / K) / 1e9 / (HBM_PEAK_GBS * world), 4), "traffic": None}}
         if c4 is not None:
             out["config"]["c4_512"] = c4
+        if p2p is not None:
+            out["config"]["p2p"] = p2p
         sys.stdout.flush()
         os.write(result_fd, (json.dumps(out) + "\n").encode())
     dist.destroy_process_group()
@@ -349,7 +390,9 @@ def main():
     ap.add_argument("--strong", action="store_true", help="N>1: one fixed --size^3 grid (default 512) only")
     ap.add_argument("--weak", action="store_true", help="N>1: 256^3 voxels per GPU (256x256x512 / 256x512x512 / 512^3)")
     ap.add_argument("--no-512", action="store_true", help="N>1: skip the config-4 (512^3) block of the line")
-    ap.add_argument("--exchange", default=os.environ.get("KW_EXCHANGE", "native"), choices=("native", "torch"),
+    ap.add_argument("--no-p2p", action="store_true", help="N>1: skip the P2P-transport leg of the line")
+    ap.add_argument("--rccl-library", default=None, help="N>1: library the device layer's RCCL binding loads (default search otherwise)")
+    ap.add_argument("--exchange", default=os.environ.get("KW_EXCHANGE", "native"), choices=("native", "p2p", "torch"),
                     help="N>1 data path: the device library's own RCCL exchange, or torch.distributed as a callback")
     ap.add_argument("--slab-selftest", action="store_true",
                     help="one rank through the N>1 code path (slab kernels + RCCL all-to-all with itself): rehearsal on a 1-GPU box")

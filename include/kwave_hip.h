@@ -106,6 +106,30 @@ KW_API kw_status   kw_device_info_get(kw_ctx* ctx, kw_device_info* out);
 KW_API kw_status   kw_set_stream(kw_ctx* ctx, void* hip_stream);
 KW_API void*       kw_get_stream(kw_ctx* ctx);
 KW_API kw_status   kw_sync(kw_ctx* ctx);
+/* Schedule parameters of the fused pipeline and of the multi-GPU exchange — every switch the library has, in one
+ * documented place (the library reads no environment variable).  kw_get_tuning returns the current values (the defaults
+ * after kw_init); kw_set_tuning takes effect at the next kw_fused_create.  struct_bytes = sizeof(kw_tuning) of the
+ * caller, so that the struct can grow: fields beyond it keep their defaults. */
+typedef struct kw_tuning
+{
+  uint32_t struct_bytes;
+  int32_t  side_array;          /* 1: x-Nyquist bins of an even-Nx grid live in a compact side array behind rows of
+                                   exactly Nx/2 bins; 0: in the rows, padded to whole 16-bin tiles */
+  int32_t  tail_chunks;         /* single GPU: the plane-local tail of a stage (y-inverse, x-inverse + epilogue, chained
+                                   x / y forward) runs per chunk of planes so that a chunk's spectra stay in the
+                                   Infinity Cache between those kernels; 0 = automatic (1 when all three scratch arrays
+                                   fit the cache anyway), n >= 1 = that many chunks */
+  int32_t  split512;            /* 1: 512-point y / z lines as 2 x 256-point transforms; 0: 16 x 32-point kernels */
+  int32_t  slab_pipeline;       /* 1: pipelined slab schedule (third buffer set, forward transposes started by the
+                                   producing stage); 0: whole-array schedule */
+  int32_t  slab_chunks;         /* plane chunks per array of the pipelined slab tail (1..4) */
+  int32_t  slab_batch;          /* all arrays of a stage in ONE exchange per direction: -1 automatic (below 4 MB per
+                                   peer and array), 0 never, 1 always */
+  int32_t  p2p_blocks_per_peer; /* P2P transport: workgroups that store to one peer (1..8) */
+  float    p2p_timeout_s;       /* P2P transport: a rank that waits longer than this for a peer gives up (KW_ERR_COMM) */
+} kw_tuning;
+KW_API kw_status   kw_get_tuning(kw_ctx* ctx, kw_tuning* out);
+KW_API kw_status   kw_set_tuning(kw_ctx* ctx, const kw_tuning* tuning);
 /* Launch-bound loops (small grids): record the launches of a fixed sequence of kw_* calls once, replay it per step.
  * kw_graph_begin puts the context's stream into capture mode (nothing executes until the graph is launched);
  * every kw_* call in between must be a pure kernel-launch call (no allocation, copy or synchronisation). */
@@ -301,6 +325,34 @@ KW_API kw_status kw_comm_unique_id(void* out_id, size_t bytes);  /* ncclGetUniqu
 KW_API kw_status kw_comm_init(kw_ctx* ctx, uint32_t nranks, uint32_t rank, const void* unique_id);
 KW_API kw_status kw_comm_destroy(kw_ctx* ctx);                    /* also done by kw_destroy */
 KW_API kw_status kw_comm_info(kw_ctx* ctx, uint32_t* nranks, uint32_t* rank, uint64_t* exchanges_started);
+/* the same two calls with the RCCL library named by the caller (a path or soname for dlopen; NULL = the default search:
+ * the process's own librccl.so.1, then ROCm's) — e.g. a site build of RCCL, or a test double */
+KW_API kw_status kw_comm_unique_id_from(const char* rccl_library, void* out_id, size_t bytes);
+KW_API kw_status kw_comm_init_with(kw_ctx* ctx, const char* rccl_library, uint32_t nranks, uint32_t rank, const void* unique_id);
+/* Device-initiated transport ("P2P"): the ranks map each other's exchange buffers — hipIpc handles between the
+ * processes of one node, plain pointers between threads of one process — and every exchange is ONE small kernel on the
+ * communication stream that stores this rank's chunks straight into the peers' receive buffers over xGMI, with a
+ * credit / full flag rendezvous per peer (csrc/kw_comm.hip k_p2p_exchange).  Same split-phase contract and the same
+ * schedules as the RCCL path; what it removes is the per-exchange fixed cost of a library group (launching thread and
+ * communication kernel), which is what bounds small and chunked exchanges.  Single node.  Call order on every rank:
+ *   kw_comm_init_p2p(ctx, nranks, rank)                 (with or without a prior kw_comm_init)
+ *   kw_fused_set_slab(ctx, nranks, rank, nz_global, NULL, NULL);  kw_fused_create(ctx)
+ *   kw_comm_p2p_export(ctx, blob, KW_COMM_P2P_BLOB_BYTES)          what this rank publishes: plain bytes
+ *   < the caller gathers the blobs of all ranks, in rank order, by any means it has: MPI, a torch.distributed store,
+ *     files — all_blobs = nranks * KW_COMM_P2P_BLOB_BYTES bytes, the same on every rank >
+ *   kw_comm_p2p_connect(ctx, all_blobs)                  maps the peers' buffers; exchanges go P2P from here on
+ * A rank that waits longer than kw_tuning::p2p_timeout_s for a peer stops waiting: the next exchange (or kw_sync of the
+ * step loop) returns KW_ERR_COMM — a lost peer ends the run, it does not hang the GPU queue. */
+#define KW_COMM_P2P_BLOB_BYTES 1024
+KW_API kw_status kw_comm_init_p2p(kw_ctx* ctx, uint32_t nranks, uint32_t rank);
+KW_API kw_status kw_comm_p2p_export(kw_ctx* ctx, void* blob, size_t bytes);
+KW_API kw_status kw_comm_p2p_connect(kw_ctx* ctx, const void* all_blobs);
+/* Link model for schedule studies on a one-GPU machine (tools/emulate_rank.py): ONE rank of an nranks run alone on the
+ * GPU — the chunks for the absent peers are copied locally and every peer's transfer is held for latency_us +
+ * bytes / link_gbs, as a link of that rate would.  In place of export / connect.  Results are not a simulation's. */
+KW_API kw_status kw_comm_p2p_emulate(kw_ctx* ctx, float link_gbs, float latency_us);
+/* -1 no communicator, 0 RCCL, 1 P2P not yet connected, 2 P2P, 3 P2P link model */
+KW_API kw_status kw_comm_transport(kw_ctx* ctx, int* out_transport);
 /* Override: a caller that owns its own communicator passes exchange(user, send, recv, bytes_per_peer), which must be
  * ordered after all prior work on the context's stream and complete (or stream-ordered) before it returns — e.g.
  * torch.distributed.all_to_all_single, or a host-staged all-to-all when several ranks share one GPU (tests).  The

@@ -71,7 +71,21 @@ typedef struct kwh_options
   void*    exchange_piece_fn; /* optional kw_exchange_piece_fn (strided pieces; exchange_wait_fn, if set, is its wait):
                                  a caller-owned transport that lets the pipeline run its pipelined slab schedule.
                                  Give exchange_fn as well (used when the pipeline is told not to pipeline). */
+  const void* tuning;         /* optional const kw_tuning* (kwave_hip.h): schedule parameters of the device library */
+  int32_t  step_graph;        /* 1: replay the steady-state step from a recorded graph (launch-bound small grids; measured
+                                 3-5 % slower than eager launches at 64^3 / 128^3, hence off by default) */
+  int32_t  comm_p2p;          /* 1: slab exchange over the device library's P2P transport (kw_comm_init_p2p: mapped peer
+                                 buffers, one store kernel per exchange) instead of RCCL groups; needs comm_allgather_fn.
+                                 With comm_unique_id as well, the RCCL communicator is created first and stays behind it. */
+  void*    comm_allgather_fn; /* kwh_allgather_fn: how the ranks trade their kw_comm_p2p_export blobs */
+  void*    comm_allgather_user;
+  const char* rccl_library;   /* optional library name / path for the RCCL binding (kw_comm_init_with); NULL = default */
+  float    p2p_emulate_link_gbs;   /* > 0 with comm_p2p: link model instead of peers (kw_comm_p2p_emulate; schedule studies */
+  float    p2p_emulate_latency_us; /*   with ONE rank of slab_ranks on a one-GPU machine, tools/emulate_rank.py) */
 } kwh_options;
+/* gathers `bytes` bytes of every rank, in rank order, into all (nranks * bytes); the same result on every rank; 0 = ok.
+ * Any transport the launcher has will do: MPI_Allgather, torch.distributed.all_gather on a gloo group, files. */
+typedef int (*kwh_allgather_fn)(void* user, const void* mine, void* all, size_t bytes);
 
 KWH_API const char* kwh_last_error(void);
 KWH_API int      kwh_create(const kwh_dataset* datasets, size_t n_datasets, const kwh_options* options, kwh_solver** out);

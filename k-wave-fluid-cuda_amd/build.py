@@ -147,12 +147,13 @@ def build_native_drivers(force: bool = False) -> str:
     return SLAB_SELFTEST_BIN
 
 
-MOCK_RCCL_LIB = os.path.join(LIB_DIR, "libmock_rccl.so")
+MOCK_RCCL_LIB = os.path.join(ROOT, "tests", "native", "libmock_rccl.so")  # test infrastructure: not in the product's lib/
 
 
 def build_test_mocks(force: bool = False) -> str:
     """tests/native/mock_rccl.cpp: test infrastructure — a stand-in for librccl whose ranks are threads sharing one GPU
-    (KW_RCCL_LIB), so that the library's own exchange path can be driven with several ranks on a one-GPU box."""
+    (named through kw_comm_init_with by the test workers), so that the library's RCCL exchange path can be driven with
+    several ranks on a one-GPU box."""
     src = os.path.join(ROOT, "tests", "native", "mock_rccl.cpp")
     if not os.path.exists(src):
         return ""

@@ -131,6 +131,15 @@ _SIG: Dict[str, list] = {
     "kw_comm_init": [_P, C.c_uint32, C.c_uint32, _P],
     "kw_comm_destroy": [_P],
     "kw_comm_info": [_P, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)],
+    "kw_comm_unique_id_from": [C.c_char_p, _P, C.c_size_t],
+    "kw_comm_init_with": [_P, C.c_char_p, C.c_uint32, C.c_uint32, _P],
+    "kw_comm_init_p2p": [_P, C.c_uint32, C.c_uint32],
+    "kw_comm_p2p_export": [_P, _P, C.c_size_t],
+    "kw_comm_p2p_connect": [_P, _P],
+    "kw_comm_p2p_emulate": [_P, C.c_float, C.c_float],
+    "kw_comm_transport": [_P, C.POINTER(C.c_int)],
+    "kw_get_tuning": [_P, _P],
+    "kw_set_tuning": [_P, _P],
     "kw_fused_set_slab": [_P, C.c_uint32, C.c_uint32, C.c_uint32, _P, _P],
     "kw_fused_set_slab_async": [_P, _P, _P],
     "kw_fused_set_slab_pieces": [_P, _P, _P],
@@ -295,13 +304,49 @@ class Device:
 
 
 COMM_ID_BYTES = 128
+COMM_P2P_BLOB_BYTES = 1024
+TRANSPORTS = {-1: "none", 0: "rccl", 1: "p2p (not connected)", 2: "p2p", 3: "p2p link model"}
 
 
-def comm_unique_id() -> bytes:
+class Tuning(C.Structure):
+    """kw_tuning of include/kwave_hip.h: every schedule parameter of the device library"""
+    _fields_ = [("struct_bytes", C.c_uint32), ("side_array", C.c_int32), ("tail_chunks", C.c_int32), ("split512", C.c_int32),
+                ("slab_pipeline", C.c_int32), ("slab_chunks", C.c_int32), ("slab_batch", C.c_int32),
+                ("p2p_blocks_per_peer", C.c_int32), ("p2p_timeout_s", C.c_float)]
+
+
+def default_tuning() -> Tuning:
+    """the library's defaults (what a fresh context reports through kw_get_tuning)"""
+    return Tuning(C.sizeof(Tuning), 1, 0, 1, 1, 1, -1, 4, 20.0)
+
+
+def make_tuning(spec=None) -> Tuning:
+    """Tuning from a dict or a "key=value,key=value" string over the defaults; the KW_TUNING environment variable, read
+    HERE (tools' A/B scripts), is applied first — the library itself reads no environment."""
+    t = default_tuning()
+    for src in (os.environ.get("KW_TUNING"), spec):
+        if not src:
+            continue
+        items = src.items() if isinstance(src, dict) else (kv.split("=", 1) for kv in str(src).replace(" ", ",").split(",") if kv)
+        for k, v in items:
+            if k not in dict(Tuning._fields_) or k == "struct_bytes":
+                raise KWaveError(f"unknown tuning parameter {k!r}")
+            setattr(t, k, float(v) if k == "p2p_timeout_s" else int(v))
+    return t
+
+
+def comm_unique_id(rccl_library=None) -> bytes:
     """ncclGetUniqueId through the device library (kw_comm_unique_id): call on rank 0, hand the bytes to every rank."""
     buf = C.create_string_buffer(COMM_ID_BYTES)
-    check(load().kw_comm_unique_id(buf, COMM_ID_BYTES))
+    lib = rccl_library.encode() if rccl_library else None
+    check(load().kw_comm_unique_id_from(lib, buf, COMM_ID_BYTES))
     return buf.raw
+
+
+def comm_transport(ctx) -> str:
+    v = C.c_int()
+    check(load().kw_comm_transport(ctx, C.byref(v)))
+    return TRANSPORTS.get(v.value, str(v.value))
 
 
 def comm_exchanges(ctx) -> int:

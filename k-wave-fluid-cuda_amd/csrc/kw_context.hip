@@ -189,6 +189,27 @@ kw_status kw_sync(kw_ctx* ctx)
 {
   KW_CHECK_CTX(ctx);
   KW_HIP(hipStreamSynchronize(ctx->stream));
+  return kw_comm_check(ctx); // a P2P exchange that gave up waiting for a peer surfaces here (KW_ERR_COMM)
+}
+
+kw_status kw_get_tuning(kw_ctx* ctx, kw_tuning* out)
+{
+  KW_CHECK_CTX(ctx);
+  KW_REQUIRE(out != nullptr);
+  *out = ctx->tuning;
+  return KW_OK;
+}
+
+kw_status kw_set_tuning(kw_ctx* ctx, const kw_tuning* tuning)
+{
+  KW_CHECK_CTX(ctx);
+  KW_REQUIRE(tuning != nullptr && tuning->struct_bytes >= sizeof(uint32_t) && tuning->struct_bytes <= sizeof(kw_tuning));
+  kw_tuning t = ctx->tuning; // fields beyond the caller's struct keep their values
+  memcpy(&t, tuning, tuning->struct_bytes);
+  t.struct_bytes = static_cast<uint32_t>(sizeof(kw_tuning));
+  KW_REQUIRE(t.tail_chunks >= 0 && t.slab_chunks >= 1 && t.slab_chunks <= KW_XCHUNKS_MAX && t.slab_batch >= -1 && t.slab_batch <= 1);
+  KW_REQUIRE(t.p2p_blocks_per_peer >= 1 && t.p2p_blocks_per_peer <= 8 && t.p2p_timeout_s > 0.f);
+  ctx->tuning = t;
   return KW_OK;
 }
 

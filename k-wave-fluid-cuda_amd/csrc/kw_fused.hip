@@ -46,20 +46,14 @@ constexpr int NLMAX = 16; // widest tile: 16 complex = 128-B segments (also the 
 // x passes, rows per block = 2 * nl_x: 16 line pairs up to L = 384; 8 from L = 400 on, where the 20- to 32-point register
 // DFTs of the epilogue kernels need the VGPR budget of a small block (384^3 measured: 244 steps/s with 16, 235 with 8)
 constexpr int nl_x(int L) { return L >= 400 ? 8 : 16; }
-// y / z passes, columns per tile: 16 (128-B row segments).  500^3 measured with 8-column tiles (64-B segments) for the
-// long lines: y passes 1.5x, z-fused 1.25x slower.  KW_NLYZ_LONG: tile width of lines longer than 512 (LDS: 128 B * L).
-#ifndef KW_NLYZ_LONG
-#define KW_NLYZ_LONG 16
-#endif
-constexpr int nl_yz(int L) { return L > 512 ? KW_NLYZ_LONG : 16; }
+// y / z passes, columns per tile: 16 (128-B row segments) at every length.  500^3 measured with 8-column tiles (64-B
+// segments) for the long lines: y passes 1.5x, z-fused 1.25x slower.
+constexpr int nl_yz(int) { return 16; }
 
 constexpr int cmax(int a, int b) { return a > b ? a : b; }
 // 20- to 32-point register DFTs next to a multi-array epilogue want more than 256 VGPRs, which leaves ONE wave per SIMD
 // (nothing to hide a memory round trip behind): hold those kernels to the two-wave budget instead
-#ifndef KW_BIGL_WAVES
-#define KW_BIGL_WAVES 2
-#endif
-constexpr int big_line_waves(int L) { return L >= 400 ? KW_BIGL_WAVES : 1; }
+constexpr int big_line_waves(int L) { return L >= 400 ? 2 : 1; }
 // largest divisor of n that is <= want
 constexpr int gq_pick(int n, int want) { return (n % want == 0) ? want : gq_pick(n, want - 1); }
 
@@ -71,9 +65,8 @@ template<int L, int NLV = nl_yz(L)> struct Geo
   static constexpr int THREADS = NL * TPL;
   // y/z passes: LDS[k1][n2][c]; +16 complex per k1 block keeps the step-B reads conflict-free
   static constexpr int PADB    = NL;
-  static constexpr int SF      = R2 * NL + PADB; // stride per k1 (forward / standalone inverse)
-  static constexpr int SI      = R1 * NL + PADB; // stride per q1 (inverse started from registers)
-  static constexpr int LDSB    = cmax(R1 * SF, R2 * SI);
+  static constexpr int SF      = R2 * NL + PADB; // stride per k1 (forward and inverse use the same cells, see inverse_from_regs)
+  static constexpr int LDSB    = R1 * SF;
   // x passes: LDS[c][k1][n2] (pitch LP per line) aliased with a natural-order line buffer (pitch ZP)
   static constexpr int LP0  = R1 * (R2 + 1);
   static constexpr int LP   = LP0 + ((16 - LP0 % 32) + 32) % 32;
@@ -97,10 +90,8 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 
 // State and medium arrays are touched once per step and not again for a whole step (> 5 GB of traffic later): they are
 // streamed past the caches (non-temporal), which leaves the 256 MB Infinity Cache to the spectral scratch that the very
-// next kernel re-reads.  Measured: +5.4 % on the whole step (KW_TEMPORAL_STATE restores plain accesses for A/B); the
-// same for the reduced operators (+2.6 %).  Spectra stay on plain accesses: marking their last-use reads non-temporal
-// costs 0.6-2 % in every pass type.
-#ifndef KW_TEMPORAL_STATE
+// next kernel re-reads.  Measured: +5.4 % on the whole step against plain accesses; the same for the reduced operators
+// (+2.6 %).  Spectra stay on plain accesses: marking their last-use reads non-temporal costs 0.6-2 % in every pass type.
 typedef float v4f __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ float4 ld4(const float* p)
 {
@@ -113,22 +104,14 @@ __device__ __forceinline__ void st4(float* p, const float4& v)
   __builtin_nontemporal_store(t, reinterpret_cast<v4f*>(p));
 }
 __device__ __forceinline__ float ldop(const float* p) { return __builtin_nontemporal_load(p); }
-#else
-__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
-__device__ __forceinline__ void   st4(float* p, const float4& v) { *reinterpret_cast<float4*>(p) = v; }
-__device__ __forceinline__ float  ldop(const float* p) { return *p; }
-#endif
 #define LDOP(p) ldop(p) // reduced real operators (kappa, nabla): one or two reads per step each (+2.6 % measured)
 
 // Reduced operators are stored for the z-pass that consumes them: [ky][kx tile of 16][q][j][c][V] — thread (c, j) of the
 // block owning that tile finds the values of ITS bins (kz = j + R1*k2, k2 = q*V + r; 2 x 256 split lines: kz = 2j + h +
 // 2*R1*k2 with run index 2*k2 + h) as RUN / V vectors of V floats, and the 64 lanes of a wave read one contiguous
 // 64 * V * 4-byte piece per load instruction.  V = 4 when the per-thread run length allows, else 2 or 1 (V = 1 is
-// plain [kz][c] order).  KW_OPVEC=0 forces V = 1 (A/B).
-#ifndef KW_OPVEC
-#define KW_OPVEC 1
-#endif
-constexpr int op_vec(int run) { return !KW_OPVEC ? 1 : (run % 4 == 0) ? 4 : (run % 2 == 0) ? 2 : 1; }
+// plain [kz][c] order).
+constexpr int op_vec(int run) { return (run % 4 == 0) ? 4 : (run % 2 == 0) ? 2 : 1; }
 template<int RUN, int R1> __device__ __forceinline__ void load_op_run(float (&dst)[RUN], const float* __restrict__ op, uint32_t base)
 { // base: index (in floats) of vector q = 0 of this thread; consecutive q are R1 * 16 vectors apart
   constexpr int V = op_vec(RUN);
@@ -139,11 +122,7 @@ template<int RUN, int R1> __device__ __forceinline__ void load_op_run(float (&ds
     if constexpr (V == 1) dst[q] = LDOP(op + base + static_cast<uint32_t>(q * R1 * NLMAX));
     else
     {
-#ifndef KW_TEMPORAL_STATE
       const vf t = __builtin_nontemporal_load(reinterpret_cast<const vf*>(op + base + static_cast<uint32_t>(q * R1 * NLMAX * V)));
-#else
-      const vf t = *reinterpret_cast<const vf*>(op + base + static_cast<uint32_t>(q * R1 * NLMAX * V));
-#endif
 #pragma unroll
       for (int r = 0; r < V; r++) dst[q * V + r] = t[r];
     }
@@ -155,10 +134,6 @@ template<int RUN, int R1> __device__ __forceinline__ void load_op_run(float (&ds
 // (array base + n * line stride) is 64-bit scalar arithmetic, the lane part one VGPR holding a byte offset — written
 // this way the loads / stores of a tile cost no vector ALU work at all (as  p[lane + n * stride]  every access pays a
 // v_add_u32 and a 64-bit v_lshl_add_u64: a sixth of the vector instructions of a z-pass, whose VALU is ~75 % busy).
-// KW_SADDR=0 restores the indexed form (A/B).
-#ifndef KW_SADDR
-#define KW_SADDR 1
-#endif
 // (the empty asm pins the uniform part to an SGPR pair: left alone, the compiler re-associates it into a chain of 64-bit
 // vector adds)
 __device__ __forceinline__ float2 ld_uni(const float2* __restrict__ p, uint64_t uniform_elems, uint32_t lane_bytes)
@@ -320,7 +295,7 @@ __global__ __launch_bounds__(Geo<L>::THREADS) void k_ypass(PassArgs a)
       const uint32_t step = R2 * a.ain.estride * Pe;
 #pragma unroll
       for (int n1 = 0; n1 < R1; n1++)
-        v[n1] = KW_SADDR ? ld_uni(Sin, static_cast<uint64_t>(n1) * step, b * static_cast<uint32_t>(sizeof(float2))) : Sin[b + n1 * step];
+        v[n1] = ld_uni(Sin, static_cast<uint64_t>(n1) * step, b * static_cast<uint32_t>(sizeof(float2)));
     }
   };
 
@@ -364,11 +339,7 @@ __global__ __launch_bounds__(Geo<L>::THREADS) void k_ypass(PassArgs a)
           asm volatile("" : "+v"(b));
           const uint32_t step = R1 * a.aout.estride * Pe;
 #pragma unroll
-          for (int k2 = 0; k2 < R2; k2++)
-          {
-            if (KW_SADDR) st_uni(Sout, static_cast<uint64_t>(k2) * step, b * static_cast<uint32_t>(sizeof(float2)), w[k2]);
-            else Sout[b + k2 * step] = w[k2];
-          }
+          for (int k2 = 0; k2 < R2; k2++) st_uni(Sout, static_cast<uint64_t>(k2) * step, b * static_cast<uint32_t>(sizeof(float2)), w[k2]);
         }
       }
     }
@@ -409,10 +380,7 @@ struct ZArgs
 // (k1, n2) for all k1 ("its column") and thread k1 reads (k1, n2) for all n2 ("its row"); here thread k1 writes its row
 // — cells nobody else has read — and thread q1 reads its column.  A thread therefore only ever overwrites what it read
 // last itself: no barrier is needed between the forward read and this write, nor between this read and the next
-// forward write (KW_ZSYM=0 restores the q1-major layout with its two extra barriers, for A/B).
-#ifndef KW_ZSYM
-#define KW_ZSYM 1
-#endif
+// forward write.
 // COLWRITE (square factorisations only, used by the 2 x 256 split kernels): the transposed cell assignment — thread k1
 // writes its column and thread q1 reads its row — for an exchange that follows one whose read was by columns.
 template<int L, bool COLWRITE = false>
@@ -430,8 +398,7 @@ __device__ __forceinline__ void inverse_from_regs(float2 (&w)[Fac<L>::R2], float
     {
       const float2 t = (q1 == 0) ? w[0] : apply_tw<kInv>(w[q1], twl[j * G::TP + q1]);
       if (COLWRITE) lds[q1 * G::SF + j * G::NL + c] = t;
-      else if (KW_ZSYM) lds[j * G::SF + q1 * G::NL + c] = t;
-      else lds[q1 * G::SI + j * G::NL + c] = t;
+      else lds[j * G::SF + q1 * G::NL + c] = t;
     }
   }
   lds_barrier();
@@ -439,7 +406,7 @@ __device__ __forceinline__ void inverse_from_regs(float2 (&w)[Fac<L>::R2], float
   {
 #pragma unroll
     for (int k1 = 0; k1 < R1; k1++)
-      v[k1] = COLWRITE ? lds[j * G::SF + k1 * G::NL + c] : KW_ZSYM ? lds[k1 * G::SF + j * G::NL + c] : lds[j * G::SI + k1 * G::NL + c];
+      v[k1] = COLWRITE ? lds[j * G::SF + k1 * G::NL + c] : lds[k1 * G::SF + j * G::NL + c];
     Dft<R1, kInv>::run(v);
   }
 }
@@ -485,7 +452,7 @@ template<int L, int MODE> __global__ __launch_bounds__(Geo<L>::THREADS, big_line
     const uint32_t lb = (basel + static_cast<uint32_t>(j) * zstr) * static_cast<uint32_t>(sizeof(float2));
 #pragma unroll
     for (int n1 = 0; n1 < R1; n1++)
-      v[n1] = KW_SADDR ? ld_uni(in, static_cast<uint64_t>(n1 * R2) * zstr, lb) : in[basel + static_cast<uint32_t>(n1 * R2 + j) * zstr];
+      v[n1] = ld_uni(in, static_cast<uint64_t>(n1 * R2) * zstr, lb);
   }
   // spectral operator of the elements this thread will hold after the forward transform (kz = j + R1*k2)
   float kap[R2];
@@ -513,8 +480,7 @@ template<int L, int MODE> __global__ __launch_bounds__(Geo<L>::THREADS, big_line
       asm volatile("" : "+v"(lb)); // per-iteration address arithmetic instead of 16 loop-invariant address registers
 #pragma unroll
       for (int n1 = 0; n1 < R1; n1++)
-        v[n1] = KW_SADDR ? ld_uni(in, static_cast<uint64_t>(n1 * R2) * zstr, lb * static_cast<uint32_t>(sizeof(float2)))
-                         : in[lb + static_cast<uint32_t>(n1 * R2) * zstr];
+        v[n1] = ld_uni(in, static_cast<uint64_t>(n1 * R2) * zstr, lb * static_cast<uint32_t>(sizeof(float2)));
     }
     lds_barrier();
     float2 X[R2];
@@ -549,7 +515,6 @@ template<int L, int MODE> __global__ __launch_bounds__(Geo<L>::THREADS, big_line
         load_op_run<R2, R1>(kap, a.op[arr + 1], lb);
       }
     }
-    if (!KW_ZSYM) lds_barrier(); // forward exchange buffer is free again
 
 #pragma unroll 1
     for (int o = 0; o < NOUT; o++)
@@ -593,15 +558,11 @@ template<int L, int MODE> __global__ __launch_bounds__(Geo<L>::THREADS, big_line
         uint32_t ob = base + static_cast<uint32_t>(j) * zstr;
         asm volatile("" : "+v"(ob)); // recomputed per output: 16 hoisted 64-bit addresses cost an occupancy step
 #pragma unroll
-        for (int q2 = 0; q2 < R1; q2++)
-        {
-          if (KW_SADDR) st_uni(out, static_cast<uint64_t>(R2 * q2) * zstr, ob * static_cast<uint32_t>(sizeof(float2)), r[q2]);
-          else out[ob + static_cast<uint32_t>(R2 * q2) * zstr] = r[q2];
-        }
+        for (int q2 = 0; q2 < R1; q2++) st_uni(out, static_cast<uint64_t>(R2 * q2) * zstr, ob * static_cast<uint32_t>(sizeof(float2)), r[q2]);
       }
       // the next output's inverse writes rows while other threads may still read their columns: barrier; the next
       // array's forward transform writes the column this thread has just read: none
-      if (o + 1 < NOUT || (!KW_ZSYM && ia + 1 < narr)) lds_barrier();
+      if (o + 1 < NOUT) lds_barrier();
     }
   }
 }
@@ -688,8 +649,8 @@ __global__ __launch_bounds__(Geo<L / 2>::THREADS) void k_ypass_split(PassArgs a)
 #pragma unroll
     for (int n1 = 0; n1 < R1; n1++)
     {
-      va[n1] = KW_SADDR ? ld_uni(Sin, static_cast<uint64_t>(n1) * step, b * static_cast<uint32_t>(sizeof(float2))) : Sin[b + n1 * step];
-      vb[n1] = KW_SADDR ? ld_uni(Sin, static_cast<uint64_t>(R1 + n1) * step, b * static_cast<uint32_t>(sizeof(float2))) : Sin[b + (R1 + n1) * step];
+      va[n1] = ld_uni(Sin, static_cast<uint64_t>(n1) * step, b * static_cast<uint32_t>(sizeof(float2)));
+      vb[n1] = ld_uni(Sin, static_cast<uint64_t>(R1 + n1) * step, b * static_cast<uint32_t>(sizeof(float2)));
     }
   }
   lds_barrier(); // twiddle tables visible (the line loads stay in flight across it)
@@ -704,8 +665,7 @@ __global__ __launch_bounds__(Geo<L / 2>::THREADS) void k_ypass_split(PassArgs a)
   }
   float2 wa[R2], wb[R2];
   line_fft<H, DIR>(va, wa, lds, c, j, twl);
-  if (!KW_ZSYM) lds_barrier();
-  line_fft<H, DIR, KW_ZSYM != 0>(vb, wb, lds, c, j, twl); // writes the rows the first transform just read: no barrier
+  line_fft<H, DIR, true>(vb, wb, lds, c, j, twl); // writes the rows the first transform just read: no barrier
   if (valid)
   {
     if (POUT)
@@ -725,16 +685,8 @@ __global__ __launch_bounds__(Geo<L / 2>::THREADS) void k_ypass_split(PassArgs a)
 #pragma unroll
       for (int k2 = 0; k2 < R2; k2++)
       {
-        if (KW_SADDR)
-        {
-          st_uni(Sout, static_cast<uint64_t>(k2) * step, b * static_cast<uint32_t>(sizeof(float2)), wa[k2]);
-          st_uni(Sout, static_cast<uint64_t>(k2) * step + one, b * static_cast<uint32_t>(sizeof(float2)), wb[k2]);
-        }
-        else
-        {
-          Sout[b + k2 * step]       = wa[k2];
-          Sout[b + one + k2 * step] = wb[k2];
-        }
+        st_uni(Sout, static_cast<uint64_t>(k2) * step, b * static_cast<uint32_t>(sizeof(float2)), wa[k2]);
+        st_uni(Sout, static_cast<uint64_t>(k2) * step + one, b * static_cast<uint32_t>(sizeof(float2)), wb[k2]);
       }
     }
   }
@@ -779,10 +731,8 @@ template<int L, int MODE> __global__ __launch_bounds__(Geo<L / 2>::THREADS) void
 #pragma unroll
     for (int n1 = 0; n1 < R1; n1++)
     {
-      va[n1] = KW_SADDR ? ld_uni(in, static_cast<uint64_t>(n1 * R2) * zstr, lb * static_cast<uint32_t>(sizeof(float2)))
-                        : in[lb + static_cast<uint32_t>(n1 * R2) * zstr];
-      vb[n1] = KW_SADDR ? ld_uni(in, static_cast<uint64_t>(H + n1 * R2) * zstr, lb * static_cast<uint32_t>(sizeof(float2)))
-                        : in[lb + static_cast<uint32_t>(H + n1 * R2) * zstr];
+      va[n1] = ld_uni(in, static_cast<uint64_t>(n1 * R2) * zstr, lb * static_cast<uint32_t>(sizeof(float2)));
+      vb[n1] = ld_uni(in, static_cast<uint64_t>(H + n1 * R2) * zstr, lb * static_cast<uint32_t>(sizeof(float2)));
     }
     lds_barrier(); // twiddle tables visible
 #pragma unroll
@@ -795,9 +745,7 @@ template<int L, int MODE> __global__ __launch_bounds__(Geo<L / 2>::THREADS) void
     // four exchanges per line and output (two forward, two inverse halves), each writing exactly the cells its thread
     // read in the one before (column / row / column / row ...): the only barriers left are the ones inside them
     line_fft<H, kFwd>(va, Xa, lds, c, j, twl);
-    if (!KW_ZSYM) lds_barrier();
-    line_fft<H, kFwd, KW_ZSYM != 0>(vb, Xb, lds, c, j, twl);
-    if (!KW_ZSYM) lds_barrier(); // exchange buffer free for the inverse transforms
+    line_fft<H, kFwd, true>(vb, Xb, lds, c, j, twl);
   }
   { // spectral operator (see k_zfused for the reference lines), kz = 2*(j + R1*k2) (+1)
     float run[2 * R2];
@@ -847,9 +795,8 @@ template<int L, int MODE> __global__ __launch_bounds__(Geo<L / 2>::THREADS) void
 #pragma unroll
         for (int k2 = 0; k2 < R2; k2++) w[k2] = half ? Xb[k2] : Xa[k2];
       }
-      if (half == 0) inverse_from_regs<H, KW_ZSYM != 0>(w, ra, lds, c, j, twl); // after a read by columns: write columns
-      else inverse_from_regs<H>(w, rb, lds, c, j, twl);                          // after a read by rows: write rows
-      if (!KW_ZSYM && (half == 0 || o + 1 < NOUT)) lds_barrier(); // exchange buffer reused by the next half / output
+      if (half == 0) inverse_from_regs<H, true>(w, ra, lds, c, j, twl); // after a read by columns: write columns
+      else inverse_from_regs<H>(w, rb, lds, c, j, twl);                  // after a read by rows: write rows
     }
     if (valid)
     {
@@ -860,16 +807,8 @@ template<int L, int MODE> __global__ __launch_bounds__(Geo<L / 2>::THREADS) void
       for (int q2 = 0; q2 < R1; q2++)
       { // n = j + R2*q2
         const float2 t = apply_tw<kInv>(rb[q2], tw2[j + R2 * q2]);
-        if (KW_SADDR)
-        {
-          st_uni(out, static_cast<uint64_t>(R2 * q2) * zstr, ob * static_cast<uint32_t>(sizeof(float2)), cadd(ra[q2], t));
-          st_uni(out, static_cast<uint64_t>(H + R2 * q2) * zstr, ob * static_cast<uint32_t>(sizeof(float2)), csub(ra[q2], t));
-        }
-        else
-        {
-          out[ob + static_cast<uint32_t>(R2 * q2) * zstr]     = cadd(ra[q2], t);
-          out[ob + static_cast<uint32_t>(H + R2 * q2) * zstr] = csub(ra[q2], t);
-        }
+        st_uni(out, static_cast<uint64_t>(R2 * q2) * zstr, ob * static_cast<uint32_t>(sizeof(float2)), cadd(ra[q2], t));
+        st_uni(out, static_cast<uint64_t>(H + R2 * q2) * zstr, ob * static_cast<uint32_t>(sizeof(float2)), csub(ra[q2], t));
       }
     }
   }
@@ -992,7 +931,6 @@ struct XinvArgs
   float2*       fout[3]; // CHAIN: where the forward x-transform of the epilogue's result goes (scratch rows)
   uint32_t      tile0;   // first 2*NL-row tile of this launch (chunked plane-local passes)
   const float2* mulx[3]; // per component: optional factor mulx[kx] applied to the rows before the inverse (ddx of the gradient)
-  uint32_t      descending; // tiles (and components) are taken from the last to the first (experiment: KW_FUSED_XINV_DESC)
   uint32_t      nrows;      // rows of the grid (ny * nz): bounds the partial last tile (TAIL kernels)
   uint32_t      side_off;   // element offset of the x-Nyquist side array in in[] / fout[] (0: none)
 };
@@ -1096,9 +1034,8 @@ __global__ __launch_bounds__(GeoX<L>::THREADS, (EPI == EPI_DENSITY && L == 256) 
   float* ldsr = reinterpret_cast<float*>(lds);
   const int f = threadIdx.x % G::TPL;
   const int c = threadIdx.x / G::TPL;
-  const uint32_t by   = a.descending ? gridDim.y - 1u - blockIdx.y : blockIdx.y;
-  const uint32_t comp = (NA == 1) ? by + a.comp0 : 0; // component / array index for single-array epilogues
-  const uint32_t tile = (a.descending ? gridDim.x - 1u - blockIdx.x : blockIdx.x) + a.tile0;
+  const uint32_t comp = (NA == 1) ? blockIdx.y + a.comp0 : 0; // component / array index for single-array epilogues
+  const uint32_t tile = blockIdx.x + a.tile0;
   float4 res[NA][NQ];
   constexpr int NF = CHAIN ? ((EPI == EPI_DENSITY) ? 2 : 1) : 1; // chained forward transforms
   // rows to chain: kept in registers, except the first of the density epilogue's two, which goes straight into the
@@ -1723,11 +1660,7 @@ bool supported_len(uint32_t n)
     if (!(ctx)->fused.ready) { kw_set_error("%s: kw_fused_create has not been called", __func__); return KW_ERR_STATE; } \
   } while (0)
 
-#define KW_TRY(call)                                                                                                   \
-  do {                                                                                                                 \
-    kw_status st_ = (call);                                                                                            \
-    if (st_ != KW_OK) return st_;                                                                                      \
-  } while (0)
+#define KW_TRY(call) KW_TRY_STATUS(call)
 
 #if KW_FUSED_TU == 0
 kw_status launch_xfwd(kw_ctx* ctx, int narr, const float* const* in, float2* const* out)
@@ -1770,7 +1703,7 @@ kw_status launch_ypass(kw_ctx* ctx, int dir, int narr, float2* const* in, float2
 {
   const kw_constants& c = ctx->c;
   const auto& f = ctx->fused;
-  if (ordered && narr > 1 && (!f.ypass_loop || (c.ny == 512 && f.split512)))
+  if (ordered && narr > 1 && c.ny == 512 && f.split512)
   { // one array per block in these kernels: order by launch instead
     KW_TRY(launch_ypass(ctx, dir, 1, in, out, pack_in, pack_out, z0, nzc, mul, false));
     return launch_ypass(ctx, dir, narr - 1, in + 1, out + 1, pack_in, pack_out, z0, nzc, mul ? mul + 1 : nullptr, true);
@@ -1791,7 +1724,7 @@ kw_status launch_ypass(kw_ctx* ctx, int dir, int narr, float2* const* in, float2
   const RowAddr packed{(1u << 20) / f.nyl + 1u, f.nyl, c.nz * f.nyl, f.nyl, 1u};
   a.ain  = pack_in ? packed : natural;
   a.aout = pack_out ? packed : natural;
-  a.narr = f.ypass_loop ? narr : 1;
+  a.narr = narr; // each block walks the arrays of the launch (the next one's lines requested before the current transform)
   a.z0   = z0;
   if (c.ny == 512 && f.split512)
   { // 2 x 256 lines: 16-column tiles, one array per block
@@ -1882,7 +1815,6 @@ kw_status launch_xinv_impl(kw_ctx* ctx, int ncomp, XinvArgs a, uint32_t z0, uint
   a.P  = ctx->fused.P;
   a.side_off = ctx->fused.side_off;
   a.nrows = c.ny * c.nz;
-  a.descending = ctx->fused.xinv_desc ? 1u : 0u;
   const uint32_t rows_per_tile = 2u * static_cast<uint32_t>(nl_x(c.nx));
   const uint32_t rows = c.ny * (nzc ? nzc : c.nz), full = rows / rows_per_tile;
   a.tile0 = z0 * c.ny / rows_per_tile; // chunked launches start on tile boundaries (plane_local_tail)
@@ -1896,7 +1828,6 @@ kw_status launch_xinv_impl(kw_ctx* ctx, int ncomp, XinvArgs a, uint32_t z0, uint
   if (rows % rows_per_tile != 0)
   { // the partial last tile of the grid, masked (only ever the last chunk: chunks are whole tiles otherwise)
     a.tile0 += full;
-    a.descending = 0u;
     const dim3 grid(1, ncomp, 1);
 #define M(LEN) LAUNCH((k_xinv<LEN, EPI, CHAIN, TERMS, true>), grid, dim3(GeoX<LEN>::THREADS), a)
     KW_LEN_SWITCH(c.nx, M)
@@ -2106,7 +2037,7 @@ kw_status pslab_tail(kw_ctx* ctx, int narr, int ncomp, const XinvArgs& x, int nc
   const uint32_t C = f.xchunks, nzc = ctx->c.nz / C;
   for (uint32_t c = 0; c < C; c++)
   {
-    if (f.xbatch || narr == 1 || !f.tail_per_array)
+    if (f.xbatch || narr == 1)
     {
       for (int a = 0; a < narr; a++) KW_TRY(pwait(ctx, X_BACK, a, static_cast<int>(c)));
       KW_TRY(launch_ypass(ctx, +1, narr, f.t, f.s, true, false, c * nzc, nzc));
@@ -2191,7 +2122,7 @@ kw_status plane_local_tail(kw_ctx* ctx, int narr, int ncomp, const XinvArgs& x, 
 {
   auto& f = ctx->fused;
   const kw_constants& c = ctx->c;
-  uint32_t nch = f.zchunks;
+  uint32_t nch = static_cast<uint32_t>(ctx->tuning.tail_chunks > 0 ? ctx->tuning.tail_chunks : 1);
   while (nch > 1 && (c.nz % nch != 0 || (c.nz / nch * c.ny) % (2 * nl_x(c.nx)) != 0)) nch--;
   const uint32_t nzc = c.nz / nch;
   for (uint32_t ch = 0; ch < nch; ch++)
@@ -2371,45 +2302,36 @@ kw_status create_impl(kw_ctx* ctx, void* const s[3], void* const t[3])
   {
     // x-Nyquist column apart (see tile_coord) whenever it is the one bin beyond whole tiles.  On slabs the exchange then
     // moves two pieces per peer — the row chunk [nz local][nyl][Nx/2] and the side chunk [nz local][nyl] — i.e. exactly
-    // the Nx/2 + 1 bins per row, in aligned rows.  KW_FUSED_SIDE=0 keeps the column in the (padded) rows (A/B).
-    const char* e   = getenv("KW_FUSED_SIDE");
-    const bool side = (e == nullptr || e[0] != '0') && (c.nx_complex % NLMAX == 1u) && (c.nx_complex > NLMAX) && !f.two_d;
+    // the Nx/2 + 1 bins per row, in aligned rows.  kw_tuning::side_array = 0 keeps the column in the (padded) rows.
+    const bool side = (ctx->tuning.side_array != 0) && (c.nx_complex % NLMAX == 1u) && (c.nx_complex > NLMAX) && !f.two_d;
     f.nxm      = side ? c.nx_complex - 1u : c.nx_complex;
     f.P        = side ? f.nxm : f.Palloc;
     f.side_off = side ? f.P * c.ny * c.nz : 0u;
   }
-  // Exchange-side row pitch.  Default: the padded pitch — every 16-column tile segment of the packed y-passes and of the
-  // transposed z-pass is one aligned 128-B line.  KW_SLAB_UNPADDED=1 sends rows without their padding (nx/2+1 complex:
-  // -10 % wire bytes at 256, -5.5 % at 512) at the price of tile segments that straddle two lines: measured on one
-  // rank at 256^3 the z-pass then takes 67 us per array instead of 30 and the packed y-passes 35-42 us instead of 23-27
-  // (profiles/r02_statsslab_*), i.e. +0.45 ms of local time per step for 0.2 ms less on the wire at 8 GPUs / 512^3.
-  {
-    const char* e = getenv("KW_SLAB_UNPADDED");
-    f.PX = (f.slab && f.side_off == 0 && e != nullptr && e[0] != '0') ? c.nx_complex : f.P;
-  }
+  // Exchange-side row pitch = the pipeline's pitch: every 16-column tile segment of the packed y-passes and of the
+  // transposed z-pass is one aligned 128-B line.  (Rows sent without their padding — nx/2+1 complex — would save 5-10 % of
+  // the wire bytes of a grid without a side array, but their tile segments straddle two lines: measured on one rank at
+  // 256^3 the z-pass then takes 67 us per array instead of 30 and the packed y-passes 35-42 us instead of 23-27.)
+  f.PX = f.P;
   memset(f.xslot, -1, sizeof(f.xslot));
   {
-    // Pipelined schedule: whenever the exchange can move plane chunks (the library's RCCL path, or a piece callback).
-    // KW_SLAB_PIPELINE=0 keeps the whole-array schedule; KW_SLAB_CHUNKS sets the chunk count (chunks are whole planes
-    // and whole x tiles).
-    const char* e  = getenv("KW_SLAB_PIPELINE");
+    // Pipelined schedule: whenever the exchange can move plane chunks (the library's own transports, or a piece
+    // callback).  kw_tuning::slab_pipeline = 0 keeps the whole-array schedule; slab_chunks sets the chunk count (chunks
+    // are whole planes and whole x tiles).
+    const kw_tuning& tn = ctx->tuning;
     const bool can = f.slab && (f.exchange_piece != nullptr || (f.exchange == nullptr && f.exchange_start == nullptr));
-    f.pipelined    = can && !(e != nullptr && e[0] == '0');
-    // Plane chunks are off by default (KW_SLAB_CHUNKS=1): a step on 8 GPUs is bound by the links, and every exchange
-    // group has a fixed cost on the wire (~30 us measured with RCCL on one rank) and on the launching thread (~44 us);
-    // with the links modelled (tools/emulate_rank.py) two chunks gain 3-4 % at a 10 us fixed cost and lose 6 % at 30 us.
-    const char* ec = getenv("KW_SLAB_CHUNKS");
-    uint32_t nch   = (ec != nullptr && atoi(ec) > 0) ? static_cast<uint32_t>(atoi(ec)) : 1u;
+    f.pipelined    = can && tn.slab_pipeline != 0;
+    // Plane chunks are off by default (slab_chunks = 1): a step on 8 GPUs is bound by the links, and every RCCL group
+    // has a fixed cost on the wire (~30 us measured on one rank) and on the launching thread (~44 us); with the links
+    // modelled (tools/emulate_rank.py) two chunks gain 3-4 % at a 10 us fixed cost and lose 6 % at 30 us.
+    uint32_t nch = static_cast<uint32_t>(tn.slab_chunks > 0 ? tn.slab_chunks : 1);
     if (nch > KW_XCHUNKS_MAX) nch = KW_XCHUNKS_MAX;
     while (nch > 1 && (c.nz % nch != 0 || (c.nz / nch * c.ny) % (2 * nl_x(c.nx)) != 0)) nch--;
     f.xchunks = f.pipelined ? nch : 1u;
     // Below 4 MB per peer and array the exchanges are latency- and launch-bound: all arrays of a stage then travel in
-    // one exchange per direction (6 per step instead of 13) and the passes run as multi-array launches.  KW_SLAB_BATCH=0/1.
-    const char* et = getenv("KW_SLAB_TAIL_PER_ARRAY");
-    f.tail_per_array = !(et != nullptr && et[0] == '0');
-    const char* eb = getenv("KW_SLAB_BATCH");
+    // one exchange per direction (6 per step instead of 13) and the passes run as multi-array launches (slab_batch).
     const size_t per_peer = static_cast<size_t>(c.nz) * f.nyl * c.nx_complex * sizeof(float2);
-    f.xbatch = f.pipelined && ((eb != nullptr) ? (eb[0] == '1') : (per_peer < (4u << 20)));
+    f.xbatch = f.pipelined && ((tn.slab_batch >= 0) ? (tn.slab_batch == 1) : (per_peer < (4u << 20)));
     if (f.xbatch) f.xchunks = 1u;
   }
   KW_TRY(alloc_scratch(ctx, s, t));
@@ -2426,18 +2348,7 @@ kw_status create_impl(kw_ctx* ctx, void* const s[3], void* const t[3])
     KW_HIP(hipMemcpyAsync(f.tw[i], tw.data(), lens[i] * sizeof(float2), hipMemcpyHostToDevice, ctx->stream));
     KW_HIP(hipStreamSynchronize(ctx->stream));
   }
-  {
-    const char* e = getenv("KW_FUSED_PER_ARRAY");
-    f.per_array   = (e != nullptr) && (e[0] != '0');
-    e             = getenv("KW_FUSED_ZCHUNKS");
-    f.zchunks     = (e != nullptr && atoi(e) > 0) ? static_cast<uint32_t>(atoi(e)) : 1u;
-    e             = getenv("KW_FUSED_XINV_DESC");
-    f.xinv_desc   = (e != nullptr && atoi(e) != 0);
-    e             = getenv("KW_FUSED_SPLIT512");
-    f.split512    = (e == nullptr) || (e[0] != '0');
-    e             = getenv("KW_FUSED_YPASS_LOOP");
-    f.ypass_loop  = (e == nullptr) || (e[0] != '0');
-  }
+  f.split512 = (ctx->tuning.split512 != 0);
   f.ready = true;
   return KW_OK;
 }
@@ -2550,6 +2461,7 @@ kw_status kw_fused_destroy(kw_ctx* ctx)
   KW_CHECK_CTX(ctx);
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
   (void)kw_comm_sync(ctx); // forward exchanges started ahead by the last stage may still be on the communication stream
+  kw_comm_buffers_gone(ctx);
   auto& f = ctx->fused;
   for (int i = 0; i < 3; i++)
   {
@@ -2714,22 +2626,12 @@ kw_status kw_fused_density(kw_ctx* ctx, int nonlinear, const float* ux, const fl
   {
     KW_TRY(slab_chain<Z_VGRAD>(ctx, 3, u_in_scratch ? nullptr : in3, z));
   }
-  else if (ctx->fused.per_array)
-  {
-    for (int i = 0; i < 3; i++)
-    {
-      KW_TRY(forward_xy(ctx, 1, u_in_scratch ? nullptr : in3 + i, i));
-      z.arr0 = i;
-      KW_TRY(launch_zfused<Z_VGRAD>(ctx, 1, z));
-      KW_TRY(inverse_y(ctx, 1, i));
-    }
-  }
   else
   {
     KW_TRY(forward_xy(ctx, 3, u_in_scratch ? nullptr : in3));
     KW_TRY(launch_zfused<Z_VGRAD>(ctx, 3, z));
   }
-  const bool tail_chunked = (!ctx->fused.slab && !ctx->fused.per_array && !ctx->fused.two_d);
+  const bool tail_chunked = (!ctx->fused.slab && !ctx->fused.two_d);
   XinvArgs x{};
   float* rho[3] = { rx, ry, rz };
   const float* pml[3] = { pmlx, pmly, pmlz };
@@ -2824,16 +2726,6 @@ kw_status kw_fused_absorption_pressure(kw_ctx* ctx, float* p, const float* vel_g
   {
     KW_TRY(slab_chain<Z_ABSORB>(ctx, 2, terms_in_scratch ? nullptr : in2, z));
   }
-  else if (ctx->fused.per_array)
-  {
-    for (int i = 0; i < 2; i++)
-    {
-      KW_TRY(forward_xy(ctx, 1, terms_in_scratch ? nullptr : in2 + i, i));
-      z.arr0 = i;
-      KW_TRY(launch_zfused<Z_ABSORB>(ctx, 1, z));
-      KW_TRY(inverse_y(ctx, 1, i));
-    }
-  }
   else
   {
     KW_TRY(forward_xy(ctx, 2, terms_in_scratch ? nullptr : in2));
@@ -2845,7 +2737,7 @@ kw_status kw_fused_absorption_pressure(kw_ctx* ctx, float* p, const float* vel_g
   x.m0[0] = first; x.m0[1] = c2;
   x.m1[0] = tau;   x.m1[1] = eta;
   x.fout[0] = S[0]; // chained: x-spectrum of the new p
-  if (!ctx->fused.slab && !ctx->fused.per_array && !ctx->fused.two_d)
+  if (!ctx->fused.slab && !ctx->fused.two_d)
   {
     if (chain_p) KW_TRY((plane_local_tail<EPI_PSUM, true>(ctx, 2, 1, x, 1)));
     else KW_TRY((plane_local_tail<EPI_PSUM, false>(ctx, 2, 1, x, 0)));

@@ -19,7 +19,22 @@ struct kw_fft_plan
   size_t                work  = 0;
 };
 
-struct kw_comm_state; // kw_comm.hip: RCCL communicator + communication stream + per-slot events
+struct kw_comm_state; // kw_comm.hip: communicator (RCCL or P2P) + communication stream + per-slot events
+// defaults of every schedule parameter (kwave_hip.h kw_tuning)
+inline kw_tuning kw_tuning_defaults()
+{
+  kw_tuning t{};
+  t.struct_bytes        = static_cast<uint32_t>(sizeof(kw_tuning));
+  t.side_array          = 1;
+  t.tail_chunks         = 0;
+  t.split512            = 1;
+  t.slab_pipeline       = 1;
+  t.slab_chunks         = 1;
+  t.slab_batch          = -1;
+  t.p2p_blocks_per_peer = 4;
+  t.p2p_timeout_s       = 20.f;
+  return t;
+}
 #define KW_COMM_SLOTS 32 /* 2 directions x 3 arrays x KW_XCHUNKS_MAX plane chunks, + spare (z-shift staging) */
 #define KW_XCHUNKS_MAX 4
 
@@ -43,14 +58,10 @@ struct kw_ctx
   struct fused_plan
   {
     bool     ready = false;
-    bool     per_array = false;                    // launch order: chain per array instead of batched (A/B knob; batched is faster)
-    bool     ypass_loop = true;                    // y-pass blocks walk the arrays of a launch (prefetching) instead of one array per block
     bool     split512 = true;                      // 512-point y / z lines as 2 x 256 (A/B knob against the 16 x 32 kernels)
     uint32_t nxm = 0;                              // columns kept in the rows: nx/2+1, or nx/2 when the x-Nyquist column is kept apart
     uint32_t side_off = 0;                         // element offset of that column's compact array N[z][y] in s[] (0: none)
     uint32_t Palloc = 0;                           // pitch the scratch / imported operator arrays are sized by (nx/2+1 rounded up to 16)
-    bool     xinv_desc = false;                    // x-inverse kernels take their tiles last-to-first (KW_FUSED_XINV_DESC)
-    uint32_t zchunks = 1;                          // plane-local passes (y^-1, x^-1 + epilogue, chained x, y) run per chunk of planes
     int      y_done  = 0;                          // chained spectra in s[0..y_done) already carry their forward y-pass
     uint32_t P     = 0;                            // row pitch of the spectra (complex), multiple of 16: nxm rounded up
     uint32_t PX    = 0;                            // row pitch of exchange-side buffers (slab mode: nx/2+1, no padding)
@@ -76,13 +87,13 @@ struct kw_ctx
     uint32_t xchunks   = 1;                        // plane chunks per array of the pipelined tail
     float2*  r[3]      = {nullptr, nullptr, nullptr};
     int      fwd_ahead = 0;                        // arrays whose forward exchange into r[] was started by the producer's tail
-    bool     tail_per_array = true;                // pipelined tail: one y-inverse launch per array, as each comes back (A/B: KW_SLAB_TAIL_PER_ARRAY=0)
     bool     xbatch    = false;                    // small messages: all arrays of a stage travel in ONE exchange per direction
     int8_t   xslot[2][3][KW_XCHUNKS_MAX] = {};     // [dir][array][chunk] -> slot of the started exchange that carries it, -1 none
     bool     slot_waited[KW_COMM_SLOTS] = {};      // the compute stream already waits for that exchange
     int8_t   slot_pieces[KW_COMM_SLOTS] = {};      // pieces of the exchange started on that slot (callback transports wait per piece)
   } fused;
-  kw_comm_state* comm = nullptr; // multi-GPU exchange (kw_comm_init)
+  kw_comm_state* comm = nullptr; // multi-GPU exchange (kw_comm_init / kw_comm_init_p2p)
+  kw_tuning      tuning = kw_tuning_defaults(); // kw_set_tuning
   // profiling (kw_profile_enable)
   struct prof_rec { const char* name; hipEvent_t e0, e1; };
   bool                  profiling = false;
@@ -120,6 +131,8 @@ struct kw_comm_piece { const void* send; void* recv; size_t stride, offset, byte
 kw_status kw_comm_exchange_start_pieces(kw_ctx* ctx, int slot, const kw_comm_piece* pieces, int n);
 kw_status kw_comm_exchange_wait(kw_ctx* ctx, int slot);
 kw_status kw_comm_sync(kw_ctx* ctx); // host waits for the communication stream (no-op without a communicator)
+kw_status kw_comm_check(kw_ctx* ctx); // KW_ERR_COMM once a P2P exchange has given up waiting for a peer (no-op otherwise)
+void      kw_comm_buffers_gone(kw_ctx* ctx); // kw_fused_destroy: the exchange buffers the P2P transport mapped are being freed
 
 // thread-local error text (kw_last_error)
 void kw_set_error(const char* fmt, ...) __attribute__((format(printf, 1, 2)));
@@ -149,6 +162,12 @@ void kw_set_error(const char* fmt, ...) __attribute__((format(printf, 1, 2)));
                    __LINE__);                                                                                          \
       return (e_ == hipErrorOutOfMemory) ? KW_ERR_ALLOC : KW_ERR_HIP;                                                  \
     }                                                                                                                  \
+  } while (0)
+
+#define KW_TRY_STATUS(call)                                                                                            \
+  do {                                                                                                                 \
+    const kw_status st_ = (call);                                                                                      \
+    if (st_ != KW_OK) return st_;                                                                                      \
   } while (0)
 
 // checked right after each launch, without synchronising (reference: cudaCheckErrors(cudaGetLastError()))

@@ -2,10 +2,13 @@
 
 New with this build (the reference is single-GPU, /root/reference/Readme.md:12-13).  Real-space arrays are split into
 Z-slabs; every 3-D FFT of the fused pipeline (csrc/kw_fused.hip) does x- and y-passes locally, one all-to-all transpose,
-the fused z-pass on `Ny/P` rows with all `Nz` planes, and the mirror image on the way back.  Three transports:
+the fused z-pass on `Ny/P` rows with all `Nz` planes, and the mirror image on the way back.  Four transports:
   "native"  the device library's own RCCL path (csrc/kw_comm.hip: ncclSend/ncclRecv groups on a communication stream,
             events against the compute stream).  Python only hands over the communicator id — nothing of it runs in
             the step loop.  The default on a GPU node.
+  "p2p"     the device library's device-initiated transport (kw_comm_init_p2p): the ranks map each other's exchange
+            buffers and one store kernel per exchange writes the peers' receive buffers directly.  Python's part is
+            the all-gather of the buffer handles at set-up (any process-group backend; ranks may share a GPU).
   "torch"   `torch.distributed.all_to_all_single` (backend nccl = RCCL) as a callback (`kw_exchange_fn`).
   "host"    device -> pinned host -> gloo all-to-all -> device, for ranks that share one GPU (tests).
 
@@ -262,7 +265,7 @@ class DistSolver:
 
     exchange: "native" | "torch" | "host" (module docstring); None picks "torch" for an nccl process group (kept for
     the callback path's tests) and "host" otherwise.  "native" needs one GPU per rank (RCCL refuses two ranks on one
-    device) — or a single rank, which then exchanges with itself."""
+    device) — or a single rank, which then exchanges with itself; "p2p" has no such limit."""
 
     def __init__(self, pr_local: Dict[str, np.ndarray], rank: int, nranks: int, nz_global: int, device_index: int = 0,
                  exchange: Optional[str] = None, **opts):
@@ -273,15 +276,24 @@ class DistSolver:
         backend = dist.get_backend() if (dist.is_available() and dist.is_initialized()) else None
         if exchange is None:
             exchange = "torch" if backend == "nccl" else "host"
-        if exchange not in ("native", "torch", "host"):
+        if exchange not in ("native", "p2p", "torch", "host"):
             raise ValueError(f"unknown exchange {exchange!r}")
         if exchange == "torch" and backend != "nccl":
             raise ValueError("exchange='torch' needs an nccl (= RCCL) process group")
         self.transport = exchange
         nx, ny, nzl = (_sc(pr_local[k]) for k in ("Nx", "Ny", "Nz"))
+        if exchange == "p2p":
+            def allgather(mine: bytes) -> bytes:
+                box = [None] * nranks
+                dist.all_gather_object(box, mine)
+                return b"".join(box)
+            self.exchange = None
+            self.sim = HostSolver(pr_local, slab_ranks=nranks, slab_rank=rank, nz_global=nz_global, comm_p2p=True,
+                                  comm_allgather=allgather if nranks > 1 else None, device_idx=device_index, **opts)
+            return
         if exchange == "native":
             # rank 0 draws the communicator id; it travels through the process group (any backend) as plain bytes
-            box = [capi.comm_unique_id() if rank == 0 else None]
+            box = [capi.comm_unique_id(opts.get("rccl_library")) if rank == 0 else None]
             if nranks > 1:
                 dist.broadcast_object_list(box, src=0)
             self.exchange = None

@@ -59,11 +59,21 @@ void KSpaceFirstOrderSolver::initializeFftPlans()
   kw_ctx* ctx = mParameters.getHipParameters().getContext();
   int fusedOk = 0;
   const Parameters::Options& opt = mParameters.getOptions();
+  if (opt.hasTuning) kwCheck(kw_set_tuning(ctx, &opt.tuning));
+  const bool libraryExchange = mParameters.isSlabDecomposed() && (opt.commUniqueId != nullptr || opt.commP2P);
+  if (libraryExchange && (opt.exchangeFn != nullptr || opt.exchangeStartFn != nullptr))
+    throw std::invalid_argument("Z-slab decomposition: give either the device library's exchange (commUniqueId / commP2P) or exchange callbacks");
   if (mParameters.isSlabDecomposed() && opt.commUniqueId != nullptr)
   { // the device library's own all-to-all: RCCL communicator + communication stream on the context (collective call)
-    if (opt.exchangeFn != nullptr || opt.exchangeStartFn != nullptr)
-      throw std::invalid_argument("Z-slab decomposition: give either commUniqueId (RCCL inside the device library) or exchange callbacks");
-    kwCheck(kw_comm_init(ctx, static_cast<uint32_t>(opt.slabRanks), static_cast<uint32_t>(opt.slabRank), opt.commUniqueId));
+    kwCheck(kw_comm_init_with(ctx, opt.rcclLibrary.empty() ? nullptr : opt.rcclLibrary.c_str(), static_cast<uint32_t>(opt.slabRanks),
+                              static_cast<uint32_t>(opt.slabRank), opt.commUniqueId));
+    mOwnsComm = true;
+  }
+  if (mParameters.isSlabDecomposed() && opt.commP2P)
+  { // device-initiated transport: mapped peer buffers, one store kernel per exchange (connected below, once the buffers exist)
+    if (opt.allgatherFn == nullptr && opt.slabRanks > 1 && !(opt.p2pEmulateLinkGbs > 0.0f))
+      throw std::invalid_argument("Z-slab decomposition over the P2P transport needs allgatherFn (the ranks trade their buffer handles through it)");
+    kwCheck(kw_comm_init_p2p(ctx, static_cast<uint32_t>(opt.slabRanks), static_cast<uint32_t>(opt.slabRank)));
     mOwnsComm = true;
   }
   if (mParameters.isSlabDecomposed())
@@ -81,6 +91,17 @@ void KSpaceFirstOrderSolver::initializeFftPlans()
   { // hand-written FFT passes: no library plans needed for the 3-D transforms
     if (opt.scratch[0] != nullptr) kwCheck(kw_fused_create_with_scratch(ctx, opt.scratch, opt.scratch + 3));
     else kwCheck(kw_fused_create(ctx));
+    if (mParameters.isSlabDecomposed() && opt.commP2P && opt.p2pEmulateLinkGbs > 0.0f)
+      kwCheck(kw_comm_p2p_emulate(ctx, opt.p2pEmulateLinkGbs, opt.p2pEmulateLatencyUs));
+    else if (mParameters.isSlabDecomposed() && opt.commP2P)
+    { // every rank publishes where its exchange buffers are; all ranks map all of them
+      std::vector<char> mine(KW_COMM_P2P_BLOB_BYTES), all(KW_COMM_P2P_BLOB_BYTES * opt.slabRanks);
+      kwCheck(kw_comm_p2p_export(ctx, mine.data(), mine.size()));
+      if (opt.slabRanks == 1) all = mine;
+      else if (opt.allgatherFn(opt.allgatherUser, mine.data(), all.data(), mine.size()) != 0)
+        throw std::runtime_error("Z-slab decomposition: the caller's allgather of the P2P buffer handles failed");
+      kwCheck(kw_comm_p2p_connect(ctx, all.data()));
+    }
   }
   else
   {
@@ -551,8 +572,7 @@ void KSpaceFirstOrderSolver::fusedDensity(bool nonlinear)
   mTermsFused              = absorbing && !pSourceActive;
   // lossless media: the equation of state (computePressure*'s lossless branch) is part of the density kernel, and the
   // spectrum of the new p is chained unless p is about to be overwritten by the initial pressure source (step 0)
-  static const bool kNoLosslessFusion = (std::getenv("KW_FUSED_NO_LOSSLESS_P") != nullptr); // A/B knob
-  mPressureFused           = !absorbing && !pSourceActive && !kNoLosslessFusion;
+  mPressureFused           = !absorbing && !pSourceActive;
   const bool chainP        = mPressureFused &&
                              !((mParameters.getTimeIndex() == 0) && (mParameters.getInitialPressureSourceFlag() == 1));
   const bool storeDu       = absorbing && pSourceActive; // the stand-alone terms kernel will need the gradients
@@ -799,10 +819,9 @@ float* KSpaceFirstOrderSolver::importPadded(MI idx)
 
 void KSpaceFirstOrderSolver::initializeFusedPipeline()
 {
-  // step graphs (KW_STEP_GRAPH=1): measured 3-5 % SLOWER than eager launches at 64^3 and 128^3 on this stack (the small
+  // step graphs (Options::stepGraph): measured 3-5 % SLOWER than eager launches at 64^3 and 128^3 on this stack (the small
   // grids are bound by the device-side kernel boundaries, ~7 us per kernel, not by host launch cost) — off by default
-  const char* e = std::getenv("KW_STEP_GRAPH");
-  mUseStepGraph = (e != nullptr) && (e[0] != '0');
+  mUseStepGraph = mParameters.getOptions().stepGraph;
   if (mParameters.isSlabDecomposed()) mUseStepGraph = false; // the exchange callbacks cannot be recorded
   mKappaPadded = importPadded(MI::kKappa);
   if (mMatrixContainer.has(MI::kAbsorbNabla1))

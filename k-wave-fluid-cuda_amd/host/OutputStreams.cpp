@@ -190,16 +190,11 @@ void BaseOutputStream::restoreState(const float* state, size_t n, size_t sampled
 }
 
 // ---- raw helpers ----------------------------------------------------------------------------------------------------
-static bool rawZeroCopy()
-{ // KW_RAW_ZERO_COPY=1: the sampling kernel writes the pinned host buffer itself, as the reference's zero-copy mapped
-  // buffers do (BaseOutputStream.cpp:369-388) — measured equal to the staged copy (both ~10 us per step at 256^3 with
-  // 65 536 points), so the staged copy on the copy stream stays the default
-  static const bool on = std::getenv("KW_RAW_ZERO_COPY") != nullptr && std::getenv("KW_RAW_ZERO_COPY")[0] == '1';
-  return on;
-}
+// (the reference's sampling kernel writes zero-copy mapped host buffers itself, BaseOutputStream.cpp:369-388; measured
+// equal to this staged copy on the copy stream — both ~10 us per step at 256^3 with 65 536 points)
 static void rawSampleTail(kw_ctx* c, float* dev, float* pinned, void* event, size_t n)
 {
-  kwCheck(kw_memcpy_d2h_overlapped(c, pinned, dev, rawZeroCopy() ? 0 : n * sizeof(float), event));
+  kwCheck(kw_memcpy_d2h_overlapped(c, pinned, dev, n * sizeof(float), event));
 }
 
 // ---- IndexOutputStream ----------------------------------------------------------------------------------------------
@@ -216,7 +211,7 @@ void IndexOutputStream::sample()
 float* IndexOutputStream::sampleTarget()
 {
   if (mReduceOp != ReduceOperator::kNone) return mDeviceBuffer;
-  return rawZeroCopy() ? mPinned[mSampledSteps & 1] : mDeviceRaw[mSampledSteps & 1];
+  return mDeviceRaw[mSampledSteps & 1];
 }
 void IndexOutputStream::sampleDone()
 {

@@ -77,6 +77,15 @@ class Parameters
     kw_exchange_wait_fn  exchangeWaitFn  = nullptr;
     kw_exchange_piece_fn exchangePieceFn = nullptr; // optional strided form (plane chunks): pipelined slab schedule
     void*  scratch[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}; // optional caller-owned pipeline scratch
+    bool   hasTuning = false; // schedule parameters of the device library (kw_set_tuning), else its defaults
+    kw_tuning tuning{};
+    bool   stepGraph = false; // steady-state step replayed from a recorded graph (small, launch-bound grids)
+    // slab exchange over the device library's P2P transport: the ranks trade their export blobs through allgatherFn
+    bool   commP2P = false;
+    int  (*allgatherFn)(void* user, const void* mine, void* all, size_t bytes) = nullptr;
+    void*  allgatherUser = nullptr;
+    std::string rcclLibrary; // library the RCCL binding loads (empty: the default search)
+    float  p2pEmulateLinkGbs = 0.0f, p2pEmulateLatencyUs = 0.0f; // > 0: link model instead of peers (kw_comm_p2p_emulate)
   };
 
   /// The parameter set the calling thread works on: the one bound by the innermost live Scope of this thread (every
@@ -113,7 +122,7 @@ class Parameters
   size_t getSlabRank() const { return mOptions.slabRank; }
   bool   isSlabDecomposed() const
   {
-    return mOptions.slabRanks > 1 || mOptions.exchangeFn != nullptr || mOptions.commUniqueId != nullptr;
+    return mOptions.slabRanks > 1 || mOptions.exchangeFn != nullptr || mOptions.commUniqueId != nullptr || mOptions.commP2P;
   }
   DimensionSizes getReducedDimensionSizes() const { return mReducedDimensionSizes; }
   bool           isSimulation3D() const { return mGlobalDimensionSizes.is3D(); }

@@ -45,6 +45,14 @@ Parameters::Options kwh_convert_options(const kwh_options* o)
   opt.exchangeWaitFn  = reinterpret_cast<kw_exchange_wait_fn>(o->exchange_wait_fn);
   opt.exchangePieceFn = reinterpret_cast<kw_exchange_piece_fn>(o->exchange_piece_fn);
   for (int i = 0; i < 6; i++) opt.scratch[i] = o->scratch[i];
+  if (o->tuning != nullptr) { opt.hasTuning = true; opt.tuning = *static_cast<const kw_tuning*>(o->tuning); }
+  opt.stepGraph     = o->step_graph != 0;
+  opt.commP2P       = o->comm_p2p != 0;
+  opt.allgatherFn   = reinterpret_cast<int (*)(void*, const void*, void*, size_t)>(o->comm_allgather_fn);
+  opt.allgatherUser = o->comm_allgather_user;
+  if (o->rccl_library != nullptr) opt.rcclLibrary = o->rccl_library;
+  opt.p2pEmulateLinkGbs   = o->p2p_emulate_link_gbs;
+  opt.p2pEmulateLatencyUs = o->p2p_emulate_latency_us;
   return opt;
 }
 

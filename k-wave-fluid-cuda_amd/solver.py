@@ -42,7 +42,12 @@ class Options(C.Structure):
                 ("exchange_start_fn", C.c_void_p), ("exchange_wait_fn", C.c_void_p), ("scratch", C.c_void_p * 6),
                 ("i_avg", C.c_int32), ("q_term", C.c_int32), ("q_term_c", C.c_int32), ("u_c", C.c_int32),
                 ("frequency", C.c_float), ("only_post_processing", C.c_int32), ("comm_unique_id", C.c_void_p),
-                ("complex_40bit", C.c_int32), ("reserved_", C.c_int32), ("exchange_piece_fn", C.c_void_p)]
+                ("complex_40bit", C.c_int32), ("reserved_", C.c_int32), ("exchange_piece_fn", C.c_void_p),
+                ("tuning", C.c_void_p), ("step_graph", C.c_int32), ("comm_p2p", C.c_int32),
+                ("comm_allgather_fn", C.c_void_p), ("comm_allgather_user", C.c_void_p), ("rccl_library", C.c_char_p),
+                ("p2p_emulate_link_gbs", C.c_float), ("p2p_emulate_latency_us", C.c_float)]
+
+ALLGATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t)  # kwh_allgather_fn
 
 
 _hlib: Optional[C.CDLL] = None
@@ -146,6 +151,36 @@ class HostSolver:
             buf = C.create_string_buffer(bytes(comm_id), len(comm_id))
             self._keep.append(buf)
             o.comm_unique_id = C.cast(buf, C.c_void_p)
+        # schedule parameters of the device library: tuning={"tail_chunks": 4, ...} or "key=value,..." (+ KW_TUNING, a
+        # tool-side convenience read by capi.make_tuning — the libraries read no environment)
+        tuning = opts.pop("tuning", None)
+        if tuning is not None or os.environ.get("KW_TUNING"):
+            t = capi.make_tuning(tuning)
+            self._keep.append(t)
+            o.tuning = C.cast(C.pointer(t), C.c_void_p)
+        # slab exchange over the library's P2P transport: allgather(bytes mine) -> bytes of all ranks, in rank order
+        allgather = opts.pop("comm_allgather", None)
+        if opts.pop("comm_p2p", False):
+            o.comm_p2p = 1
+            if allgather is not None:
+                def _gather(user, mine, out, n, _fn=allgather):
+                    try:
+                        data = _fn(C.string_at(mine, n))
+                        if len(data) != n * int(o.slab_ranks):
+                            return 2
+                        C.memmove(out, data, len(data))
+                        return 0
+                    except BaseException:  # noqa: BLE001 - must not unwind through the C frames
+                        return 1
+                cb = ALLGATHER_FN(_gather)
+                self._keep.append(cb)
+                o.comm_allgather_fn = C.cast(cb, C.c_void_p)
+        emu = opts.pop("p2p_emulate", None)  # (link GB/s, latency us): tools/emulate_rank.py
+        if emu is not None:
+            o.p2p_emulate_link_gbs, o.p2p_emulate_latency_us = float(emu[0]), float(emu[1])
+        lib = opts.pop("rccl_library", None)
+        if lib:
+            o.rccl_library = lib.encode()
         scratch = opts.pop("scratch", None)
         if scratch is not None:
             for i, ptr in enumerate(scratch):

@@ -9,7 +9,7 @@
 // are given.  Transport: a device-to-device copy on the RECEIVER's stream after the sender's "data ready" event; the
 // sender's stream waits for the receiver's "copied" event before the group counts as finished on it.
 //
-//   selected with KW_RCCL_LIB=<this library>  (kw_comm.hip binds RCCL at run time)
+//   selected with named by the caller of kw_comm_init_with (kw_comm.hip binds RCCL at run time)
 //
 // Emulation mode (MOCK_RCCL_EMULATE=1; tools/emulate_rank.py): ONE rank of an N-rank run alone on the GPU.  Every peer is
 // looped back to the rank itself (values become meaningless, sizes and buffers are the real ones): a group then costs

@@ -13,6 +13,7 @@ pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 TOL = 1e-5
+MOCK = os.path.join(HERE, "native", "libmock_rccl.so")  # tests/native/mock_rccl.cpp (build.py build_test_mocks)
 
 
 def run_ranks(world, dims, steps, source, mode, tmp_path, backend="gloo", medium="111", exchange=None, config5=False,
@@ -171,8 +172,10 @@ def _full_size_reference(syn, orc, dims, steps):
     (2, "gloo", (512, 512, 512)),   # 2 ranks share the one GPU (host-staged all-to-all)
     (1, "native", (512, 512, 512)), # the device library's RCCL path exchanging with itself
     (4, "gloo", (256, 512, 512)),   # 128 ky rows / 128 planes per rank: the 2 x 256 split y / z kernels with 4 peer chunks
-    (8, "mock", (512, 512, 512)),   # the 8-GPU decomposition itself (64 planes, 64 ky rows per rank, two plane chunks) on the
-                                    # library's own exchange path: 8 thread-ranks on the one GPU, mock_rccl.cpp as the wire
+    (8, "mock", (512, 512, 512)),   # the 8-GPU decomposition itself (64 planes, 64 ky rows per rank) on the library's RCCL
+                                    # exchange path: 8 thread-ranks on the one GPU, mock_rccl.cpp as the wire
+    (8, "p2p-threads", (512, 512, 512)),  # the same decomposition over the P2P transport: 8 thread-ranks, mapped peer buffers
+    (4, "p2p", (256, 512, 512)),    # 4 PROCESSES sharing the GPU, buffers mapped through hipIpc handles
 ])
 def test_config4_slab_at_full_size(orc, syn, tmp_path, world, backend, dims):
     """BASELINE config 4: 512^3 heterogeneous absorbing nonlinear medium as Z-slabs (KSpaceFirstOrderSolver.cpp:885-935
@@ -184,17 +187,18 @@ def test_config4_slab_at_full_size(orc, syn, tmp_path, world, backend, dims):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
            "--master-addr", "127.0.0.1", "--master-port", str(29790 + world),
            os.path.join(HERE, "dist_worker_gpu.py"), "--dims", *map(str, dims), "--steps", str(steps), "--source", "p0",
-           "--backend", "gloo", "--pml", "10", "--per-rank", "--out", out] + (["--exchange", "native"] if backend == "native" else [])
+           "--backend", "gloo", "--pml", "10", "--per-rank", "--out", out] + (["--exchange", backend] if backend in ("native", "p2p") else [])
     env = dict(os.environ, OMP_NUM_THREADS="4", HSA_ENABLE_IPC_MODE_LEGACY="0")
     if backend == "mock":
         import kwave_amd  # noqa: F401
         from kwave_amd import capi
-        mock = os.path.join(capi.PKG, "lib", "libmock_rccl.so")
-        if not os.path.exists(mock):
+        if not os.path.exists(MOCK):
             pytest.skip("mock exchange library not built")
         cmd = [sys.executable, os.path.join(HERE, "mock_ranks_worker.py"), "--ranks", str(world), "--dims", *map(str, dims),
-               "--steps", str(steps), "--source", "p0", "--pml", "10", "--per-rank", "--out", out]
-        env["KW_RCCL_LIB"] = mock
+               "--steps", str(steps), "--source", "p0", "--pml", "10", "--per-rank", "--out", out, "--rccl-library", MOCK]
+    if backend == "p2p-threads":
+        cmd = [sys.executable, os.path.join(HERE, "mock_ranks_worker.py"), "--ranks", str(world), "--dims", *map(str, dims),
+               "--steps", str(steps), "--source", "p0", "--pml", "10", "--per-rank", "--out", out, "--transport", "p2p"]
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900, env=env)
     assert r.returncode == 0, r.stdout[-4000:]
     parts = [np.load(f"{out}.rank{k}.npz") for k in range(world)]
@@ -285,26 +289,27 @@ def test_bench_moves_to_the_torch_transport_when_the_library_cannot_bind_rccl():
     import json
     import subprocess
     import sys
-    env = dict(os.environ, KW_RCCL_DISABLE="1", MASTER_PORT="29547")
+    env = dict(os.environ, MASTER_PORT="29547")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--slab-selftest", "--size", "64", "--steps", "4",
-                        "--warmup", "2", "--no-512"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600,
+                        "--warmup", "2", "--no-512", "--rccl-library", "/nonexistent/librccl.so"], stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, text=True, timeout=600,
                        env=env, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-3000:]
     line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert line["config"]["exchange"].startswith("torch.distributed")
-    assert "KW_RCCL_DISABLE" in line["config"]["exchange_fallback"]
+    assert "cannot load RCCL" in line["config"]["exchange_fallback"]
     assert line["config"]["exchanges_per_step"] >= 13 and line["value"] > 0
 
 
 @pytest.mark.parametrize("world,exchange,env", [
-    (2, None, {"KW_SLAB_PIPELINE": "0"}),   # whole-array schedule (blocking callback), as every torch-transport run
-    (2, None, {"KW_SLAB_BATCH": "0", "KW_SLAB_CHUNKS": "1"}),     # per-array pipelining, one chunk
-    (2, None, {"KW_SLAB_BATCH": "0", "KW_SLAB_CHUNKS": "4"}),     # 4 plane chunks of 4 planes per rank
-    (4, None, {"KW_SLAB_BATCH": "0", "KW_SLAB_CHUNKS": "3"}),     # 3 does not divide the 8 local planes: falls to 2
-    (4, None, {"KW_SLAB_BATCH": "1"}),      # small messages (the default at these sizes): one exchange per stage and direction
-    (1, "native", {"KW_SLAB_BATCH": "0", "KW_SLAB_CHUNKS": "4"}), # RCCL with itself, strided pieces
-    (1, "native", {"KW_SLAB_BATCH": "1"}),
-    (1, "native", {"KW_SLAB_PIPELINE": "0"}),
+    (2, None, {"KW_TUNING": "slab_pipeline=0"}),   # whole-array schedule (blocking callback), as every torch-transport run
+    (2, None, {"KW_TUNING": "slab_batch=0,slab_chunks=1"}),     # per-array pipelining, one chunk
+    (2, None, {"KW_TUNING": "slab_batch=0,slab_chunks=4"}),     # 4 plane chunks of 4 planes per rank
+    (4, None, {"KW_TUNING": "slab_batch=0,slab_chunks=3"}),     # 3 does not divide the 8 local planes: falls to 2
+    (4, None, {"KW_TUNING": "slab_batch=1"}),      # small messages (the default at these sizes): one exchange per stage and direction
+    (1, "native", {"KW_TUNING": "slab_batch=0,slab_chunks=4"}), # RCCL with itself, strided pieces
+    (1, "native", {"KW_TUNING": "slab_batch=1"}),
+    (1, "native", {"KW_TUNING": "slab_pipeline=0"}),
 ])
 @pytest.mark.parametrize("source,mode", [("p0", 0), ("u_source", 2)])
 def test_slab_schedules_agree(orc, syn, tmp_path, world, exchange, env, source, mode):
@@ -331,27 +336,28 @@ def test_slab_schedules_agree(orc, syn, tmp_path, world, exchange, env, source, 
 
 @pytest.mark.parametrize("ranks,dims,source,mode,env", [
     (4, (32, 64, 32), "p0", 0, {}),                                              # small messages: the batched schedule
-    (4, (32, 64, 32), "u_source", 2, {"KW_SLAB_BATCH": "0", "KW_SLAB_CHUNKS": "2"}),   # per-array pipelining, plane chunks
-    (8, (48, 64, 64), "p0", 0, {"KW_SLAB_BATCH": "0", "KW_SLAB_CHUNKS": "4"}),   # 8 ranks, 2-plane chunks, 8 ky rows each
+    (4, (32, 64, 32), "u_source", 2, {"KW_TUNING": "slab_batch=0,slab_chunks=2"}),   # per-array pipelining, plane chunks
+    (8, (48, 64, 64), "p0", 0, {"KW_TUNING": "slab_batch=0,slab_chunks=4"}),   # 8 ranks, 2-plane chunks, 8 ky rows each
     (8, (32, 64, 32), "p_source", 1, {}),
-    (2, (64, 32, 16), "p0", 0, {"KW_SLAB_PIPELINE": "0"}),                       # whole-array schedule on the native path
+    (2, (64, 32, 16), "p0", 0, {"KW_TUNING": "slab_pipeline=0"}),                       # whole-array schedule on the native path
 ])
-def test_native_exchange_with_many_ranks_on_one_gpu(orc, syn, tmp_path, ranks, dims, source, mode, env):
-    """The device library's OWN exchange path (kw_comm.hip: groups of ncclSend / ncclRecv over strided pieces, events
-    between the compute and the communication stream) with 2 / 4 / 8 ranks: the ranks are threads of one process, each
-    with its own solver, and RCCL is replaced by tests/native/mock_rccl.cpp (same matching rules, device copies as the
-    wire) because the real one refuses two ranks on a device.  What the real multi-GPU run adds to this is the wire."""
-    import kwave_amd  # noqa: F401
-    from kwave_amd import capi
-    mock = os.path.join(capi.PKG, "lib", "libmock_rccl.so")
-    if not os.path.exists(mock):
+@pytest.mark.parametrize("transport", ["mock", "p2p"])
+def test_native_exchange_with_many_ranks_on_one_gpu(orc, syn, tmp_path, ranks, dims, source, mode, env, transport):
+    """The device library's OWN exchange paths (kw_comm.hip, events between the compute and the communication stream)
+    with 2 / 4 / 8 ranks as threads of one process, each with its own solver.  mock: the RCCL path (groups of ncclSend /
+    ncclRecv over strided pieces) with RCCL replaced by tests/native/mock_rccl.cpp (same matching rules, device copies as
+    the wire) because the real one refuses two ranks on a device.  p2p: the device-initiated transport as it is — every
+    rank maps the others' buffers (plain pointers inside one process) and stores its chunks into them, credit / full
+    flags between the ranks' exchange kernels.  What the real multi-GPU run adds to this is the wire."""
+    if transport == "mock" and not os.path.exists(MOCK):
         pytest.skip("mock exchange library not built")
     steps = 12
     out = str(tmp_path / "mock.npz")
     cmd = [sys.executable, os.path.join(HERE, "mock_ranks_worker.py"), "--ranks", str(ranks), "--dims", *map(str, dims),
-           "--steps", str(steps), "--source", source, "--mode", str(mode), "--out", out]
+           "--steps", str(steps), "--source", source, "--mode", str(mode), "--out", out] + \
+          (["--rccl-library", MOCK] if transport == "mock" else ["--transport", "p2p"])
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600,
-                       env=dict(os.environ, OMP_NUM_THREADS="2", KW_RCCL_LIB=mock, **env))
+                       env=dict(os.environ, OMP_NUM_THREADS="2", **env))
     assert r.returncode == 0, r.stdout[-4000:]
     res = np.load(out)
     nx, ny, nz = dims
@@ -370,12 +376,8 @@ def test_native_exchange_with_many_ranks_on_one_gpu(orc, syn, tmp_path, ranks, d
 
 
 def test_rank_emulation_tool_runs():
-    """tools/emulate_rank.py (one rank of an N-GPU run, links modelled by the mock exchange library): the tool behind the
+    """tools/emulate_rank.py (one rank of an N-GPU run, links modelled by kw_comm_p2p_emulate): the tool behind the
     schedule defaults of DESIGN §5 keeps running."""
-    import kwave_amd  # noqa: F401
-    from kwave_amd import capi
-    if not os.path.exists(os.path.join(capi.PKG, "lib", "libmock_rccl.so")):
-        pytest.skip("mock exchange library not built")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "emulate_rank.py"), "--grid", "64", "--ranks", "4", "--steps", "5"],
                        stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300, env=dict(os.environ))
     assert r.returncode == 0, r.stdout[-2000:]
@@ -469,3 +471,61 @@ def test_file_driven_slab_run_with_a_corner_sensor_mask(syn, tmp_path, world, fi
             got = h5io.read_dataset(many, ds)
             assert got.shape == ref[c].shape and np.abs(got - ref[c]).max() <= 2 * TOL * scale, ds
         assert rel_l2(h5io.read_dataset(many, f"{name}/1"), ref[1]) < 10 * TOL, name
+
+
+# ---- the device-initiated (P2P) transport with PROCESSES sharing the GPU: buffers mapped through hipIpc handles --------------
+@pytest.mark.parametrize("world,dims,source,mode,env", [
+    (2, (32, 32, 32), "p0", 0, {}),                                                 # small messages: batched schedule
+    (4, (32, 64, 64), "p0", 0, {"KW_TUNING": "slab_batch=0,slab_chunks=1"}),        # per-array pipelining
+    (2, (64, 32, 16), "u_source", 1, {"KW_TUNING": "slab_batch=0,slab_chunks=4"}),  # plane chunks: strided pieces
+    (4, (32, 120, 48), "p_source", 2, {"KW_TUNING": "slab_pipeline=0"}),            # whole-array schedule, radix-3/5 lines
+    (2, (16, 512, 16), "p0", 0, {"KW_TUNING": "p2p_blocks_per_peer=1"}),            # 512-point y lines; one block per peer
+    (4, (16, 16, 512), "p0", 0, {"KW_TUNING": "p2p_blocks_per_peer=8"}),            # 512-point z lines; eight blocks per peer
+])
+def test_slab_ranks_over_p2p_match_oracle(orc, syn, tmp_path, world, dims, source, mode, env):
+    """kw_comm_init_p2p / export / connect between processes: every rank opens the others' exchange buffers and flag
+    words (hipIpcOpenMemHandle) and the exchange kernels rendezvous across process boundaries."""
+    steps = 20
+    res = run_ranks(world, dims, steps, source, mode, tmp_path, exchange="p2p", env=env)
+    nx, ny, nz = dims
+    pr = syn.make_problem(nx, ny, nz, heterogeneous=True, nonlinear=True, absorbing=True, source=source,
+                          source_mode=mode, source_many=1, nt=steps, pml_size=4, sensor="random")
+    o = orc.OracleSim(pr)
+    series = []
+    for _ in range(steps):
+        o.step()
+        series.append(o.field("p").reshape(-1)[o.sensor_index].copy())
+    for f in ("p", "ux", "uz", "rhoy"):
+        assert rel_l2(res[f], o.field(f)) < TOL, f
+    assert rel_l2(res["series"], np.array(series)) < TOL
+    assert int(res["exchanges"][0]) >= 6 * (steps - 1)
+    o.close()
+
+
+def test_slab_config5_streams_over_p2p(syn, tmp_path):
+    """the z half-cell shift and the Q-term's z derivative send REAL arrays through the exchange (staging in scratch pair 1):
+    receive buffers other than the spectra's, over the P2P transport with 2 processes"""
+    import kwave_amd  # noqa: F401
+    from kwave_amd.solver import HostSolver
+    dims, steps = (32, 48, 64), 36
+    res = run_ranks(2, dims, steps, "p_source", 1, tmp_path, config5=True, exchange="p2p")
+    nx, ny, nz = dims
+    pr = syn.make_problem(nx, ny, nz, heterogeneous=True, nonlinear=True, absorbing=True, source="p_source", source_mode=1,
+                          source_many=1, nt=steps, pml_size=4, sensor="random")
+    dt = float(pr["dt"].ravel()[0])
+    g = HostSolver(pr, p_raw=1, p_max=1, u_non_staggered_raw=1, p_c=1, u_non_staggered_c=1, i_avg_c=1, i_avg=1, q_term=1,
+                   q_term_c=1, period=1.0 / (1.0e6 * dt) / 2.0, mos=1, harmonics=2)
+    g.run(steps)
+    g.finish()
+    assert rel_l2(res["uz_shifted"], g.field("uz_shifted")) < TOL
+    assert rel_l2(res["p"], g.field("p")) < TOL
+    g.close()
+
+
+def test_p2p_rank_that_never_comes_ends_the_run_instead_of_hanging(tmp_path):
+    """a peer that does not start its exchanges: the waiting rank's kernel gives up after kw_tuning::p2p_timeout_s, the
+    queue drains and the step loop stops with KW_ERR_COMM (no wave spins for ever)"""
+    cmd = [sys.executable, os.path.join(HERE, "mock_ranks_worker.py"), "--ranks", "2", "--dims", "32", "32", "32", "--steps", "6",
+           "--transport", "p2p", "--absent", "1", "--tuning", "p2p_timeout_s=1.5", "--out", str(tmp_path / "none.npz")]
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300, env=dict(os.environ, OMP_NUM_THREADS="2"))
+    assert r.returncode == 0 and "TIMEOUT-OK" in r.stdout, r.stdout[-3000:]

@@ -416,21 +416,19 @@ def test_cuboid_sensor_mask_streams(orc, syn):
     o.close()
 
 
-def test_step_graph_replay_is_bit_identical(syn, monkeypatch):
-    """KW_STEP_GRAPH=1: the steady-state step replayed from a recorded graph (kw_graph_*) gives the same bits as eager
+def test_step_graph_replay_is_bit_identical(syn):
+    """kwh_options::step_graph: the steady-state step replayed from a recorded graph (kw_graph_*) gives the same bits as eager
     launches, including across a source that stops mid-run (eager while it is active, graph afterwards)."""
     for kw in (dict(source="p0"), dict(source="u_source", source_mode=1, nt_src=6)):
         pr = syn.make_problem(32, heterogeneous=True, nonlinear=True, absorbing=True, nt=30, pml_size=4,
                               sensor="random", **kw)
-        monkeypatch.setenv("KW_STEP_GRAPH", "0")
-        a = make_gpu(pr, p_raw=1, p_max=1)
+        a = make_gpu(pr, p_raw=1, p_max=1, step_graph=0)
         a.run(7)
         a.run(17)
         a.finish()
         pa, sa, ma = a.field("p"), a.stream("p"), a.stream("p_max")
         a.close()
-        monkeypatch.setenv("KW_STEP_GRAPH", "1")
-        b = make_gpu(pr, p_raw=1, p_max=1)
+        b = make_gpu(pr, p_raw=1, p_max=1, step_graph=1)
         b.run(7)
         b.run(17)
         b.finish()

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""One rank through the slab path (RCCL with itself): host enqueue time vs total time per step — is the launching thread
-or the GPU the limit?   python tools/slab_host_time.py [n] [steps]      (KW_SLAB_CHUNKS / KW_SLAB_PIPELINE apply)"""
+"""One rank through the slab path (exchanging with itself over RCCL or over the P2P transport): host enqueue time vs total
+time per step — is the launching thread or the GPU the limit?
+  python tools/slab_host_time.py [n] [steps] [native|p2p]      (KW_TUNING="slab_chunks=2,slab_batch=0" ... applies)"""
 import os
 import sys
 import time
@@ -21,7 +22,8 @@ def main():
     dist.init_process_group("gloo")
     pr = synthetic.make_problem(n, n, n, heterogeneous=True, nonlinear=True, absorbing=True, source="p0", nt=k + 20)
     loc, _ = partition_problem(pr, 0, 1)
-    sim = DistSolver(loc, 0, 1, n, exchange="native", p_max=1)
+    exchange = sys.argv[3] if len(sys.argv) > 3 else "native"
+    sim = DistSolver(loc, 0, 1, n, exchange=exchange, p_max=1)
     sim.run(5)
     sim.sync()
     t0 = time.perf_counter()
@@ -29,7 +31,7 @@ def main():
     t1 = time.perf_counter()
     sim.sync()
     t2 = time.perf_counter()
-    print(f"chunks={os.environ.get('KW_SLAB_CHUNKS', 'default')} pipeline={os.environ.get('KW_SLAB_PIPELINE', '1')}: "
+    print(f"{exchange}, {os.environ.get('KW_TUNING') or 'default schedule'}: "
           f"enqueue {1e3 * (t1 - t0) / k:.3f} ms/step, total {1e3 * (t2 - t0) / k:.3f} ms/step, "
           f"exchange groups per step {sim.exchanges // (k + 5)}")
     sim.close()
