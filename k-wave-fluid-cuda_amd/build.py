@@ -20,6 +20,7 @@ INCLUDE = os.path.join(ROOT, "include")
 ROCM = os.environ.get("ROCM_PATH", "/opt/rocm")
 HIPCC = os.path.join(ROCM, "bin", "hipcc")
 
+FUSED_TUS = (1, 3, 2, 4, 0)  # passes over kw_fused.hip, slowest first
 HIP_LIB = os.path.join(LIB_DIR, "libkwave_hip.so")
 HOST_LIB = os.path.join(LIB_DIR, "libkwave_host.so")
 
@@ -45,8 +46,8 @@ def build_hip(force: bool = False, verbose: bool = False) -> str:
     deps = srcs + glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(INCLUDE, "*.h"))
     if force or _newer(HIP_LIB, deps):
         objs, jobs = [], []
-        # kw_fused.hip is compiled in three passes (its x-inverse epilogue kernels in two of them, see the file's header)
-        units = [(s, tu) for s in srcs for tu in ((0, 1, 2) if os.path.basename(s) == "kw_fused.hip" else (None,))]
+        # kw_fused.hip is compiled in five passes (its x-inverse epilogue kernels in four of them, see the file's header)
+        units = [(s, tu) for s in srcs for tu in (FUSED_TUS if os.path.basename(s) == "kw_fused.hip" else (None,))]
         for s, tu in units:
             o = os.path.join(LIB_DIR, os.path.basename(s) + (".o" if not tu else f".tu{tu}.o"))
             if force or _newer(o, [s] + [d for d in deps if d.endswith(".h")]):
@@ -60,7 +61,7 @@ def build_hip(force: bool = False, verbose: bool = False) -> str:
                 jobs.append(cmd)
             objs.append(o)
         # the translation units compile side by side (kw_fused.hip alone takes minutes: one kernel set per line length)
-        with concurrent.futures.ThreadPoolExecutor(max_workers=max(1, min(6, len(jobs)))) as pool:
+        with concurrent.futures.ThreadPoolExecutor(max_workers=max(1, min(8, len(jobs)))) as pool:
             for out in pool.map(_run, jobs):
                 if verbose:
                     print(out)
@@ -75,7 +76,7 @@ def build_hip_variant(name: str, extra_flags, only_length: int = 256) -> str:
     out_dir = os.path.join(ROOT, "ab", name)
     os.makedirs(out_dir, exist_ok=True)
     srcs = sorted(glob.glob(os.path.join(CSRC, "*.hip")))
-    units = [(s, tu) for s in srcs for tu in ((0, 1, 2) if os.path.basename(s) == "kw_fused.hip" else (None,))]
+    units = [(s, tu) for s in srcs for tu in (FUSED_TUS if os.path.basename(s) == "kw_fused.hip" else (None,))]
     jobs, objs = [], []
     for s, tu in units:
         o = os.path.join(out_dir, os.path.basename(s) + (".o" if not tu else f".tu{tu}.o"))
@@ -85,7 +86,7 @@ def build_hip_variant(name: str, extra_flags, only_length: int = 256) -> str:
                                                           "-I" + os.path.join(ROCM, "include"), "-c", s, "-o", o]
         jobs.append(cmd)
         objs.append(o)
-    with concurrent.futures.ThreadPoolExecutor(max_workers=6) as pool:
+    with concurrent.futures.ThreadPoolExecutor(max_workers=8) as pool:
         list(pool.map(_run, jobs))
     lib = os.path.join(out_dir, "libkwave_hip.so")
     _run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs +

@@ -174,7 +174,13 @@ void release(kw_comm_state* st)
 // communication stream + per-slot events: what both transports need
 kw_status create_stream_and_events(kw_comm_state* st)
 {
-  if (hipStreamCreateWithFlags(&st->stream, hipStreamNonBlocking) != hipSuccess)
+  // Highest stream priority: the runtime keeps a pool of hardware queues per priority, so the communication stream does
+  // not share a queue with the compute / copy streams of this process (a P2P exchange kernel waits for its peers while
+  // it runs: work queued behind it in the same hardware queue would wait with it), and its few workgroups are placed
+  // ahead of the compute kernels' many.
+  int least = 0, greatest = 0;
+  (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+  if (hipStreamCreateWithPriority(&st->stream, hipStreamNonBlocking, greatest) != hipSuccess)
   {
     kw_set_error("kw_comm_init: cannot create the communication stream");
     return KW_ERR_HIP;

@@ -29,16 +29,21 @@
 
 using namespace kwfft;
 
-// The x-inverse + epilogue kernels are the bulk of this file's compile time (one kernel per epilogue variant and line
-// length).  They are compiled in two extra passes over this file, side by side with the main pass (build.py):
-//   KW_FUSED_TU == 0  everything except those kernels;  1  the density epilogues;  2  the other epilogues.
-// The main pass reaches them through the two functions below (XinvArgs passed as an opaque pointer: the struct lives in
-// this file's anonymous namespace).
+// The x-inverse + epilogue kernels are the bulk of this file's compile time and code size (one kernel per epilogue
+// variant and line length).  They are compiled in four extra passes over this file, side by side with the main pass
+// (build.py):
+//   KW_FUSED_TU == 0  everything except those kernels;  1  the density epilogues;  2  the other epilogues;
+//                  3 / 4  the masked (TAIL) forms of 1 / 2, which only grids with a partial last x tile ever launch.
+// Every pass is a code object of its own that the runtime loads at the first launch out of it: a run pays for the
+// variants it uses.  The main pass reaches the others through the functions below (XinvArgs passed as an opaque pointer:
+// the struct lives in this file's anonymous namespace).
 #ifndef KW_FUSED_TU
 #define KW_FUSED_TU 0
 #endif
-kw_status kw_fused_xinv_density(int chain, int terms, kw_ctx* ctx, int ncomp, const void* xinv_args, uint32_t z0, uint32_t nzc);
-kw_status kw_fused_xinv_other(int epi, int chain, kw_ctx* ctx, int ncomp, const void* xinv_args, uint32_t z0, uint32_t nzc);
+kw_status kw_fused_xinv_density(int chain, int terms, kw_ctx* ctx, int ncomp, const void* xinv_args, uint32_t tile0, uint32_t ntiles);
+kw_status kw_fused_xinv_other(int epi, int chain, kw_ctx* ctx, int ncomp, const void* xinv_args, uint32_t tile0, uint32_t ntiles);
+kw_status kw_fused_xinv_density_tail(int chain, int terms, kw_ctx* ctx, int ncomp, const void* xinv_args, uint32_t tile0, uint32_t ntiles);
+kw_status kw_fused_xinv_other_tail(int epi, int chain, kw_ctx* ctx, int ncomp, const void* xinv_args, uint32_t tile0, uint32_t ntiles);
 
 namespace {
 
@@ -1794,16 +1799,10 @@ template<int MODE> kw_status launch_zfused(kw_ctx* ctx, int narr, ZArgs a)
   return KW_OK;
 }
 
-// main pass: forward to the pass that holds this epilogue's kernels
+// main pass: the full tiles go to the pass that holds this epilogue's kernels, the partial last tile of the grid (if any;
+// only ever in the last chunk: chunks are whole tiles otherwise) to the pass that holds their masked forms
 template<int EPI, bool CHAIN = false, int TERMS = 0>
 kw_status launch_xinv(kw_ctx* ctx, int ncomp, XinvArgs a, uint32_t z0 = 0, uint32_t nzc = 0)
-{
-  if (EPI == EPI_DENSITY) return kw_fused_xinv_density(CHAIN ? 1 : 0, TERMS, ctx, ncomp, &a, z0, nzc);
-  return kw_fused_xinv_other(EPI, CHAIN ? 1 : 0, ctx, ncomp, &a, z0, nzc);
-}
-#else
-template<int EPI, bool CHAIN = false, int TERMS = 0>
-kw_status launch_xinv_impl(kw_ctx* ctx, int ncomp, XinvArgs a, uint32_t z0, uint32_t nzc)
 {
   const kw_constants& c = ctx->c;
   static const char* const names[5][2] = { { "k_xinv_store", "k_xinv_store" }, { "k_xinv_velocity", "k_xinv_velocity_chain" },
@@ -1817,22 +1816,24 @@ kw_status launch_xinv_impl(kw_ctx* ctx, int ncomp, XinvArgs a, uint32_t z0, uint
   a.nrows = c.ny * c.nz;
   const uint32_t rows_per_tile = 2u * static_cast<uint32_t>(nl_x(c.nx));
   const uint32_t rows = c.ny * (nzc ? nzc : c.nz), full = rows / rows_per_tile;
-  a.tile0 = z0 * c.ny / rows_per_tile; // chunked launches start on tile boundaries (plane_local_tail)
+  const uint32_t tile0 = z0 * c.ny / rows_per_tile; // chunked launches start on tile boundaries (plane_local_tail)
   if (full > 0)
-  {
-    const dim3 grid(full, ncomp, 1);
-#define M(LEN) LAUNCH((k_xinv<LEN, EPI, CHAIN, TERMS, false>), grid, dim3(GeoX<LEN>::THREADS), a)
-    KW_LEN_SWITCH(c.nx, M)
-#undef M
-  }
+    KW_TRY(EPI == EPI_DENSITY ? kw_fused_xinv_density(CHAIN ? 1 : 0, TERMS, ctx, ncomp, &a, tile0, full)
+                              : kw_fused_xinv_other(EPI, CHAIN ? 1 : 0, ctx, ncomp, &a, tile0, full));
   if (rows % rows_per_tile != 0)
-  { // the partial last tile of the grid, masked (only ever the last chunk: chunks are whole tiles otherwise)
-    a.tile0 += full;
-    const dim3 grid(1, ncomp, 1);
-#define M(LEN) LAUNCH((k_xinv<LEN, EPI, CHAIN, TERMS, true>), grid, dim3(GeoX<LEN>::THREADS), a)
-    KW_LEN_SWITCH(c.nx, M)
+    KW_TRY(EPI == EPI_DENSITY ? kw_fused_xinv_density_tail(CHAIN ? 1 : 0, TERMS, ctx, ncomp, &a, tile0 + full, 1)
+                              : kw_fused_xinv_other_tail(EPI, CHAIN ? 1 : 0, ctx, ncomp, &a, tile0 + full, 1));
+  return KW_OK;
+}
+#else
+template<int EPI, bool CHAIN, int TERMS, bool TAIL>
+kw_status launch_xinv_impl(kw_ctx* ctx, int ncomp, XinvArgs a, uint32_t tile0, uint32_t ntiles)
+{
+  a.tile0 = tile0;
+  const dim3 grid(ntiles, ncomp, 1);
+#define M(LEN) LAUNCH((k_xinv<LEN, EPI, CHAIN, TERMS, TAIL>), grid, dim3(GeoX<LEN>::THREADS), a)
+  KW_LEN_SWITCH(ctx->c.nx, M)
 #undef M
-  }
   return KW_OK;
 }
 #endif
@@ -2356,34 +2357,44 @@ kw_status create_impl(kw_ctx* ctx, void* const s[3], void* const t[3])
 #endif // KW_FUSED_TU == 0
 } // namespace
 
+#if KW_FUSED_TU == 1 || KW_FUSED_TU == 3
 #if KW_FUSED_TU == 1
-kw_status kw_fused_xinv_density(int chain, int terms, kw_ctx* ctx, int ncomp, const void* xinv_args, uint32_t z0, uint32_t nzc)
+kw_status kw_fused_xinv_density(int chain, int terms, kw_ctx* ctx, int ncomp, const void* xinv_args, uint32_t tile0, uint32_t ntiles)
+#else
+kw_status kw_fused_xinv_density_tail(int chain, int terms, kw_ctx* ctx, int ncomp, const void* xinv_args, uint32_t tile0, uint32_t ntiles)
+#endif
 {
+  constexpr bool T = (KW_FUSED_TU == 3);
   const XinvArgs& a = *static_cast<const XinvArgs*>(xinv_args);
   switch (2 * terms + chain)
   {
-    case 0: return launch_xinv_impl<EPI_DENSITY, false, 0>(ctx, ncomp, a, z0, nzc);
-    case 2: return launch_xinv_impl<EPI_DENSITY, false, 1>(ctx, ncomp, a, z0, nzc);
-    case 3: return launch_xinv_impl<EPI_DENSITY, true, 1>(ctx, ncomp, a, z0, nzc);
-    case 4: return launch_xinv_impl<EPI_DENSITY, false, 2>(ctx, ncomp, a, z0, nzc);
-    case 5: return launch_xinv_impl<EPI_DENSITY, true, 2>(ctx, ncomp, a, z0, nzc);
-    case 6: return launch_xinv_impl<EPI_DENSITY, false, 3>(ctx, ncomp, a, z0, nzc);
-    case 7: return launch_xinv_impl<EPI_DENSITY, true, 3>(ctx, ncomp, a, z0, nzc);
+    case 0: return launch_xinv_impl<EPI_DENSITY, false, 0, T>(ctx, ncomp, a, tile0, ntiles);
+    case 2: return launch_xinv_impl<EPI_DENSITY, false, 1, T>(ctx, ncomp, a, tile0, ntiles);
+    case 3: return launch_xinv_impl<EPI_DENSITY, true, 1, T>(ctx, ncomp, a, tile0, ntiles);
+    case 4: return launch_xinv_impl<EPI_DENSITY, false, 2, T>(ctx, ncomp, a, tile0, ntiles);
+    case 5: return launch_xinv_impl<EPI_DENSITY, true, 2, T>(ctx, ncomp, a, tile0, ntiles);
+    case 6: return launch_xinv_impl<EPI_DENSITY, false, 3, T>(ctx, ncomp, a, tile0, ntiles);
+    case 7: return launch_xinv_impl<EPI_DENSITY, true, 3, T>(ctx, ncomp, a, tile0, ntiles);
     default: kw_set_error("fused pipeline: no density epilogue for chain = %d, terms = %d", chain, terms); return KW_ERR_INVALID;
   }
 }
-#elif KW_FUSED_TU == 2
-kw_status kw_fused_xinv_other(int epi, int chain, kw_ctx* ctx, int ncomp, const void* xinv_args, uint32_t z0, uint32_t nzc)
+#elif KW_FUSED_TU == 2 || KW_FUSED_TU == 4
+#if KW_FUSED_TU == 2
+kw_status kw_fused_xinv_other(int epi, int chain, kw_ctx* ctx, int ncomp, const void* xinv_args, uint32_t tile0, uint32_t ntiles)
+#else
+kw_status kw_fused_xinv_other_tail(int epi, int chain, kw_ctx* ctx, int ncomp, const void* xinv_args, uint32_t tile0, uint32_t ntiles)
+#endif
 {
+  constexpr bool T = (KW_FUSED_TU == 4);
   const XinvArgs& a = *static_cast<const XinvArgs*>(xinv_args);
   switch (2 * epi + chain)
   {
-    case 2 * EPI_STORE: return launch_xinv_impl<EPI_STORE, false>(ctx, ncomp, a, z0, nzc);
-    case 2 * EPI_VELOCITY: return launch_xinv_impl<EPI_VELOCITY, false>(ctx, ncomp, a, z0, nzc);
-    case 2 * EPI_VELOCITY + 1: return launch_xinv_impl<EPI_VELOCITY, true>(ctx, ncomp, a, z0, nzc);
-    case 2 * EPI_INITVEL: return launch_xinv_impl<EPI_INITVEL, false>(ctx, ncomp, a, z0, nzc);
-    case 2 * EPI_PSUM: return launch_xinv_impl<EPI_PSUM, false>(ctx, ncomp, a, z0, nzc);
-    case 2 * EPI_PSUM + 1: return launch_xinv_impl<EPI_PSUM, true>(ctx, ncomp, a, z0, nzc);
+    case 2 * EPI_STORE: return launch_xinv_impl<EPI_STORE, false, 0, T>(ctx, ncomp, a, tile0, ntiles);
+    case 2 * EPI_VELOCITY: return launch_xinv_impl<EPI_VELOCITY, false, 0, T>(ctx, ncomp, a, tile0, ntiles);
+    case 2 * EPI_VELOCITY + 1: return launch_xinv_impl<EPI_VELOCITY, true, 0, T>(ctx, ncomp, a, tile0, ntiles);
+    case 2 * EPI_INITVEL: return launch_xinv_impl<EPI_INITVEL, false, 0, T>(ctx, ncomp, a, tile0, ntiles);
+    case 2 * EPI_PSUM: return launch_xinv_impl<EPI_PSUM, false, 0, T>(ctx, ncomp, a, tile0, ntiles);
+    case 2 * EPI_PSUM + 1: return launch_xinv_impl<EPI_PSUM, true, 0, T>(ctx, ncomp, a, tile0, ntiles);
     default: kw_set_error("fused pipeline: no epilogue %d with chain = %d", epi, chain); return KW_ERR_INVALID;
   }
 }

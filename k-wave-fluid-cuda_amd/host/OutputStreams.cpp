@@ -310,6 +310,25 @@ void CompressedIndexOutputStream::checkpointState(std::vector<float>& state, siz
   if (nacc == 2) kwCheck(kw_memcpy_d2h(ctx(), state.data() + frames + mSize, mC2, mSize * sizeof(float)));
   sampledSteps = mSampledSteps;
 }
+void CompressedIndexOutputStream::accumulators(std::vector<float>& c1, std::vector<float>& c2)
+{
+  if (mSink) mSink->flush();
+  c1.resize(mSize);
+  c2.resize(mSize);
+  kwCheck(kw_memcpy_d2h(ctx(), c1.data(), mC1, mSize * sizeof(float)));
+  kwCheck(kw_memcpy_d2h(ctx(), c2.data(), mC2, mSize * sizeof(float)));
+}
+void CompressedIndexOutputStream::restoreAccumulators(const float* c1, const float* c2, size_t n, size_t sampledSteps)
+{
+  if (n != mSize) throw std::invalid_argument("checkpoint of stream " + mName + " has the wrong size");
+  mCompressedTimeStep = mFlushedSteps = sampledSteps / CompressHelper::getInstance().getOSize(); // IndexOutputStream.cpp:204-209
+  if (mSink) mSink->setRows(mCompressedTimeStep);
+  else mDataset.clear();
+  kwCheck(kw_memcpy_h2d(ctx(), mC1, c1, mSize * sizeof(float)));
+  if (mC2 != mC1) kwCheck(kw_memcpy_h2d(ctx(), mC2, c2, mSize * sizeof(float)));
+  mSampledSteps = sampledSteps;
+  mCurrent      = nullptr;
+}
 void CompressedIndexOutputStream::restoreState(const float* state, size_t n, size_t sampledSteps)
 {
   const size_t nacc = (mC2 == mC1) ? 1 : 2;

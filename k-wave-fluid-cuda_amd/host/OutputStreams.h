@@ -131,6 +131,11 @@ class CompressedIndexOutputStream : public BaseOutputStream
   /// state = frames stored so far, then the accumulators c1 (and c2 unless --no_overlap); steps = sampled steps
   void checkpointState(std::vector<float>& state, size_t& sampledSteps) override;
   void restoreState(const float* state, size_t n, size_t sampledSteps) override;
+  /// the reference's checkpoint form (BaseOutputStream.cpp:551-606): the two accumulators alone — Temp_<name>_1 / _2; with
+  /// --no_overlap they are one buffer and c2 == c1.  restoreAccumulators: the frames so far are in the re-opened output
+  /// file (or, for a stream that only feeds others, nowhere: nothing reads them again)
+  void accumulators(std::vector<float>& c1, std::vector<float>& c2);
+  void restoreAccumulators(const float* c1, const float* c2, size_t n, size_t sampledSteps);
   size_t frames() const { return mCompressedTimeStep; }
   size_t points() const { return mSensorMask.size(); }
   bool   shiftedBasis() const { return mShifted; }

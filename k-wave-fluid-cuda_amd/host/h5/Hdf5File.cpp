@@ -145,6 +145,23 @@ static void writeDataset(hid_t file, const std::string& name, const DimensionSiz
                          const void* data, bool chunked = false, unsigned compressionLevel = 0)
 {
   hsize_t dims[3] = {d.nz, d.ny, d.nx};
+  if (H5Lexists(file, name.c_str(), H5P_DEFAULT) > 0)
+  { // rewritten in place (the accumulators a checkpoint leaves in the output file, the scalars of every leg): same extent
+    hid_t set = H5Dopen2(file, name.c_str(), H5P_DEFAULT);
+    herr_t st = -1;
+    if (set >= 0)
+    {
+      hid_t sp = H5Dget_space(set);
+      hsize_t have[3] = {0, 0, 0};
+      const bool same = (H5Sget_simple_extent_ndims(sp) == 3) && (H5Sget_simple_extent_dims(sp, have, nullptr) == 3) &&
+                        have[0] == dims[0] && have[1] == dims[1] && have[2] == dims[2];
+      H5Sclose(sp);
+      if (same) st = (d.nx * d.ny * d.nz == 0) ? 0 : H5Dwrite(set, memType, H5S_ALL, H5S_ALL, H5P_DEFAULT, data);
+      H5Dclose(set);
+    }
+    if (st < 0) throw std::ios_base::failure("Error: cannot rewrite dataset \"" + name + "\"");
+    return;
+  }
   hid_t space = H5Screate_simple(3, dims, nullptr);
   hid_t plist = H5P_DEFAULT;
   if (chunked && d.nElements() > 0)
@@ -191,6 +208,15 @@ void Hdf5File::writeCuboid(const std::string& name, const DimensionSizes& d, con
   const int rank = (d.nt > 0) ? 4 : 3;
   hsize_t dims[4] = {d.nt, d.nz, d.ny, d.nx};
   hsize_t* dp = (rank == 4) ? dims : dims + 1;
+  if (H5Lexists(mFile, name.c_str(), H5P_DEFAULT) > 0)
+  { // an aggregate written by an earlier checkpoint: rewritten in place
+    if (getDatasetDimensionSizes(name).nElements() != d.nElements()) fail("Error: cannot rewrite dataset \"" + name + "\"");
+    hid_t set = H5Dopen2(mFile, name.c_str(), H5P_DEFAULT);
+    const herr_t st = (set < 0) ? -1 : (d.nElements() == 0) ? 0 : H5Dwrite(set, H5T_NATIVE_FLOAT, H5S_ALL, H5S_ALL, H5P_DEFAULT, data);
+    if (set >= 0) H5Dclose(set);
+    if (st < 0) fail("Error: cannot rewrite dataset \"" + name + "\"");
+    return;
+  }
   hid_t space = H5Screate_simple(rank, dp, nullptr);
   hid_t plist = H5P_DEFAULT;
   if (mChunkedOutput && d.nx * d.ny * d.nz > 0)

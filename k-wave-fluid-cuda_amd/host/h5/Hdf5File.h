@@ -42,7 +42,8 @@ class Hdf5File
   /// run needs of a grid-sized input array
   void readPlanes(const std::string& name, size_t z0, size_t nPlanes, float* data) const;
   void readCompleteDataset(const std::string& name, size_t nElements, size_t* data) const; // :805-815
-  /// write a whole 3-D dataset (x,y,z sizes) + its data_type / domain_type attributes
+  /// write a whole 3-D dataset (x,y,z sizes) + its data_type / domain_type attributes; a dataset of that name and extent
+  /// that exists already is rewritten in place
   void writeMatrix(const std::string& name, const DimensionSizes& dims, const float* data, MatrixDomainType domain);
   void writeMatrix(const std::string& name, const DimensionSizes& dims, const size_t* data);
   /// group + dataset of one sampled cuboid (CuboidOutputStream.cpp:656-722): dims = (nx, ny, nz[, nt]); 4-D when nt > 0;

@@ -94,23 +94,12 @@ void kwh_open_output(kwh_solver* s, const std::string& path, unsigned compressio
   s->series_writer = writer;
 }
 
-void kwh_write_output(kwh_solver* s, const std::string& path, unsigned compressionLevel, bool copySensorMask)
+// Header and scalars of the output file (writeOutputDataInfo, KSpaceFirstOrderSolver.cpp:1161-1168 + Parameters.cpp:559-647).
+// The reference writes them at the end of EVERY leg of a checkpointed run (compute(), :429-430) — a restart checks the
+// file through them (checkOutputFile, :2843-2891) — so this runs at every checkpoint as well as at the end.
+static void writeOutputInfo(kwh_solver* s, Hdf5File& out)
 {
   const Parameters& params = Parameters::getInstance();
-  Hdf5File fresh;
-  Hdf5SeriesWriter* writer = seriesWriter(s);
-  if (writer != nullptr)
-  { // the file has been open since the start of the run and holds the series already: complete it
-    if (writer->path() != path) throw std::invalid_argument("the output is being streamed to " + writer->path() + ", it cannot be written to " + path);
-    writer->finish();
-    compressionLevel = writer->compressionLevel();
-  }
-  else
-  {
-    fresh.create(path);
-    fresh.setOutputLayout(true, compressionLevel); // chunked like the reference's output; -c N deflate level
-  }
-  Hdf5File& out = writer ? writer->file() : fresh;
   out.writeHeader("output", "k-Wave output written by kspaceFirstOrder-HIP");
   { // the rest of the output header (Hdf5FileHeader.cpp:78-87, :340-384): host, cores, memory, phase times as strings
     char host[256] = "unknown";
@@ -177,7 +166,80 @@ void kwh_write_output(kwh_solver* s, const std::string& path, unsigned compressi
   }
   if (params.getAbsorbingFlag() != 0) out.writeScalarValue(kAlphaPowerName, params.getAlphaPower());
   out.writeScalarValue(kSensorMaskTypeName, static_cast<size_t>(params.getSensorMaskType()));
-  // streams: raw series (Nsens, Nt - s, 1); aggregates (Nsens, 1, 1); whole-domain (Nx, Ny, Nz)
+}
+
+// One stream's data as its dataset(s) of the output file: raw series (Nsens, steps, 1); aggregates (Nsens, 1, 1);
+// whole-domain (Nx, Ny, Nz); with a corners mask a group per stream and a dataset per cuboid — (nx, ny, nz, steps) for
+// series, (nx, ny, nz) for aggregates (CuboidOutputStream.cpp:95-140, :656-722; `data` holds the cuboids back to back per
+// step).  Datasets that exist already (an aggregate flushed by an earlier checkpoint) are rewritten in place.
+static void writeStreamData(kwh_solver* s, Hdf5File& out, BaseOutputStream* st, const std::string& name, const float* data,
+                            bool series, size_t steps)
+{
+  const DimensionSizes dims = Parameters::getInstance().getGlobalDimensionSizes();
+  MatrixContainer& mcs = s->solver->getMatrixContainer();
+  if (mcs.has(MatrixContainer::MatrixIdx::kSensorMaskCorners) && dynamic_cast<WholeDomainOutputStream*>(st) == nullptr)
+  {
+    const IndexMatrix& corners = mcs.getMatrix<IndexMatrix>(MatrixContainer::MatrixIdx::kSensorMaskCorners);
+    if (!out.datasetExists(name)) out.createGroup(name);
+    size_t offset = 0;
+    std::vector<float> block;
+    for (size_t c = 0; c < corners.getDimensionSizes().ny; c++)
+    {
+      const DimensionSizes a = corners.getTopLeftCorner(c), b = corners.getBottomRightCorner(c);
+      DimensionSizes cd(b.nx - a.nx + 1, b.ny - a.ny + 1, b.nz - a.nz + 1, series ? steps : 0);
+      const size_t n = corners.getSizeOfCuboid(c);
+      block.resize(n * steps);
+      for (size_t t = 0; t < steps; t++) std::copy_n(data + t * st->size() + offset, n, block.data() + t * n);
+      out.writeCuboid(name + "/" + std::to_string(c + 1), cd, block.data());
+      offset += n;
+    }
+    return;
+  }
+  DimensionSizes d(st->size(), steps, 1);
+  if (!series && st->size() == dims.nElements()) d = dims;
+  out.writeMatrix(name, d, data, Hdf5File::MatrixDomainType::kReal);
+  if (auto* cs = dynamic_cast<CompressedIndexOutputStream*>(st)) writeCompressionAttributes(out, name, *cs);
+}
+// the inverse for an aggregate: the accumulator a checkpoint left in the output file (reopen(), e.g.
+// IndexOutputStream.cpp:213-232, WholeDomainOutputStream.cpp:124-133)
+static void readAggregate(kwh_solver* s, Hdf5File& out, BaseOutputStream* st, const std::string& name, std::vector<float>& data)
+{
+  data.resize(st->size());
+  MatrixContainer& mcs = s->solver->getMatrixContainer();
+  if (mcs.has(MatrixContainer::MatrixIdx::kSensorMaskCorners) && dynamic_cast<WholeDomainOutputStream*>(st) == nullptr)
+  {
+    const IndexMatrix& corners = mcs.getMatrix<IndexMatrix>(MatrixContainer::MatrixIdx::kSensorMaskCorners);
+    size_t offset = 0;
+    for (size_t c = 0; c < corners.getDimensionSizes().ny; c++)
+    {
+      const size_t n = corners.getSizeOfCuboid(c);
+      out.readCompleteDataset(name + "/" + std::to_string(c + 1), n, data.data() + offset);
+      offset += n;
+    }
+    return;
+  }
+  out.readCompleteDataset(name, data.size(), data.data());
+}
+
+void kwh_write_output(kwh_solver* s, const std::string& path, unsigned compressionLevel, bool copySensorMask)
+{
+  const Parameters& params = Parameters::getInstance();
+  Hdf5File fresh;
+  Hdf5SeriesWriter* writer = seriesWriter(s);
+  if (writer != nullptr)
+  { // the file has been open since the start of the run and holds the series already: complete it
+    if (writer->path() != path) throw std::invalid_argument("the output is being streamed to " + writer->path() + ", it cannot be written to " + path);
+    writer->finish();
+    compressionLevel = writer->compressionLevel();
+  }
+  else
+  {
+    fresh.create(path);
+    fresh.setOutputLayout(true, compressionLevel); // chunked like the reference's output; -c N deflate level
+  }
+  Hdf5File& out = writer ? writer->file() : fresh;
+  writeOutputInfo(s, out);
+  const DimensionSizes dims = params.getGlobalDimensionSizes();
   OutputStreamContainer& streams = s->solver->getOutputStreamContainer();
   for (const std::string& name : streams.names())
   {
@@ -185,33 +247,9 @@ void kwh_write_output(kwh_solver* s, const std::string& path, unsigned compressi
     const bool series = st->reduceOp() == BaseOutputStream::ReduceOperator::kNone ||
                         st->reduceOp() == BaseOutputStream::ReduceOperator::kC;
     if (series && st->hasSink()) continue; // streamed: in the file since the step it was sampled at
-    DimensionSizes d(st->size(), series ? st->sampledSteps() : 1, 1);
-    if (!series && st->size() == dims.nElements()) d = dims;
-    if (st->dataset().size() != d.nElements()) continue; // nothing sampled yet
-    MatrixContainer& mcs = s->solver->getMatrixContainer();
-    if (mcs.has(MatrixContainer::MatrixIdx::kSensorMaskCorners) && dynamic_cast<WholeDomainOutputStream*>(st) == nullptr)
-    { // corners mask: a group per stream, a dataset per cuboid — (nx, ny, nz, Nt - s) for series, (nx, ny, nz) for
-      // aggregates (CuboidOutputStream.cpp:95-140, :656-722); the stream buffer holds the cuboids back to back per step
-      const IndexMatrix& corners = mcs.getMatrix<IndexMatrix>(MatrixContainer::MatrixIdx::kSensorMaskCorners);
-      const size_t steps = series ? st->sampledSteps() : 1;
-      out.createGroup(name);
-      size_t offset = 0;
-      std::vector<float> block;
-      for (size_t c = 0; c < corners.getDimensionSizes().ny; c++)
-      {
-        const DimensionSizes a = corners.getTopLeftCorner(c), b = corners.getBottomRightCorner(c);
-        DimensionSizes cd(b.nx - a.nx + 1, b.ny - a.ny + 1, b.nz - a.nz + 1, series ? steps : 0);
-        const size_t n = corners.getSizeOfCuboid(c);
-        block.resize(n * steps);
-        for (size_t t = 0; t < steps; t++)
-          std::copy_n(st->dataset().data() + t * st->size() + offset, n, block.data() + t * n);
-        out.writeCuboid(name + "/" + std::to_string(c + 1), cd, block.data());
-        offset += n;
-      }
-      continue;
-    }
-    out.writeMatrix(name, d, st->dataset().data(), Hdf5File::MatrixDomainType::kReal);
-    if (auto* cs = dynamic_cast<CompressedIndexOutputStream*>(st)) writeCompressionAttributes(out, name, *cs);
+    const size_t steps = series ? st->sampledSteps() : 1;
+    if (st->dataset().size() != st->size() * steps) continue; // nothing sampled yet
+    writeStreamData(s, out, st, name, st->dataset().data(), series, steps);
   }
   auto writeFinal = [&](MatrixContainer::MatrixIdx idx, const std::string& name) {
     RealMatrix& m = s->solver->getMatrixContainer().getMatrix<RealMatrix>(idx);
@@ -285,9 +323,24 @@ void kwh_post_process_output(kwh_solver* s, const std::string& path)
 
 // ---- checkpoint file (KSpaceFirstOrderSolver.cpp:1176-1224 write, :186-228 + :1124-1169 read / check) --------------
 // Root datasets: the seven state arrays under their matrix names (MatrixContainer.cpp:504-537), t_index, Nx, Ny, Nz;
-// header file_type = "checkpoint".  Streams: "stream_<name>" (series so far or accumulator) + "stream_<name>_steps";
-// the reference keeps raw series in the output file and re-opens it, here both live in the one checkpoint file.
+// header file_type = "checkpoint".
+//
+// Stream state, the reference's layout — used whenever the output file is open (the command-line program always;
+// kwh_open_output_file), so that either code can resume the other's run:
+//   * raw series and compression frames are in the output file already (appended step by step);
+//   * aggregated streams (rms / max / min, index, cuboid or whole-domain; I_avg_c) are flushed, as the accumulators
+//     they are, into their own datasets of the OUTPUT file and read back from there on restart (checkpoint() / reopen():
+//     IndexOutputStream.cpp:536-557, 213-232; WholeDomainOutputStream.cpp:233-241, 124-133) — the final values
+//     replace them when the run completes;
+//   * compression accumulators go to the CHECKPOINT file as Temp_<name>_1 / Temp_<name>_2 (c1, c2) and the running
+//     I_avg_c sum as Temp_<name> (BaseOutputStream.cpp:551-606, 520-543);
+//   * the number of sampled steps is not stored: it follows from t_index and the sampling start (reopen(), :197-209);
+//   * header and scalars of the output file are written at every checkpoint (compute(), :429-430).
+// Without an output file (the file-less host API) the streams' state has nowhere to go but the checkpoint file:
+// "stream_<name>" (series so far, accumulators) + "stream_<name>_steps" — this build's private layout, also still read.
 static const char* const kCheckpointMatrices[] = { "p", "rhox", "rhoy", "rhoz", "ux_sgx", "uy_sgy", "uz_sgz" };
+using RO = BaseOutputStream::ReduceOperator;
+static bool isAggregate(RO op) { return op == RO::kRms || op == RO::kMax || op == RO::kMin || op == RO::kIAvgC; }
 
 void kwh_checkpoint_write_impl(kwh_solver* s, const std::string& path)
 {
@@ -311,14 +364,48 @@ void kwh_checkpoint_write_impl(kwh_solver* s, const std::string& path)
     f.writeMatrix(name, dims, buf.data(), Hdf5File::MatrixDomainType::kReal);
   }
   OutputStreamContainer& streams = s->solver->getOutputStreamContainer();
+  Hdf5SeriesWriter* writer = seriesWriter(s);
+  const bool sampled = params.getTimeIndex() > params.getSamplingStartTimeIndex(); // "we're here one step ahead" (:1212-1219)
   for (const std::string& name : streams.names(true))
   {
+    BaseOutputStream* st = streams.find(name);
+    if (writer == nullptr)
+    { // private layout
+      std::vector<float> state;
+      size_t steps = 0;
+      st->checkpointState(state, steps);
+      f.writeScalarValue("stream_" + name + "_steps", steps);
+      if (!state.empty())
+        f.writeMatrix("stream_" + name, DimensionSizes(state.size(), 1, 1), state.data(), Hdf5File::MatrixDomainType::kReal);
+      continue;
+    }
+    const RO op = st->reduceOp();
+    if (st->isSeries() && !st->hasSink() && op == RO::kNone && sampled)
+      throw std::runtime_error("checkpoint: the series of stream " + name + " is kept in memory only (it feeds a post-processed "
+                               "quantity and is not part of the output); such a run cannot be checkpointed in the reference's layout");
+    if (!sampled) continue;
+    if (auto* cs = dynamic_cast<CompressedIndexOutputStream*>(st))
+    {
+      std::vector<float> c1, c2;
+      cs->accumulators(c1, c2);
+      f.writeMatrix("Temp_" + name + "_1", DimensionSizes(c1.size(), 1, 1), c1.data(), Hdf5File::MatrixDomainType::kReal);
+      f.writeMatrix("Temp_" + name + "_2", DimensionSizes(c2.size(), 1, 1), c2.data(), Hdf5File::MatrixDomainType::kReal);
+      continue;
+    }
     std::vector<float> state;
     size_t steps = 0;
-    streams.find(name)->checkpointState(state, steps);
-    f.writeScalarValue("stream_" + name + "_steps", steps);
-    if (!state.empty())
-      f.writeMatrix("stream_" + name, DimensionSizes(state.size(), 1, 1), state.data(), Hdf5File::MatrixDomainType::kReal);
+    st->checkpointState(state, steps); // raw: flushes what is still in flight; aggregates: the accumulator as it stands
+    if (!isAggregate(op)) continue;
+    if (op == RO::kIAvgC) f.writeMatrix("Temp_" + name, DimensionSizes(state.size(), 1, 1), state.data(), Hdf5File::MatrixDomainType::kReal);
+    if (st->doNotSave()) continue;
+    writer->drain();
+    writeStreamData(s, writer->file(), st, name, state.data(), false, 1);
+  }
+  if (writer != nullptr)
+  {
+    writer->drain();
+    writeOutputInfo(s, writer->file());
+    H5Fflush(writer->file().handle(), H5F_SCOPE_GLOBAL);
   }
   f.close();
   if (std::rename(partial.c_str(), path.c_str()) != 0)
@@ -347,21 +434,81 @@ void kwh_checkpoint_read_impl(kwh_solver* s, const std::string& path)
     if (kwh_set_matrix(s, name, buf.data(), buf.size()) != 0) throw std::runtime_error(kwh_last_error());
   }
   OutputStreamContainer& streams = s->solver->getOutputStreamContainer();
-  for (const std::string& name : streams.names(true))
+  const std::vector<std::string> names = streams.names(true);
+  bool privateLayout = false;
+  for (const std::string& name : names) privateLayout = privateLayout || f.datasetExists("stream_" + name + "_steps");
+  if (privateLayout)
   {
-    size_t steps = 0;
-    if (!f.datasetExists("stream_" + name + "_steps"))
-      throw std::invalid_argument(path + " holds no state for the output stream \"" + name + "\": checkpoints of this build carry "
-                                  "their streams inside the checkpoint file (datasets stream_<name>), the reference's "
-                                  "kspaceFirstOrder-CUDA keeps them in the output file - the two cannot resume each other's runs");
-    f.readCompleteDataset("stream_" + name + "_steps", 1, &steps);
-    std::vector<float> state;
-    if (f.datasetExists("stream_" + name))
+    for (const std::string& name : names)
     {
-      state.resize(f.getDatasetSize("stream_" + name));
-      f.readCompleteDataset("stream_" + name, state.size(), state.data());
+      size_t steps = 0;
+      if (!f.datasetExists("stream_" + name + "_steps"))
+        throw std::invalid_argument(path + " holds no state for the output stream \"" + name + "\"");
+      f.readCompleteDataset("stream_" + name + "_steps", 1, &steps);
+      std::vector<float> state;
+      if (f.datasetExists("stream_" + name))
+      {
+        state.resize(f.getDatasetSize("stream_" + name));
+        f.readCompleteDataset("stream_" + name, state.size(), state.data());
+      }
+      streams.find(name)->restoreState(state.data(), state.size(), steps);
     }
-    streams.find(name)->restoreState(state.data(), state.size(), steps);
+  }
+  else if (!names.empty())
+  { // the reference's layout: stream state lives in the re-opened output file and in the Temp_ datasets
+    Hdf5SeriesWriter* writer = seriesWriter(s);
+    if (writer == nullptr)
+      throw std::invalid_argument(path + " is a checkpoint in the reference's layout: the state of the output streams is in the "
+                                  "output file of that run — re-open it first (kwh_open_output_file with reopen = 1)");
+    writer->drain();
+    Hdf5File& out = writer->file();
+    if (out.readFileType() != "output") throw std::invalid_argument(writer->path() + " is not the output file of a checkpointed run"); // :2843-2891
+    size_t o[3] = {0, 0, 0};
+    out.readCompleteDataset(kNxName, 1, &o[0]);
+    out.readCompleteDataset(kNyName, 1, &o[1]);
+    out.readCompleteDataset(kNzName, 1, &o[2]);
+    const DimensionSizes g = params.getGlobalDimensionSizes();
+    if (o[0] != g.nx || o[1] != g.ny || o[2] != g.nz)
+      throw std::invalid_argument("The dimension sizes in the output file do not match the input file");
+    const size_t start = params.getSamplingStartTimeIndex();
+    const size_t steps = (v[3] > start) ? v[3] - start : 0; // IndexOutputStream.cpp:197-203
+    for (const std::string& name : names)
+    {
+      BaseOutputStream* st = streams.find(name);
+      const RO op = st->reduceOp();
+      if (auto* cs = dynamic_cast<CompressedIndexOutputStream*>(st))
+      {
+        std::vector<float> c1(st->size(), 0.0f), c2(st->size(), 0.0f);
+        if (steps > 0)
+        {
+          f.readCompleteDataset("Temp_" + name + "_1", c1.size(), c1.data());
+          f.readCompleteDataset("Temp_" + name + "_2", c2.size(), c2.data());
+        }
+        cs->restoreAccumulators(c1.data(), c2.data(), c1.size(), steps);
+      }
+      else if (op == RO::kNone)
+      {
+        if (!st->hasSink() && steps > 0)
+          throw std::invalid_argument("the series of stream " + name + " is not in the output file: this run cannot be resumed from a "
+                                      "checkpoint in the reference's layout");
+        st->restoreState(nullptr, 0, steps);
+      }
+      else if (isAggregate(op) && steps > 0)
+      {
+        std::vector<float> state;
+        if (op == RO::kIAvgC)
+        { // the running sum, and the number of frames added to it (IndexOutputStream.cpp:204-209)
+          state.resize(st->size());
+          f.readCompleteDataset("Temp_" + name, state.size(), state.data());
+          st->restoreState(state.data(), state.size(), steps / CompressHelper::getInstance().getOSize());
+        }
+        else
+        {
+          readAggregate(s, out, st, name, state);
+          st->restoreState(state.data(), state.size(), steps);
+        }
+      }
+    }
   }
   if (kwh_set_time_index(s, v[3]) != 0) throw std::runtime_error(kwh_last_error());
   f.close();

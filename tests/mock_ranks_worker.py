@@ -68,10 +68,12 @@ def main():
             if a.transport == "p2p":
                 sim = HostSolver(loc, slab_ranks=P, slab_rank=r, nz_global=nz, comm_p2p=True, comm_allgather=allgather_of(r),
                                  p_raw=1, p_max=1, tuning=a.tuning)
-                assert capi.comm_transport(sim.ctx) == "p2p"
             else:
                 sim = HostSolver(loc, slab_ranks=P, slab_rank=r, nz_global=nz, comm_unique_id=comm_id, rccl_library=a.rccl_library,
                                  p_raw=1, p_max=1, tuning=a.tuning)
+            sim.run(0)  # set-up only (communicator, buffers, the ranks' hand-over of handles): collective
+            if a.transport == "p2p":
+                assert capi.comm_transport(sim.ctx) == "p2p", capi.comm_transport(sim.ctx)
             if r == a.absent:
                 gate.wait(timeout=120)  # stays away until the others have given up
                 sim.close()

@@ -109,9 +109,11 @@ def test_command_line_checkpoint_legs(h5io, syn, tmp_path):
 
     def complete(path):
         """the output file is there from the first leg on (sampled series are appended step by step, like the reference's,
-        OutputStreamContainer.cpp:380-403); its header is written when the run is complete"""
+        OutputStreamContainer.cpp:380-403) and carries its header and scalars after every leg (compute(), :429-430): a
+        restart checks it through them; the run is complete when its t_index has reached Nt"""
         try:
-            return h5io.read_attribute(path, "/", "file_type") == "output"
+            assert h5io.read_attribute(path, "/", "file_type") == "output"
+            return int(h5io.read_dataset(path, "t_index").ravel()[0]) == nt
         except capi.KWaveError:
             return False
 
@@ -179,3 +181,69 @@ def test_restart_with_compression_and_post_processed_streams(syn, opts, names, s
         assert ref.stream(s).size > 0 and np.array_equal(b.stream(s), ref.stream(s)), s
     b.close()
     ref.close()
+
+
+def test_checkpoint_in_the_reference_layout(h5io, syn, tmp_path):
+    """With the output file open a checkpoint has the reference's layout (KSpaceFirstOrderSolver.cpp:1176-1224;
+    BaseOutputStream.cpp:551-606; IndexOutputStream.cpp:536-557, 177-247): the checkpoint file holds the seven state
+    arrays, t_index, the dimensions and — for compression streams — Temp_<name>_1 / _2 and Temp_<I_avg_c name>; raw series
+    and frames are in the output file, aggregated streams are flushed into their output datasets as accumulators, header
+    and scalars of the output file are current.  No stream_* dataset, no step counter.  A new solver re-opens the output
+    file, recovers and finishes: same bits as the uninterrupted run."""
+    import h5dump_util as u
+    if not u.available():
+        pytest.skip("h5dump not available")
+    nt, split, start = 120, 53, 4
+    pr = syn.make_problem(32, 24, 16, heterogeneous=True, nonlinear=False, absorbing=False, source="p_source", source_mode=1,
+                          nt=nt, pml_size=4, sensor="random")
+    dt = float(pr["dt"].ravel()[0])
+    nsens = pr["sensor_mask_index"].size
+    path_in, whole, legs, ckpt = (str(tmp_path / n) for n in ("in.h5", "whole.h5", "legs.h5", "ckpt.h5"))
+    h5io.write_input_file(pr, path_in)
+    flags = dict(p_raw=1, p_max=1, p_rms=1, u_min=1, p_max_all=1, u_min_all=1, p_final=1, p_c=1, u_non_staggered_c=1, i_avg_c=1,
+                 period=1.0 / (1.0e6 * dt), harmonics=2, sampling_start=start)
+    fs = h5io.FileSolver(path_in, output=whole, **flags)
+    fs.run(nt)
+    fs.finish()
+    fs.write_output(whole)
+    fs.close()
+    a = h5io.FileSolver(path_in, output=legs, **flags)
+    a.run(split)
+    a.write_checkpoint(ckpt)
+    a.close()
+    c = u.describe(ckpt)
+    assert u.check_kwave_conventions(c, "checkpoint") == []
+    names = {n.lstrip("/") for n in c["datasets"]}
+    state = {"p", "rhox", "rhoy", "rhoz", "ux_sgx", "uy_sgy", "uz_sgz", "t_index", "Nx", "Ny", "Nz"}
+    temps = {f"Temp_{s}_{k}" for s in ("p_c", "ux_non_staggered_c", "uy_non_staggered_c", "uz_non_staggered_c") for k in (1, 2)} | \
+            {"Temp_Ix_avg_c", "Temp_Iy_avg_c", "Temp_Iz_avg_c"}
+    assert names == state | temps, sorted(names ^ (state | temps))
+    assert c["datasets"]["/Temp_p_c_1"]["dims"] == (1, 1, nsens * 2 * 2)  # complex coefficients x harmonics
+    assert c["datasets"]["/Temp_Ix_avg_c"]["dims"] == (1, 1, nsens)
+    o = u.describe(legs)
+    assert u.check_kwave_conventions(o, "output") == []
+    assert int(h5io.read_dataset(legs, "t_index").ravel()[0]) == split
+    for name, dims in (("p_max", (1, 1, nsens)), ("p_rms", (1, 1, nsens)), ("ux_min", (1, 1, nsens)), ("p_max_all", (16, 24, 32)),
+                       ("uz_min_all", (16, 24, 32)), ("Ix_avg_c", (1, 1, nsens))):
+        assert o["datasets"]["/" + name]["dims"] == dims, name
+    # the flushed aggregates are accumulators: the maximum so far is below the final one somewhere, the rms dataset holds a
+    # plain sum of squares (scaled and rooted only at the end)
+    assert np.all(h5io.read_dataset(legs, "p_max") <= h5io.read_dataset(whole, "p_max"))
+    assert not np.array_equal(h5io.read_dataset(legs, "p_rms"), h5io.read_dataset(whole, "p_rms"))
+    assert h5io.read_dataset(legs, "p").shape[-2] == nt - start  # series dataset at its final extent, rows so far filled
+    b = h5io.FileSolver(path_in, output=legs, reopen_output=True, **flags)
+    b.read_checkpoint(ckpt)
+    assert b.t == split
+    b.run(nt)
+    b.finish()
+    b.write_output(legs)
+    b.close()
+    for name in ("p", "p_max", "p_rms", "ux_min", "uy_min", "p_max_all", "ux_min_all", "p_final", "p_c", "ux_non_staggered_c",
+                 "uz_non_staggered_c", "Ix_avg_c", "Iy_avg_c", "Iz_avg_c", "t_index"):
+        x, y = h5io.read_dataset(legs, name), h5io.read_dataset(whole, name)
+        assert x.shape == y.shape and np.array_equal(x, y), name
+    # a checkpoint in the reference's layout needs the output file of its run
+    d = h5io.FileSolver(path_in, **flags)
+    with pytest.raises(Exception, match="re-open"):
+        d.read_checkpoint(ckpt)
+    d.close()

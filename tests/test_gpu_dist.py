@@ -199,6 +199,8 @@ def test_config4_slab_at_full_size(orc, syn, tmp_path, world, backend, dims):
     if backend == "p2p-threads":
         cmd = [sys.executable, os.path.join(HERE, "mock_ranks_worker.py"), "--ranks", str(world), "--dims", *map(str, dims),
                "--steps", str(steps), "--source", "p0", "--pml", "10", "--per-rank", "--out", out, "--transport", "p2p"]
+    if backend == "p2p-threads":
+        env["GPU_MAX_HW_QUEUES"] = str(4 * world)  # a hardware queue per stream of every thread-rank (see the many-ranks test)
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900, env=env)
     assert r.returncode == 0, r.stdout[-4000:]
     parts = [np.load(f"{out}.rank{k}.npz") for k in range(world)]
@@ -356,8 +358,11 @@ def test_native_exchange_with_many_ranks_on_one_gpu(orc, syn, tmp_path, ranks, d
     cmd = [sys.executable, os.path.join(HERE, "mock_ranks_worker.py"), "--ranks", str(ranks), "--dims", *map(str, dims),
            "--steps", str(steps), "--source", source, "--mode", str(mode), "--out", out] + \
           (["--rccl-library", MOCK] if transport == "mock" else ["--transport", "p2p"])
-    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600,
-                       env=dict(os.environ, OMP_NUM_THREADS="2", **env))
+    # p2p with thread-ranks: a rank's exchange kernel waits for the other ranks' while it runs, so no other rank's stream may
+    # sit behind it in a hardware queue.  One process per GPU has its three streams on the runtime's four queues; here
+    # `ranks` solvers share one process, so the runtime is asked for a queue per stream
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300,
+                       env=dict(os.environ, OMP_NUM_THREADS="2", GPU_MAX_HW_QUEUES=str(4 * ranks), **env))
     assert r.returncode == 0, r.stdout[-4000:]
     res = np.load(out)
     nx, ny, nz = dims

@@ -16,9 +16,9 @@ SRC = os.path.join(ROOT, "k-wave-fluid-cuda_amd", "csrc", "kw_fused.hip")
 def main():
     extra = sys.argv[1:]
     out = os.environ.get("KW_ISA_OUT", "/tmp/kw_fused_isa.s")
-    # the file is built in three passes (KW_FUSED_TU = 0, 1, 2: see its header); all three are listed
+    # the file is built in five passes (KW_FUSED_TU = 0 ... 4: see its header); all are listed
     procs, outs = [], []
-    for tu in (0, 1, 2):
+    for tu in (0, 1, 2, 3, 4):
         o = f"{out}.tu{tu}"
         outs.append(o)
         procs.append(subprocess.Popen(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize",

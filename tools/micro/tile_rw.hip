@@ -25,8 +25,21 @@ __global__ __launch_bounds__(256) void k_flat(float4* p, size_t n4)
 
 // MODE: 0 read+write, 1 read only, 2 write only.  AX: 1 lines along y (stride P), 2 lines along z (stride plane).
 // block = 16 lanes x TJ threads per line; thread holds R rows (line length L = TJ * R); VEC complex per lane.
-template<int TJ, int R, int VEC, int MODE, int AX, bool YFAST> __global__ __launch_bounds__(16 * TJ) void k_tile(float2* a, Geo g, float* sink)
+// one float4 per thread, in place (dst == src) or as a copy
+__global__ __launch_bounds__(256) void k_flat1(const float4* __restrict__ src, float4* __restrict__ dst, size_t n4)
 {
+  const size_t e = static_cast<size_t>(blockIdx.x) * 256 + threadIdx.x;
+  if (e < n4) { float4 v = src[e]; v.x += 1.f; dst[e] = v; }
+}
+__global__ __launch_bounds__(256) void k_flat1_inplace(float4* p, size_t n4)
+{
+  const size_t e = static_cast<size_t>(blockIdx.x) * 256 + threadIdx.x;
+  if (e < n4) { float4 v = p[e]; v.x += 1.f; p[e] = v; }
+}
+
+template<int TJ, int R, int VEC, int MODE, int AX, bool YFAST> __global__ __launch_bounds__(16 * TJ) void k_tile(float2* a, Geo g, float* sink, float2* b = nullptr)
+{
+  float2* const dstp = (b != nullptr) ? b : a;
   typedef float vf __attribute__((ext_vector_type(2 * VEC)));
   const int c = threadIdx.x % 16, j = threadIdx.x / 16;
   unsigned bx = blockIdx.x, by = blockIdx.y;
@@ -55,7 +68,7 @@ template<int TJ, int R, int VEC, int MODE, int AX, bool YFAST> __global__ __laun
   else
   {
 #pragma unroll
-    for (int n = 0; n < R; n++) { v[n][0] += 1.f; *reinterpret_cast<vf*>(a + base + static_cast<size_t>(n) * TJ * stride) = v[n]; }
+    for (int n = 0; n < R; n++) { v[n][0] += 1.f; *reinterpret_cast<vf*>(dstp + base + static_cast<size_t>(n) * TJ * stride) = v[n]; }
   }
 }
 
@@ -83,38 +96,47 @@ int main(int argc, char** argv)
   CHECK(hipMalloc(&sink, 64));
   printf("grid %u^3, rows of %u complex\n", n, Pbase);
   // plane pad (elements) and row pad
-  const unsigned rowpads[] = { 0, 16 };
-  const unsigned planepads[] = { 0, 16, 48, 80, 272, 1040 };
+  const unsigned rowpads[] = { 0 };
+  const unsigned planepads[] = { 0, 16 };
   for (unsigned rp : rowpads)
     for (unsigned pp : planepads)
     {
       Geo g{ Pbase + rp, n, n, (Pbase + rp) * n + pp };
       const size_t elems = static_cast<size_t>(g.plane) * n + 4096;
-      float2* a;
+      float2 *a, *b2;
       CHECK(hipMalloc(&a, elems * sizeof(float2)));
       CHECK(hipMemset(a, 0, elems * sizeof(float2)));
+      CHECK(hipMalloc(&b2, elems * sizeof(float2)));
+      CHECK(hipMemset(b2, 0, elems * sizeof(float2)));
       const double bytes = 2.0 * Pbase * n * n * 8.0; // useful bytes read + written
       auto rep = [&](const char* name, float ms, double b) { printf("  rowpad %3u planepad %4u  %-34s %8.1f us  %6.2f TB/s\n", rp, pp, name, ms * 1e3, b / ms / 1e9); };
       if (pp == 0)
       {
         const size_t n4 = static_cast<size_t>(g.plane) * n / 2;
         rep("flat float4 in place", time_ms([&] { hipLaunchKernelGGL(k_flat, dim3((n4 + 4095) / 4096), dim3(256), 0, 0, reinterpret_cast<float4*>(a), n4); }), 2.0 * n4 * 16);
+        rep("flat 1 float4/thread in place", time_ms([&] { hipLaunchKernelGGL(k_flat1_inplace, dim3((n4 + 255) / 256), dim3(256), 0, 0, reinterpret_cast<float4*>(a), n4); }), 2.0 * n4 * 16);
+        rep("flat 1 float4/thread copy a->b", time_ms([&] { hipLaunchKernelGGL(k_flat1, dim3((n4 + 255) / 256), dim3(256), 0, 0, reinterpret_cast<const float4*>(a), reinterpret_cast<float4*>(b2), n4); }), 2.0 * n4 * 16);
         // y lines
         const dim3 gy(Pbase / 16, n);
-        rep("y 16col x512, 256thr r+w", time_ms([&] { hipLaunchKernelGGL((k_tile<16, 32, 1, 0, 1, false>), gy, dim3(256), 0, 0, a, g, sink); }), bytes);
-        rep("y 16col x512, 512thr r+w", time_ms([&] { hipLaunchKernelGGL((k_tile<32, 16, 1, 0, 1, false>), gy, dim3(512), 0, 0, a, g, sink); }), bytes);
-        rep("y 32col x512, 512thr r+w", time_ms([&] { hipLaunchKernelGGL((k_tile<32, 16, 2, 0, 1, false>), dim3(Pbase / 32, n), dim3(512), 0, 0, a, g, sink); }), bytes);
-        rep("y 16col read only", time_ms([&] { hipLaunchKernelGGL((k_tile<16, 32, 1, 1, 1, false>), gy, dim3(256), 0, 0, a, g, sink); }), bytes / 2);
-        rep("y 16col write only", time_ms([&] { hipLaunchKernelGGL((k_tile<16, 32, 1, 2, 1, false>), gy, dim3(256), 0, 0, a, g, sink); }), bytes / 2);
+        rep("y 16col x512, 256thr a->b", time_ms([&] { hipLaunchKernelGGL((k_tile<16, 32, 1, 0, 1, false>), gy, dim3(256), 0, 0, a, g, sink, b2); }), bytes);
+        rep("y 16col x512, 128thr(8/line) r+w", time_ms([&] { hipLaunchKernelGGL((k_tile<8, 64, 1, 0, 1, false>), gy, dim3(128), 0, 0, a, g, sink, (float2*)nullptr); }), bytes);
+        rep("y 16col x512, 1024thr(64/line) r+w", time_ms([&] { hipLaunchKernelGGL((k_tile<64, 8, 1, 0, 1, false>), gy, dim3(1024), 0, 0, a, g, sink, (float2*)nullptr); }), bytes);
+        rep("y 16col x512, 256thr r+w", time_ms([&] { hipLaunchKernelGGL((k_tile<16, 32, 1, 0, 1, false>), gy, dim3(256), 0, 0, a, g, sink, (float2*)nullptr); }), bytes);
+        rep("y 16col x512, 512thr r+w", time_ms([&] { hipLaunchKernelGGL((k_tile<32, 16, 1, 0, 1, false>), gy, dim3(512), 0, 0, a, g, sink, (float2*)nullptr); }), bytes);
+        rep("y 32col x512, 512thr r+w", time_ms([&] { hipLaunchKernelGGL((k_tile<32, 16, 2, 0, 1, false>), dim3(Pbase / 32, n), dim3(512), 0, 0, a, g, sink, (float2*)nullptr); }), bytes);
+        rep("y 16col read only", time_ms([&] { hipLaunchKernelGGL((k_tile<16, 32, 1, 1, 1, false>), gy, dim3(256), 0, 0, a, g, sink, (float2*)nullptr); }), bytes / 2);
+        rep("y 16col write only", time_ms([&] { hipLaunchKernelGGL((k_tile<16, 32, 1, 2, 1, false>), gy, dim3(256), 0, 0, a, g, sink, (float2*)nullptr); }), bytes / 2);
       }
       const dim3 gz(Pbase / 16, n);
-      rep("z 16col x512, 256thr r+w", time_ms([&] { hipLaunchKernelGGL((k_tile<16, 32, 1, 0, 2, false>), gz, dim3(256), 0, 0, a, g, sink); }), bytes);
-      rep("z 16col x512, 512thr r+w", time_ms([&] { hipLaunchKernelGGL((k_tile<32, 16, 1, 0, 2, false>), gz, dim3(512), 0, 0, a, g, sink); }), bytes);
-      rep("z 32col x512, 512thr r+w", time_ms([&] { hipLaunchKernelGGL((k_tile<32, 16, 2, 0, 2, false>), dim3(Pbase / 32, n), dim3(512), 0, 0, a, g, sink); }), bytes);
-      rep("z 16col 256thr r+w, ky fastest", time_ms([&] { hipLaunchKernelGGL((k_tile<16, 32, 1, 0, 2, true>), gz, dim3(256), 0, 0, a, g, sink); }), bytes);
-      rep("z 16col read only", time_ms([&] { hipLaunchKernelGGL((k_tile<16, 32, 1, 1, 2, false>), gz, dim3(256), 0, 0, a, g, sink); }), bytes / 2);
-      rep("z 16col write only", time_ms([&] { hipLaunchKernelGGL((k_tile<16, 32, 1, 2, 2, false>), gz, dim3(256), 0, 0, a, g, sink); }), bytes / 2);
+      rep("z 16col x512, 256thr r+w", time_ms([&] { hipLaunchKernelGGL((k_tile<16, 32, 1, 0, 2, false>), gz, dim3(256), 0, 0, a, g, sink, (float2*)nullptr); }), bytes);
+      rep("z 16col x512, 512thr r+w", time_ms([&] { hipLaunchKernelGGL((k_tile<32, 16, 1, 0, 2, false>), gz, dim3(512), 0, 0, a, g, sink, (float2*)nullptr); }), bytes);
+      rep("z 32col x512, 512thr r+w", time_ms([&] { hipLaunchKernelGGL((k_tile<32, 16, 2, 0, 2, false>), dim3(Pbase / 32, n), dim3(512), 0, 0, a, g, sink, (float2*)nullptr); }), bytes);
+      rep("z 16col x512, 256thr a->b", time_ms([&] { hipLaunchKernelGGL((k_tile<16, 32, 1, 0, 2, false>), gz, dim3(256), 0, 0, a, g, sink, b2); }), bytes);
+      rep("z 16col 256thr r+w, ky fastest", time_ms([&] { hipLaunchKernelGGL((k_tile<16, 32, 1, 0, 2, true>), gz, dim3(256), 0, 0, a, g, sink, (float2*)nullptr); }), bytes);
+      rep("z 16col read only", time_ms([&] { hipLaunchKernelGGL((k_tile<16, 32, 1, 1, 2, false>), gz, dim3(256), 0, 0, a, g, sink, (float2*)nullptr); }), bytes / 2);
+      rep("z 16col write only", time_ms([&] { hipLaunchKernelGGL((k_tile<16, 32, 1, 2, 2, false>), gz, dim3(256), 0, 0, a, g, sink, (float2*)nullptr); }), bytes / 2);
       CHECK(hipFree(a));
+      CHECK(hipFree(b2));
     }
   return 0;
 }
