@@ -31,6 +31,7 @@
 // ---- P2P transport: shared definitions --------------------------------------------------------------------------------
 constexpr int      KW_P2P_MAX_RANKS = 16;
 constexpr int      KW_P2P_NB_MAX    = 8;   // blocks per peer (kw_tuning::p2p_blocks_per_peer)
+constexpr int      KW_P2P_SELF_BLOCKS = 64; // blocks that copy the rank's own chunk (local HBM: no link to wait for)
 constexpr int      KW_P2P_NBUF      = 9;   // s[3], t[3], r[3] of the fused pipeline: every buffer an exchange may land in
 constexpr uint32_t KW_P2P_MAGIC     = 0x6b775032u; // "kwP2"
 // flag words of one rank (uint32 epochs, written by the peers): credit[slot][sender], full[slot][sender][block]
@@ -207,8 +208,9 @@ uint64_t host_id()
 }
 
 // ---- the P2P exchange kernel ----------------------------------------------------------------------------------------
-// Grid: nranks groups of nb blocks.  Group g works for peer (rank + 1 + g) % nranks; the last group is the rank's own
-// chunk (a local copy).  A peer group runs one rendezvous with its peer, symmetric on both sides:
+// Grid: nranks - 1 peer groups of nb blocks, then the rank's own chunk (a local copy at HBM speed, KW_P2P_SELF_BLOCKS
+// blocks).  Group g works for peer (rank + 1 + g) % nranks.  A peer group runs one rendezvous with its peer, symmetric on
+// both sides:
 //
 //   1. credit   block 0 tells the peer "my receive buffers of exchange (slot, epoch) may be written": this kernel starts
 //               only after the compute stream's work up to start(slot) — i.e. after the last reader of what the buffer
@@ -273,10 +275,14 @@ __device__ __forceinline__ void p2p_fail(uint32_t* status, uint32_t code, uint32
 
 __global__ __launch_bounds__(256) void k_p2p_exchange(p2p_args a)
 {
-  const uint32_t g = blockIdx.x / a.nb, b = blockIdx.x % a.nb;
+  const uint32_t npeer = (a.nranks - 1u) * a.nb; // blocks of the peer groups; the rest copy the rank's own chunk
+  const bool     self  = blockIdx.x >= npeer;
+  const uint32_t g = self ? a.nranks - 1u : blockIdx.x / a.nb;
+  const uint32_t b = self ? blockIdx.x - npeer : blockIdx.x % a.nb;
+  const uint32_t parts = self ? gridDim.x - npeer : a.nb;
   const uint32_t peer = (a.rank + 1u + g) % a.nranks;
   __shared__ uint32_t ok;
-  if (peer == a.rank || a.emulate_bytes_per_tick > 0.f)
+  if (self || a.emulate_bytes_per_tick > 0.f)
   { // own chunk — or, emulating, the chunk of a peer that is not there: a local copy paced like a link
     const uint64_t t0 = wall_clock64();
     uint64_t total = 0;
@@ -284,10 +290,10 @@ __global__ __launch_bounds__(256) void k_p2p_exchange(p2p_args a)
     {
       const p2p_piece& pc = a.piece[i];
       const uint64_t at = static_cast<uint64_t>(peer) * pc.stride + pc.offset;
-      p2p_copy(pc.recv_local + at, pc.send + at, pc.bytes, b, a.nb);
+      p2p_copy(pc.recv_local + at, pc.send + at, pc.bytes, b, parts);
       total += pc.bytes;
     }
-    if (peer != a.rank)
+    if (!self)
     { // the transfer takes latency + bytes / rate on the link to that peer, of which the copy above is a part
       const uint64_t need = a.emulate_latency_ticks + static_cast<uint64_t>(static_cast<float>(total) / a.emulate_bytes_per_tick);
       while (wall_clock64() - t0 < need) __builtin_amdgcn_s_sleep(32);
@@ -383,7 +389,7 @@ kw_status p2p_start(kw_ctx* ctx, kw_comm_state* st, int slot, const kw_comm_piec
     q.recv_off = off;
   }
   if (a.npieces == 0) return KW_OK;
-  hipLaunchKernelGGL(k_p2p_exchange, dim3(st->nranks * a.nb), dim3(256), 0, st->stream, a);
+  hipLaunchKernelGGL(k_p2p_exchange, dim3((st->nranks - 1) * a.nb + KW_P2P_SELF_BLOCKS), dim3(256), 0, st->stream, a);
   KW_LAUNCH_CHECK();
   return KW_OK;
 }
