@@ -116,9 +116,9 @@ typedef struct kw_tuning
   int32_t  side_array;          /* 1: x-Nyquist bins of an even-Nx grid live in a compact side array behind rows of
                                    exactly Nx/2 bins; 0: in the rows, padded to whole 16-bin tiles */
   int32_t  tail_chunks;         /* single GPU: the plane-local tail of a stage (y-inverse, x-inverse + epilogue, chained
-                                   x / y forward) runs per chunk of planes so that a chunk's spectra stay in the
-                                   Infinity Cache between those kernels; 0 = automatic (1 when all three scratch arrays
-                                   fit the cache anyway), n >= 1 = that many chunks */
+                                   x / y forward) runs per chunk of planes (a chunk's spectra stay in the Infinity
+                                   Cache between those kernels); 0 or 1 = whole grid (the default: measured within
+                                   +-2 % at 320^3 ... 512^3, profiles/r03_tail_chunks.txt), n = that many chunks */
   int32_t  split512;            /* 1: 512-point y / z lines as 2 x 256-point transforms; 0: 16 x 32-point kernels */
   int32_t  slab_pipeline;       /* 1: pipelined slab schedule (third buffer set, forward transposes started by the
                                    producing stage); 0: whole-array schedule */
@@ -127,6 +127,9 @@ typedef struct kw_tuning
                                    peer and array), 0 never, 1 always */
   int32_t  p2p_blocks_per_peer; /* P2P transport: workgroups that store to one peer (1..8) */
   float    p2p_timeout_s;       /* P2P transport: a rank that waits longer than this for a peer gives up (KW_ERR_COMM) */
+  int32_t  plane_kernels;       /* 1: grids with square planes of 32 / 64 / 128 points run each stage's tail (y-inverse,
+                                   x-inverse + epilogue, chained x / y forward) as ONE launch whose blocks take whole
+                                   z-planes; 0: the three-launch form of the larger grids */
 } kw_tuning;
 KW_API kw_status   kw_get_tuning(kw_ctx* ctx, kw_tuning* out);
 KW_API kw_status   kw_set_tuning(kw_ctx* ctx, const kw_tuning* tuning);

@@ -312,12 +312,12 @@ class Tuning(C.Structure):
     """kw_tuning of include/kwave_hip.h: every schedule parameter of the device library"""
     _fields_ = [("struct_bytes", C.c_uint32), ("side_array", C.c_int32), ("tail_chunks", C.c_int32), ("split512", C.c_int32),
                 ("slab_pipeline", C.c_int32), ("slab_chunks", C.c_int32), ("slab_batch", C.c_int32),
-                ("p2p_blocks_per_peer", C.c_int32), ("p2p_timeout_s", C.c_float)]
+                ("p2p_blocks_per_peer", C.c_int32), ("p2p_timeout_s", C.c_float), ("plane_kernels", C.c_int32)]
 
 
 def default_tuning() -> Tuning:
     """the library's defaults (what a fresh context reports through kw_get_tuning)"""
-    return Tuning(C.sizeof(Tuning), 1, 0, 1, 1, 1, -1, 4, 20.0)
+    return Tuning(C.sizeof(Tuning), 1, 0, 1, 1, 1, -1, 4, 20.0, 1)
 
 
 def make_tuning(spec=None) -> Tuning:

@@ -232,7 +232,7 @@ __device__ __forceinline__ bool p2p_wait_flag(const uint32_t* flag, uint32_t epo
   {
     const uint32_t v = __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     if (static_cast<int32_t>(v - epoch) >= 0) return true;
-    __builtin_amdgcn_s_sleep(16);
+    __builtin_amdgcn_s_sleep(64); // ~1.7 us between polls: the waiting wave leaves its SIMD to the compute kernels' waves
     if (wall_clock64() - t0 > timeout_ticks) return false;
   }
 }
@@ -296,7 +296,10 @@ __global__ __launch_bounds__(256) void k_p2p_exchange(p2p_args a)
     if (!self)
     { // the transfer takes latency + bytes / rate on the link to that peer, of which the copy above is a part
       const uint64_t need = a.emulate_latency_ticks + static_cast<uint64_t>(static_cast<float>(total) / a.emulate_bytes_per_tick);
-      while (wall_clock64() - t0 < need) __builtin_amdgcn_s_sleep(32);
+      __syncthreads();
+      if (threadIdx.x == 0)
+        while (wall_clock64() - t0 < need) __builtin_amdgcn_s_sleep(64); // one lane waits, as in the real rendezvous
+      __syncthreads();
     }
     return;
   }

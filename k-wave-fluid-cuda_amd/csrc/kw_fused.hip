@@ -44,6 +44,9 @@ kw_status kw_fused_xinv_density(int chain, int terms, kw_ctx* ctx, int ncomp, co
 kw_status kw_fused_xinv_other(int epi, int chain, kw_ctx* ctx, int ncomp, const void* xinv_args, uint32_t tile0, uint32_t ntiles);
 kw_status kw_fused_xinv_density_tail(int chain, int terms, kw_ctx* ctx, int ncomp, const void* xinv_args, uint32_t tile0, uint32_t ntiles);
 kw_status kw_fused_xinv_other_tail(int epi, int chain, kw_ctx* ctx, int ncomp, const void* xinv_args, uint32_t tile0, uint32_t ntiles);
+// whole-plane tiles (small grids, see k_xinv): tile0 / ntiles count z-planes; in passes 1 / 2
+kw_status kw_fused_xinv_density_plane(int chain, int terms, kw_ctx* ctx, int ncomp, const void* xinv_args, uint32_t tile0, uint32_t ntiles);
+kw_status kw_fused_xinv_other_plane(int epi, int chain, kw_ctx* ctx, int ncomp, const void* xinv_args, uint32_t tile0, uint32_t ntiles);
 
 namespace {
 
@@ -839,12 +842,14 @@ struct XfwdArgs
 // forward line FFT of this block's 16 complex lines (= 32 real rows) from the step-A registers v (valid for f < R2),
 // split into the two half-spectra and stored to rows tile_row0.. of `out`.  Called by every thread of the block; the
 // exchange buffer must be free on entry and is free again on exit (trailing barrier).
-template<int L, bool TAIL = false>
+// NLX: line pairs per block.  PLANE (the tile is a whole z-plane, see k_xinv): the half-spectrum rows go to the block's
+// plane buffer in LDS ([row][L / 2 + 1], `out`) instead of to the scratch array.
+template<int L, bool TAIL = false, int NLX = nl_x(L), bool PLANE = false>
 __device__ __forceinline__ void xfwd_tail(float2 (&v)[Fac<L>::R1], float2* lds, int c, int f,
                                           const float2* tw, float2* __restrict__ out, uint32_t P, uint32_t tile,
                                           uint32_t nrows = 0, uint32_t side_off = 0)
 {
-  using G = GeoX<L>;
+  using G = Geo<L, NLX>;
   constexpr int R1 = G::R1, R2 = G::R2, HALF = L / 2 + 1;
   if (ACT(R2, f))
   {
@@ -876,6 +881,12 @@ __device__ __forceinline__ void xfwd_tail(float2 (&v)[Fac<L>::R1], float2* lds, 
     const float2 zn = lds[cc * G::ZP + (k == 0 ? 0 : L - k)];
     const float2 xa = make_float2(0.5f * (zk.x + zn.x), 0.5f * (zk.y - zn.y));
     const float2 xb = make_float2(0.5f * (zk.y + zn.y), 0.5f * (zn.x - zk.x));
+    if (PLANE)
+    {
+      out[(2 * cc) * HALF + k]     = xa;
+      out[(2 * cc + 1) * HALF + k] = xb;
+      continue;
+    }
     const uint32_t r = tile_row0 + 2 * cc;
     // the x-Nyquist bin of a row goes to the side array N[row] when the pipeline keeps that column apart (tile_coord)
     const bool     ny_bin = (side_off != 0) && (k == L / 2);
@@ -938,16 +949,18 @@ struct XinvArgs
   const float2* mulx[3]; // per component: optional factor mulx[kx] applied to the rows before the inverse (ddx of the gradient)
   uint32_t      nrows;      // rows of the grid (ny * nz): bounds the partial last tile (TAIL kernels)
   uint32_t      side_off;   // element offset of the x-Nyquist side array in in[] / fout[] (0: none)
+  const float2* ymul[3];    // PLANE kernels: optional factor ymul[ky] applied to array i before its y-inverse (ddy of the gradient)
 };
 
 // standalone inverse of one array for this block's 32 rows; thread (c, f<R1) ends with x[f + R1*k2] of rows (2c, 2c+1)
-template<int L, int NGRP = 1, bool TAIL = false>
+// PLANE: the rows come from the block's plane buffer in LDS ([row][L / 2 + 1], `src`), where the y-inverse left them
+template<int L, int NGRP = 1, bool TAIL = false, int NLX = nl_x(L), bool PLANE = false>
 __device__ __forceinline__ void xinv_lines(const float2* __restrict__ src, uint32_t P, float2* lds, int c, int f,
                                            const float2* tw, float2 (&w)[Fac<L>::R2], uint32_t tile,
                                            const float2* __restrict__ mulx = nullptr, uint32_t nrows = 0,
                                            uint32_t side_off = 0)
 {
-  using G = GeoX<L>;
+  using G = Geo<L, NLX>;
   constexpr int R1 = G::R1, R2 = G::R2, HALF = L / 2 + 1;
   const uint32_t tile_row0 = tile * G::NL * 2;
   // all row loads of the tile are requested before the first one is consumed (a load-use loop would expose the memory
@@ -966,6 +979,12 @@ __device__ __forceinline__ void xinv_lines(const float2* __restrict__ src, uint3
       const int k  = e - cc * HALF;
       const uint32_t r = tile_row0 + 2 * cc;
       const uint32_t ra = TAIL ? min(r, nrows - 1u) : r, rb = TAIL ? min(r + 1u, nrows - 1u) : r + 1u;
+      if (PLANE)
+      {
+        A[it] = src[(2 * cc) * HALF + k];
+        B[it] = src[(2 * cc + 1) * HALF + k];
+        continue;
+      }
       const bool     ny_bin = (side_off != 0) && (k == L / 2); // the x-Nyquist bin lives in the side array N[row]
       A[it] = src[ny_bin ? side_off + ra : ra * P + k];
       B[it] = src[ny_bin ? side_off + rb : rb * P + k];
@@ -1017,16 +1036,122 @@ __device__ __forceinline__ void   f4put(float4& v, int k, float s)
 }
 
 
+// ---- small grids: a whole z-plane per block -------------------------------------------------------------------------------
+// When a half-spectrum plane [L][L / 2 + 1] (Nx == Ny == L <= 128) fits the LDS next to the x kernels' line buffers, the
+// block of an x-inverse + epilogue kernel takes a whole plane as its tile and does the plane's y transforms itself: the
+// y-inverse of every input array before its x-inverse, the y-forward of every chained array after its x-forward — same
+// small DFTs, same twiddles, same order of operations as k_ypass (bit-identical results), but the stage's tail is ONE
+// launch instead of three.  64^3 and 128^3 are bound by launches and by kernels that are over before the chip has filled
+// (13 kernels of 5-30 us per step): this takes six of them away and the spectra of a stage's tail never leave the CU.
+// plane buffer Y[ky][kx], kx < L / 2 + 1 (the x-Nyquist bin sits in its row here: no side array in LDS)
+template<int L> __device__ __forceinline__ void plane_load(float2* Y, const float2* __restrict__ src, uint32_t plane, uint32_t P,
+                                                           uint32_t side_off, const float2* __restrict__ mul, int threads)
+{ // rows plane*L .. of the scratch array (+ their side-array bins) -> Y, times mul[ky] where given (ddy of the gradient)
+  constexpr int HALF = L / 2 + 1;
+  const uint32_t row0 = plane * L;
+  if (side_off != 0)
+  { // rows of exactly L / 2 bins
+    for (int e = threadIdx.x; e < L * (L / 2); e += threads)
+    {
+      const int ky = e / (L / 2), k = e % (L / 2);
+      float2 v = src[(row0 + ky) * P + k];
+      if (mul != nullptr) v = cmulf(v, mul[ky]);
+      Y[ky * HALF + k] = v;
+    }
+    for (int ky = threadIdx.x; ky < L; ky += threads)
+    {
+      float2 v = src[side_off + row0 + ky];
+      if (mul != nullptr) v = cmulf(v, mul[ky]);
+      Y[ky * HALF + L / 2] = v;
+    }
+  }
+  else
+  {
+    for (int e = threadIdx.x; e < L * HALF; e += threads)
+    {
+      const int ky = e / HALF, k = e - ky * HALF;
+      float2 v = src[(row0 + ky) * P + k];
+      if (mul != nullptr) v = cmulf(v, mul[ky]);
+      Y[e] = v;
+    }
+  }
+}
+template<int L> __device__ __forceinline__ void plane_store(const float2* Y, float2* __restrict__ dst, uint32_t plane, uint32_t P,
+                                                            uint32_t side_off, int threads)
+{
+  constexpr int HALF = L / 2 + 1;
+  const uint32_t row0 = plane * L;
+  if (side_off != 0)
+  {
+    for (int e = threadIdx.x; e < L * (L / 2); e += threads)
+    {
+      const int ky = e / (L / 2), k = e % (L / 2);
+      dst[(row0 + ky) * P + k] = Y[ky * HALF + k];
+    }
+    for (int ky = threadIdx.x; ky < L; ky += threads) dst[side_off + row0 + ky] = Y[ky * HALF + L / 2];
+  }
+  else
+  {
+    for (int e = threadIdx.x; e < L * HALF; e += threads)
+    {
+      const int ky = e / HALF, k = e - ky * HALF;
+      dst[(row0 + ky) * P + k] = Y[e];
+    }
+  }
+}
+// in-place transform of the L / 2 + 1 columns of Y along y: the four-step of k_ypass with the plane buffer itself as the
+// exchange buffer.  (L / 2) * TPL threads: thread (c, j) of the main columns, then the first TPL threads once more for the
+// x-Nyquist column.  Y must be complete on entry (barrier before); complete again on exit (trailing barrier).
+template<int L, int DIR> __device__ __forceinline__ void plane_yfft(float2* Y, const float2* twl)
+{
+  using G = Geo<L, L / 2>;
+  constexpr int R1 = G::R1, R2 = G::R2, HALF = L / 2 + 1, TPL = G::TPL;
+#pragma unroll 1
+  for (int pass = 0; pass < 2; pass++)
+  {
+    const bool on = (pass == 0) || (threadIdx.x < TPL);
+    const int  c  = (pass == 0) ? static_cast<int>(threadIdx.x) % (L / 2) : L / 2;
+    const int  j  = (pass == 0) ? static_cast<int>(threadIdx.x) / (L / 2) : static_cast<int>(threadIdx.x);
+    if (on && ACT(R2, j))
+    { // step A on rows n1 * R2 + j; the results go back to the same cells (index k1 in place of n1)
+      float2 v[R1];
+#pragma unroll
+      for (int n1 = 0; n1 < R1; n1++) v[n1] = Y[(n1 * R2 + j) * HALF + c];
+      step_a<L, DIR>(v, j, twl);
+#pragma unroll
+      for (int k1 = 0; k1 < R1; k1++) Y[(k1 * R2 + j) * HALF + c] = v[k1];
+    }
+    lds_barrier();
+    float2 w[R2];
+    if (on && ACT(R1, j))
+    {
+#pragma unroll
+      for (int n2 = 0; n2 < R2; n2++) w[n2] = Y[(j * R2 + n2) * HALF + c];
+      Dft<R2, DIR>::run(w);
+    }
+    lds_barrier(); // every cell has been read before the natural-order results overwrite them
+    if (on && ACT(R1, j))
+    {
+#pragma unroll
+      for (int k2 = 0; k2 < R2; k2++) Y[(j + R1 * k2) * HALF + c] = w[k2];
+    }
+    lds_barrier();
+  }
+}
+constexpr bool plane_len(int L) { return L == 32 || L == 64 || L == 128; }
+
 // The inverse leaves each thread with x = f + R1*k2 of two rows — a 64-B-segment pattern.  The results are restaged
 // through LDS as a plain real tile [32 rows][L] and re-read as float4 in a row-contiguous mapping, so that every
 // epilogue access to the state / medium arrays is a 16-B-per-lane coalesced access.
 // (the 256-point density epilogue sits two registers above the 3-waves-per-SIMD step: ask the allocator for that step)
 // TERMS: compile-time value of a.terms for the density epilogue (one specialised kernel per pressure-term mode)
-template<int L, int EPI, bool CHAIN, int TERMS = 0, bool TAIL = false>
-__global__ __launch_bounds__(GeoX<L>::THREADS, (EPI == EPI_DENSITY && L == 256) ? 3 : big_line_waves(L)) void k_xinv(XinvArgs a)
+// PLANE: the tile is a whole z-plane (L / 2 line pairs) and the kernel does the plane's y transforms too — see above.
+template<int L, int EPI, bool CHAIN, int TERMS = 0, bool TAIL = false, bool PLANE = false>
+__global__ __launch_bounds__((Geo<L, PLANE ? L / 2 : nl_x(L)>::THREADS), (EPI == EPI_DENSITY && L == 256) ? 3 : big_line_waves(L)) void k_xinv(XinvArgs a)
 {
   constexpr int terms = TERMS;
-  using G = GeoX<L>;
+  constexpr int NLX = PLANE ? L / 2 : nl_x(L);
+  using G = Geo<L, NLX>;
   constexpr int R1 = G::R1, R2 = G::R2;
   constexpr int NA  = (EPI == EPI_DENSITY) ? 3 : (EPI == EPI_PSUM) ? 2 : 1;
   constexpr int RP  = L + 8;                       // real-tile row pitch (floats): conflict-free 4-B scatter
@@ -1035,7 +1160,8 @@ __global__ __launch_bounds__(GeoX<L>::THREADS, (EPI == EPI_DENSITY && L == 256) 
   static_assert((2 * G::NL * Q4) % G::THREADS == 0, "tile must divide evenly");
   __shared__ float2 lds[G::LDSX];
   __shared__ float2 twl[G::TWN];
-  load_twiddles<L>(twl, a.tw); // published by the first barrier of xinv_lines
+  __shared__ float2 Yp[PLANE ? L * (L / 2 + 1) : 1]; // PLANE: the plane's half-spectrum between its y and x transforms
+  load_twiddles<L>(twl, a.tw); // published by the first barrier of xinv_lines (PLANE: of the plane's y transform)
   float* ldsr = reinterpret_cast<float*>(lds);
   const int f = threadIdx.x % G::TPL;
   const int c = threadIdx.x / G::TPL;
@@ -1051,6 +1177,15 @@ __global__ __launch_bounds__(GeoX<L>::THREADS, (EPI == EPI_DENSITY && L == 256) 
   for (int i = 0; i < NA; i++)
   {
     float2 w[R2];
+    if constexpr (PLANE)
+    { // this array's plane: scratch -> LDS (x ddy[ky] for the y-gradient), inverse along y, then rows out of LDS
+      const uint32_t ia = (NA == 1) ? comp : i;
+      plane_load<L>(Yp, a.in[ia], tile, a.P, a.side_off, a.ymul[ia], G::THREADS);
+      lds_barrier();
+      plane_yfft<L, kInv>(Yp, twl);
+      xinv_lines<L, 1, false, NLX, true>(Yp, a.P, lds, c, f, twl, w, tile, (NA == 1) ? a.mulx[comp] : nullptr);
+    }
+    else
     xinv_lines<L, (EPI == EPI_DENSITY) ? 2 : 1, TAIL>(a.in[(NA == 1) ? comp : i], a.P, lds, c, f, twl, w, tile,
                                                        (NA == 1) ? a.mulx[comp] : nullptr, a.nrows, a.side_off); // ends with a barrier
     if (ACT(R1, f))
@@ -1331,6 +1466,14 @@ __global__ __launch_bounds__(GeoX<L>::THREADS, (EPI == EPI_DENSITY && L == 256) 
           v[n1] = make_float2(ldsr[(2 * c) * RP + n1 * R2c + f], ldsr[(2 * c + 1) * RP + n1 * R2c + f]);
       }
       lds_barrier(); // the real tile aliases the exchange buffer
+      if constexpr (PLANE)
+      { // rows into the plane buffer, forward along y, plane -> scratch (the consumer's z-pass comes next)
+        xfwd_tail<L, false, NLX, true>(v, lds, c, f, twl, Yp, a.P, tile);
+        plane_yfft<L, kFwd>(Yp, twl);
+        plane_store<L>(Yp, a.fout[(NA == 1) ? comp : jf], tile, a.P, a.side_off, G::THREADS);
+        lds_barrier(); // the plane buffer is reused by the second chained array
+      }
+      else
       xfwd_tail<L, TAIL>(v, lds, c, f, twl, a.fout[(NA == 1) ? comp : jf], a.P, tile, a.nrows, a.side_off);
     }
   }
@@ -1802,7 +1945,7 @@ template<int MODE> kw_status launch_zfused(kw_ctx* ctx, int narr, ZArgs a)
 // main pass: the full tiles go to the pass that holds this epilogue's kernels, the partial last tile of the grid (if any;
 // only ever in the last chunk: chunks are whole tiles otherwise) to the pass that holds their masked forms
 template<int EPI, bool CHAIN = false, int TERMS = 0>
-kw_status launch_xinv(kw_ctx* ctx, int ncomp, XinvArgs a, uint32_t z0 = 0, uint32_t nzc = 0)
+kw_status launch_xinv(kw_ctx* ctx, int ncomp, XinvArgs a, uint32_t z0 = 0, uint32_t nzc = 0, bool plane = false)
 {
   const kw_constants& c = ctx->c;
   static const char* const names[5][2] = { { "k_xinv_store", "k_xinv_store" }, { "k_xinv_velocity", "k_xinv_velocity_chain" },
@@ -1814,6 +1957,9 @@ kw_status launch_xinv(kw_ctx* ctx, int ncomp, XinvArgs a, uint32_t z0 = 0, uint3
   a.P  = ctx->fused.P;
   a.side_off = ctx->fused.side_off;
   a.nrows = c.ny * c.nz;
+  if (plane) // one block per z-plane; the kernel does the plane's y transforms as well
+    return EPI == EPI_DENSITY ? kw_fused_xinv_density_plane(CHAIN ? 1 : 0, TERMS, ctx, ncomp, &a, z0, nzc ? nzc : c.nz)
+                              : kw_fused_xinv_other_plane(EPI, CHAIN ? 1 : 0, ctx, ncomp, &a, z0, nzc ? nzc : c.nz);
   const uint32_t rows_per_tile = 2u * static_cast<uint32_t>(nl_x(c.nx));
   const uint32_t rows = c.ny * (nzc ? nzc : c.nz), full = rows / rows_per_tile;
   const uint32_t tile0 = z0 * c.ny / rows_per_tile; // chunked launches start on tile boundaries (plane_local_tail)
@@ -1836,6 +1982,30 @@ kw_status launch_xinv_impl(kw_ctx* ctx, int ncomp, XinvArgs a, uint32_t tile0, u
 #undef M
   return KW_OK;
 }
+#if KW_FUSED_TU == 1 || KW_FUSED_TU == 2
+template<int EPI, bool CHAIN, int TERMS>
+kw_status launch_xinv_plane_impl(kw_ctx* ctx, int ncomp, XinvArgs a, uint32_t plane0, uint32_t nplanes)
+{
+  a.tile0 = plane0;
+  const dim3 grid(nplanes, ncomp, 1);
+#define MP(LEN) LAUNCH((k_xinv<LEN, EPI, CHAIN, TERMS, false, true>), grid, dim3((Geo<LEN, LEN / 2>::THREADS)), a)
+  switch (ctx->c.nx)
+  {
+#if !defined(KW_FUSED_ONLY) || KW_FUSED_ONLY == 32
+    case 32: MP(32); break;
+#endif
+#if !defined(KW_FUSED_ONLY) || KW_FUSED_ONLY == 64
+    case 64: MP(64); break;
+#endif
+#if !defined(KW_FUSED_ONLY) || KW_FUSED_ONLY == 128
+    case 128: MP(128); break;
+#endif
+    default: kw_set_error("fused pipeline: no whole-plane kernels for rows of %u", ctx->c.nx); return KW_ERR_INVALID;
+  }
+#undef MP
+  return KW_OK;
+}
+#endif
 #endif
 
 #if KW_FUSED_TU == 0
@@ -2123,6 +2293,18 @@ kw_status plane_local_tail(kw_ctx* ctx, int narr, int ncomp, const XinvArgs& x, 
 {
   auto& f = ctx->fused;
   const kw_constants& c = ctx->c;
+  if (f.plane)
+  { // small grids: one launch — every block takes a z-plane and does its y transforms around the x kernels' work
+    XinvArgs xp = x;
+    for (int i = 0; i < narr; i++)
+    {
+      xp.in[i]   = yin ? yin[i] : f.s[i];
+      xp.ymul[i] = ymul ? ymul[i] : nullptr;
+    }
+    KW_TRY((launch_xinv<EPI, CHAIN, TERMS>(ctx, ncomp, xp, 0, 0, true)));
+    if (CHAIN) f.y_done = nchain;
+    return KW_OK;
+  }
   uint32_t nch = static_cast<uint32_t>(ctx->tuning.tail_chunks > 0 ? ctx->tuning.tail_chunks : 1);
   while (nch > 1 && (c.nz % nch != 0 || (c.nz / nch * c.ny) % (2 * nl_x(c.nx)) != 0)) nch--;
   const uint32_t nzc = c.nz / nch;
@@ -2350,6 +2532,9 @@ kw_status create_impl(kw_ctx* ctx, void* const s[3], void* const t[3])
     KW_HIP(hipStreamSynchronize(ctx->stream));
   }
   f.split512 = (ctx->tuning.split512 != 0);
+  // whole-plane x kernels (k_xinv PLANE): square planes of 32 / 64 / 128, one GPU, 3-D
+  f.plane = (ctx->tuning.plane_kernels != 0) && !f.slab && !f.two_d && c.nx == c.ny && plane_len(static_cast<int>(c.nx)) &&
+            supported_len(c.nx);
   f.ready = true;
   return KW_OK;
 }
@@ -2378,7 +2563,40 @@ kw_status kw_fused_xinv_density_tail(int chain, int terms, kw_ctx* ctx, int ncom
     default: kw_set_error("fused pipeline: no density epilogue for chain = %d, terms = %d", chain, terms); return KW_ERR_INVALID;
   }
 }
+#if KW_FUSED_TU == 1
+kw_status kw_fused_xinv_density_plane(int chain, int terms, kw_ctx* ctx, int ncomp, const void* xinv_args, uint32_t tile0, uint32_t ntiles)
+{
+  const XinvArgs& a = *static_cast<const XinvArgs*>(xinv_args);
+  switch (2 * terms + chain)
+  {
+    case 0: return launch_xinv_plane_impl<EPI_DENSITY, false, 0>(ctx, ncomp, a, tile0, ntiles);
+    case 2: return launch_xinv_plane_impl<EPI_DENSITY, false, 1>(ctx, ncomp, a, tile0, ntiles);
+    case 3: return launch_xinv_plane_impl<EPI_DENSITY, true, 1>(ctx, ncomp, a, tile0, ntiles);
+    case 4: return launch_xinv_plane_impl<EPI_DENSITY, false, 2>(ctx, ncomp, a, tile0, ntiles);
+    case 5: return launch_xinv_plane_impl<EPI_DENSITY, true, 2>(ctx, ncomp, a, tile0, ntiles);
+    case 6: return launch_xinv_plane_impl<EPI_DENSITY, false, 3>(ctx, ncomp, a, tile0, ntiles);
+    case 7: return launch_xinv_plane_impl<EPI_DENSITY, true, 3>(ctx, ncomp, a, tile0, ntiles);
+    default: kw_set_error("fused pipeline: no density epilogue for chain = %d, terms = %d", chain, terms); return KW_ERR_INVALID;
+  }
+}
+#endif
 #elif KW_FUSED_TU == 2 || KW_FUSED_TU == 4
+#if KW_FUSED_TU == 2
+kw_status kw_fused_xinv_other_plane(int epi, int chain, kw_ctx* ctx, int ncomp, const void* xinv_args, uint32_t tile0, uint32_t ntiles)
+{
+  const XinvArgs& a = *static_cast<const XinvArgs*>(xinv_args);
+  switch (2 * epi + chain)
+  {
+    case 2 * EPI_STORE: return launch_xinv_plane_impl<EPI_STORE, false, 0>(ctx, ncomp, a, tile0, ntiles);
+    case 2 * EPI_VELOCITY: return launch_xinv_plane_impl<EPI_VELOCITY, false, 0>(ctx, ncomp, a, tile0, ntiles);
+    case 2 * EPI_VELOCITY + 1: return launch_xinv_plane_impl<EPI_VELOCITY, true, 0>(ctx, ncomp, a, tile0, ntiles);
+    case 2 * EPI_INITVEL: return launch_xinv_plane_impl<EPI_INITVEL, false, 0>(ctx, ncomp, a, tile0, ntiles);
+    case 2 * EPI_PSUM: return launch_xinv_plane_impl<EPI_PSUM, false, 0>(ctx, ncomp, a, tile0, ntiles);
+    case 2 * EPI_PSUM + 1: return launch_xinv_plane_impl<EPI_PSUM, true, 0>(ctx, ncomp, a, tile0, ntiles);
+    default: kw_set_error("fused pipeline: no epilogue %d with chain = %d", epi, chain); return KW_ERR_INVALID;
+  }
+}
+#endif
 #if KW_FUSED_TU == 2
 kw_status kw_fused_xinv_other(int epi, int chain, kw_ctx* ctx, int ncomp, const void* xinv_args, uint32_t tile0, uint32_t ntiles)
 #else

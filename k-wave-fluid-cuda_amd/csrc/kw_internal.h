@@ -33,6 +33,7 @@ inline kw_tuning kw_tuning_defaults()
   t.slab_batch          = -1;
   t.p2p_blocks_per_peer = 4;
   t.p2p_timeout_s       = 20.f;
+  t.plane_kernels       = 1;
   return t;
 }
 #define KW_COMM_SLOTS 32 /* 2 directions x 3 arrays x KW_XCHUNKS_MAX plane chunks, + spare (z-shift staging) */
@@ -58,6 +59,7 @@ struct kw_ctx
   struct fused_plan
   {
     bool     ready = false;
+    bool     plane = false;                        // small square planes: the x-inverse kernels take whole z-planes and do the y transforms too
     bool     split512 = true;                      // 512-point y / z lines as 2 x 256 (A/B knob against the 16 x 32 kernels)
     uint32_t nxm = 0;                              // columns kept in the rows: nx/2+1, or nx/2 when the x-Nyquist column is kept apart
     uint32_t side_off = 0;                         // element offset of that column's compact array N[z][y] in s[] (0: none)

@@ -137,3 +137,29 @@ def test_bad_inputs_are_reported_not_computed(syn):
         gpu(bad, p_raw=1).run(1)
     with pytest.raises(TypeError):
         gpu(pr, no_such_option=1)
+
+
+@pytest.mark.parametrize("dims", [(32, 32, 32), (64, 64, 64), (128, 128, 128), (64, 64, 16), (32, 32, 48)])
+@pytest.mark.parametrize("medium", ["111", "100", "001"])
+def test_whole_plane_kernels_give_the_bits_of_the_three_launch_form(syn, dims, medium):
+    """Grids with square planes of 32 / 64 / 128 points run a stage's tail as ONE launch whose blocks take whole z-planes and
+    do the y transforms themselves (k_xinv PLANE): same small DFTs, twiddles and operation order as the separate y-passes,
+    so every field must come out bit-identical to kw_tuning::plane_kernels = 0 — heterogeneous absorbing nonlinear, linear
+    lossless (equation of state inside the density kernel) and homogeneous absorbing media, with a p0 and a velocity source."""
+    import kwave_amd  # noqa: F401
+    from kwave_amd.solver import HostSolver
+    nx, ny, nz = dims
+    het, nonlin, absorb = (c == "1" for c in medium)
+    for source, mode in (("p0", 0), ("u_source", 2)):
+        pr = syn.make_problem(nx, ny, nz, heterogeneous=het, nonlinear=nonlin, absorbing=absorb, source=source, source_mode=mode,
+                              source_many=1 if source != "p0" else 0, nt=16, pml_size=4, sensor="random")
+        out = {}
+        for plane in (1, 0):
+            g = HostSolver(pr, p_raw=1, p_max=1, tuning={"plane_kernels": plane})
+            g.run(12)
+            g.finish()
+            out[plane] = {f: g.field(f) for f in ("p", "ux", "uy", "uz", "rhox", "rhoy", "rhoz")}
+            out[plane]["series"] = g.stream("p")
+            g.close()
+        for f, v in out[1].items():
+            assert np.abs(v).max() > 0 and np.array_equal(v, out[0][f]), (f, source)
