@@ -127,7 +127,7 @@ typedef struct kw_tuning
                                    peer and array), 0 never, 1 always */
   int32_t  p2p_blocks_per_peer; /* P2P transport: workgroups that store to one peer (1..8) */
   float    p2p_timeout_s;       /* P2P transport: a rank that waits longer than this for a peer gives up (KW_ERR_COMM) */
-  int32_t  plane_kernels;       /* 1: grids with square planes of 32 / 64 / 128 points run each stage's tail (y-inverse,
+  int32_t  plane_kernels;       /* 1: grids with square planes of 32 / 64 points run each stage's tail (y-inverse,
                                    x-inverse + epilogue, chained x / y forward) as ONE launch whose blocks take whole
                                    z-planes; 0: the three-launch form of the larger grids */
 } kw_tuning;

@@ -1037,12 +1037,12 @@ __device__ __forceinline__ void   f4put(float4& v, int k, float s)
 
 
 // ---- small grids: a whole z-plane per block -------------------------------------------------------------------------------
-// When a half-spectrum plane [L][L / 2 + 1] (Nx == Ny == L <= 128) fits the LDS next to the x kernels' line buffers, the
+// When a half-spectrum plane [L][L / 2 + 1] (Nx == Ny == L <= 64) fits the LDS next to the x kernels' line buffers, the
 // block of an x-inverse + epilogue kernel takes a whole plane as its tile and does the plane's y transforms itself: the
 // y-inverse of every input array before its x-inverse, the y-forward of every chained array after its x-forward — same
 // small DFTs, same twiddles, same order of operations as k_ypass (bit-identical results), but the stage's tail is ONE
-// launch instead of three.  64^3 and 128^3 are bound by launches and by kernels that are over before the chip has filled
-// (13 kernels of 5-30 us per step): this takes six of them away and the spectra of a stage's tail never leave the CU.
+// launch instead of three.  32^3 and 64^3 are bound by launches and by kernels that are over before the chip has filled
+// (13 kernels of 5-15 us per step): this takes six of them away and the spectra of a stage's tail never leave the CU.
 // plane buffer Y[ky][kx], kx < L / 2 + 1 (the x-Nyquist bin sits in its row here: no side array in LDS)
 template<int L> __device__ __forceinline__ void plane_load(float2* Y, const float2* __restrict__ src, uint32_t plane, uint32_t P,
                                                            uint32_t side_off, const float2* __restrict__ mul, int threads)
@@ -1138,7 +1138,8 @@ template<int L, int DIR> __device__ __forceinline__ void plane_yfft(float2* Y, c
     lds_barrier();
   }
 }
-constexpr bool plane_len(int L) { return L == 32 || L == 64 || L == 128; }
+// (128: one 1024-thread block per CU, held to 128 VGPRs — measured 14 % slower than the three-launch form; 32 and 64 gain)
+constexpr bool plane_len(int L) { return L == 32 || L == 64; }
 
 // The inverse leaves each thread with x = f + R1*k2 of two rows — a 64-B-segment pattern.  The results are restaged
 // through LDS as a plain real tile [32 rows][L] and re-read as float4 in a row-contiguous mapping, so that every
@@ -1997,9 +1998,6 @@ kw_status launch_xinv_plane_impl(kw_ctx* ctx, int ncomp, XinvArgs a, uint32_t pl
 #if !defined(KW_FUSED_ONLY) || KW_FUSED_ONLY == 64
     case 64: MP(64); break;
 #endif
-#if !defined(KW_FUSED_ONLY) || KW_FUSED_ONLY == 128
-    case 128: MP(128); break;
-#endif
     default: kw_set_error("fused pipeline: no whole-plane kernels for rows of %u", ctx->c.nx); return KW_ERR_INVALID;
   }
 #undef MP
@@ -2297,9 +2295,11 @@ kw_status plane_local_tail(kw_ctx* ctx, int narr, int ncomp, const XinvArgs& x, 
   { // small grids: one launch — every block takes a z-plane and does its y transforms around the x kernels' work
     XinvArgs xp = x;
     for (int i = 0; i < narr; i++)
-    {
-      xp.in[i]   = yin ? yin[i] : f.s[i];
-      xp.ymul[i] = ymul ? ymul[i] : nullptr;
+    { // y-pass i reads yin[i] (times ymul[i]) and leaves its result where some x-inverse reads it: that one takes both over
+      const float2* from = yin ? yin[i] : f.s[i];
+      const float2* to   = yout ? yout[i] : f.s[i];
+      for (int k = 0; k < 3; k++)
+        if (x.in[k] == to) { xp.in[k] = from; xp.ymul[k] = ymul ? ymul[i] : nullptr; }
     }
     KW_TRY((launch_xinv<EPI, CHAIN, TERMS>(ctx, ncomp, xp, 0, 0, true)));
     if (CHAIN) f.y_done = nchain;
@@ -2532,9 +2532,15 @@ kw_status create_impl(kw_ctx* ctx, void* const s[3], void* const t[3])
     KW_HIP(hipStreamSynchronize(ctx->stream));
   }
   f.split512 = (ctx->tuning.split512 != 0);
-  // whole-plane x kernels (k_xinv PLANE): square planes of 32 / 64 / 128, one GPU, 3-D
+  // whole-plane x kernels (k_xinv PLANE): square planes of 32 / 64, one GPU, 3-D
   f.plane = (ctx->tuning.plane_kernels != 0) && !f.slab && !f.two_d && c.nx == c.ny && plane_len(static_cast<int>(c.nx)) &&
             supported_len(c.nx);
+  if (f.plane)
+  {
+    const size_t elems = static_cast<size_t>(f.Palloc) * c.ny * c.nz;
+    KW_HIP(hipMalloc(reinterpret_cast<void**>(&f.s4), elems * sizeof(float2)));
+    KW_HIP(hipMemsetAsync(f.s4, 0, elems * sizeof(float2), ctx->stream));
+  }
   f.ready = true;
   return KW_OK;
 }
@@ -2696,6 +2702,7 @@ kw_status kw_fused_destroy(kw_ctx* ctx)
   {
     if (f.r[i]) (void)hipFree(f.r[i]);
     f.r[i] = nullptr;
+    if (i == 0 && f.s4) { (void)hipFree(f.s4); f.s4 = nullptr; }
     if (f.owns_scratch)
     {
       if (f.s[i]) (void)hipFree(f.s[i]);
@@ -2795,6 +2802,9 @@ kw_status kw_fused_velocity(kw_ctx* ctx, const float* p, float* ux, float* uy, f
   const float* dt[3] = { dtx, dty, dtz };
   const float* pml[3] = { pmlx, pmly, pmlz };
   for (int i = 0; i < 3; i++) { x.in[i] = S[i]; x.out[i] = u[i]; x.m0[i] = dt[i]; x.m1[i] = pml[i]; x.fout[i] = S[i]; }
+  // whole-plane kernels: the block of u_x would overwrite the plane of Q that the block of u_y reads: its chained spectrum
+  // goes to a fourth array, where the density stage picks it up
+  if (ctx->fused.plane) x.fout[0] = ctx->fused.s4;
   // chained: the updated velocity rows are forward-transformed along x (and y) on the spot (valid as long as nothing
   // else writes u before kw_fused_density(..., KW_FUSED_U_IN_SCRATCH))
   if (chain_u_spectra) return gradient_tail<EPI_VELOCITY, true>(ctx, x, (const float2*)ddx, (const float2*)ddy);
@@ -2846,6 +2856,7 @@ kw_status kw_fused_density(kw_ctx* ctx, int nonlinear, const float* ux, const fl
   const float* in3[3] = { ux, uy, uz };
   ZArgs z{};
   for (int i = 0; i < 3; i++) { z.in[i] = S[i]; z.out[i] = S[i]; }
+  if (u_in_scratch && ctx->fused.plane) z.in[0] = ctx->fused.s4; // (see kw_fused_velocity)
   z.op[0] = kappa_padded;
   z.dd[0] = (const float2*)ddx; z.dd[1] = (const float2*)ddy; z.dd[2] = (const float2*)ddz;
   // 2-D: u_z is identically zero; its spectrum travels as zeros (chained stages leave G_y of the velocity stage in S[2])
@@ -2915,6 +2926,7 @@ kw_status kw_fused_velocity_gradient(kw_ctx* ctx, const float* ux, const float* 
   const float* in3[3] = { ux, uy, uz };
   ZArgs z{};
   for (int i = 0; i < 3; i++) { z.in[i] = S[i]; z.out[i] = S[i]; }
+  if (u_in_scratch && ctx->fused.plane) z.in[0] = ctx->fused.s4; // (see kw_fused_velocity)
   z.op[0] = kappa_padded;
   z.dd[0] = (const float2*)ddx; z.dd[1] = (const float2*)ddy; z.dd[2] = (const float2*)ddz;
   if (ctx->fused.two_d && u_in_scratch)

@@ -68,6 +68,8 @@ struct kw_ctx
     uint32_t P     = 0;                            // row pitch of the spectra (complex), multiple of 16: nxm rounded up
     uint32_t PX    = 0;                            // row pitch of exchange-side buffers (slab mode: nx/2+1, no padding)
     float2*  s[3]  = {nullptr, nullptr, nullptr};  // three padded complex scratch arrays [nz][ny][P]
+    float2*  s4    = nullptr;                      // whole-plane kernels: where the chained spectrum of u_x goes (its block
+                                                   // must not overwrite s[0], which the u_y block of the same plane reads)
     float2*  tw[3] = {nullptr, nullptr, nullptr};  // exp(-2 pi i m / n) for n = nx, ny, nz
     // Z-slab decomposition (multi-GPU): this context owns nz = nz_global/nranks planes of the real-space arrays and,
     // after the all-to-all transpose, nyl = ny/nranks rows of every spectrum with all nz_global planes.

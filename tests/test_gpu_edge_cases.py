@@ -139,10 +139,10 @@ def test_bad_inputs_are_reported_not_computed(syn):
         gpu(pr, no_such_option=1)
 
 
-@pytest.mark.parametrize("dims", [(32, 32, 32), (64, 64, 64), (128, 128, 128), (64, 64, 16), (32, 32, 48)])
+@pytest.mark.parametrize("dims", [(32, 32, 32), (64, 64, 64), (64, 64, 16), (32, 32, 48)])
 @pytest.mark.parametrize("medium", ["111", "100", "001"])
 def test_whole_plane_kernels_give_the_bits_of_the_three_launch_form(syn, dims, medium):
-    """Grids with square planes of 32 / 64 / 128 points run a stage's tail as ONE launch whose blocks take whole z-planes and
+    """Grids with square planes of 32 / 64 points run a stage's tail as ONE launch whose blocks take whole z-planes and
     do the y transforms themselves (k_xinv PLANE): same small DFTs, twiddles and operation order as the separate y-passes,
     so every field must come out bit-identical to kw_tuning::plane_kernels = 0 — heterogeneous absorbing nonlinear, linear
     lossless (equation of state inside the density kernel) and homogeneous absorbing media, with a p0 and a velocity source."""

@@ -27,7 +27,7 @@ def kernel_stats(d):
     if f:
         for r in csv.DictReader(open(f[0])):
             rows.append((short(r["Name"]), int(r["Calls"]), float(r["AverageNs"]) / 1e3, float(r["TotalDurationNs"]) / 1e6,
-                         float(r["Percentage"])))
+                         float(r["Percentage"]), float(r.get("MinNs", 0)) / 1e3, float(r.get("MaxNs", 0)) / 1e3))
     return rows
 
 
@@ -89,14 +89,14 @@ def main():
     dst = os.path.join(ROOT, "profiles")
     os.makedirs(dst, exist_ok=True)
     out = {}
-    for name in ("stats256", "stats512", "statsslab"):
+    for name in ("stats256", "stats512", "statsslab", "statsslab_p2p", "stats128", "stats64"):
         rows = kernel_stats(os.path.join(src, name))
         if not rows:
             continue
         with open(os.path.join(dst, f"{rnd}_{name}_kernel_stats.csv"), "w") as fo:
-            fo.write("kernel,calls,avg_us,total_ms,percent\n")
+            fo.write("kernel,calls,avg_us,total_ms,percent,min_us,max_us\n")
             for r in rows:
-                fo.write(f"\"{r[0]}\",{r[1]},{r[2]:.2f},{r[3]:.3f},{r[4]:.2f}\n")
+                fo.write(f"\"{r[0]}\",{r[1]},{r[2]:.2f},{r[3]:.3f},{r[4]:.2f},{r[5]:.2f},{r[6]:.2f}\n")
         b = bench_line(os.path.join(src, name + ".log"))
         if b:
             json.dump(b, open(os.path.join(dst, f"{rnd}_{name}_bench.json"), "w"), indent=1)
