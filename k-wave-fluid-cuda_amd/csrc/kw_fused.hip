@@ -1151,7 +1151,7 @@ template<int L, int EPI, bool CHAIN, int TERMS = 0, bool TAIL = false, bool PLAN
 __global__ __launch_bounds__((Geo<L, PLANE ? L / 2 : nl_x(L)>::THREADS), (EPI == EPI_DENSITY && L == 256) ? 3 : big_line_waves(L)) void k_xinv(XinvArgs a)
 {
   constexpr int terms = TERMS;
-  constexpr int NLX = PLANE ? L / 2 : nl_x(L);
+  constexpr int NLX = PLANE ? L / 2 : nl_x(L); // (the registers a thread needs follow from L / TPL, not from the lines per block)
   using G = Geo<L, NLX>;
   constexpr int R1 = G::R1, R2 = G::R2;
   constexpr int NA  = (EPI == EPI_DENSITY) ? 3 : (EPI == EPI_PSUM) ? 2 : 1;
@@ -1187,8 +1187,8 @@ __global__ __launch_bounds__((Geo<L, PLANE ? L / 2 : nl_x(L)>::THREADS), (EPI ==
       xinv_lines<L, 1, false, NLX, true>(Yp, a.P, lds, c, f, twl, w, tile, (NA == 1) ? a.mulx[comp] : nullptr);
     }
     else
-    xinv_lines<L, (EPI == EPI_DENSITY) ? 2 : 1, TAIL>(a.in[(NA == 1) ? comp : i], a.P, lds, c, f, twl, w, tile,
-                                                       (NA == 1) ? a.mulx[comp] : nullptr, a.nrows, a.side_off); // ends with a barrier
+    xinv_lines<L, (EPI == EPI_DENSITY) ? 2 : 1, TAIL, NLX>(a.in[(NA == 1) ? comp : i], a.P, lds, c, f, twl, w, tile,
+                                                            (NA == 1) ? a.mulx[comp] : nullptr, a.nrows, a.side_off); // ends with a barrier
     if (ACT(R1, f))
     {
 #pragma unroll
@@ -1475,7 +1475,7 @@ __global__ __launch_bounds__((Geo<L, PLANE ? L / 2 : nl_x(L)>::THREADS), (EPI ==
         lds_barrier(); // the plane buffer is reused by the second chained array
       }
       else
-      xfwd_tail<L, TAIL>(v, lds, c, f, twl, a.fout[(NA == 1) ? comp : jf], a.P, tile, a.nrows, a.side_off);
+      xfwd_tail<L, TAIL, NLX>(v, lds, c, f, twl, a.fout[(NA == 1) ? comp : jf], a.P, tile, a.nrows, a.side_off);
     }
   }
 }
