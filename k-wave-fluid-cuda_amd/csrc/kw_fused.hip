@@ -447,7 +447,7 @@ template<int L, int MODE> __global__ __launch_bounds__(Geo<L>::THREADS, big_line
   const uint32_t opbase = tc.side ? a.op_side_off + (((ky / NLMAX) * (R2 / OPV) * R1 + j) * NLMAX + ky % NLMAX) * OPV
                                   : (((ky * (a.Pop / NLMAX) + tc.col / NLMAX) * (R2 / OPV) * R1 + j) * NLMAX + tc.col % NLMAX) * OPV;
   constexpr bool MULTI  = (MODE == Z_VGRAD || MODE == Z_ABSORB);
-  const uint32_t arr0   = MULTI ? a.arr0 : 0;
+  const uint32_t arr0   = MULTI ? a.arr0 + blockIdx.z * a.narr : 0; // (grid.z > 1: small grids, one array per block)
   const uint32_t narr   = MULTI ? a.narr : 1;
   // PGRAD: the x- and y-gradients share one z-inverse — ddx(kx), ddy(ky) do not depend on kz, so they are applied after
   // the way back (y-pass / x-pass); only Q = F_z^-1{kappa X} and G_z = F_z^-1{ddz kappa X} leave this kernel
@@ -1874,6 +1874,12 @@ kw_status launch_ypass(kw_ctx* ctx, int dir, int narr, float2* const* in, float2
   a.ain  = pack_in ? packed : natural;
   a.aout = pack_out ? packed : natural;
   a.narr = narr; // each block walks the arrays of the launch (the next one's lines requested before the current transform)
+  { // ... unless the launch would not even fill the chip twice (small grids): then one array per block — three times the
+    // blocks, a third of each block's life — is worth more than the prefetch (128^3: y-passes of three arrays 15 -> 13 us,
+    // step +3 %).  Not for `ordered` lists (in-place hazards).
+    const uint32_t blocks = (f.P / nl_yz(c.ny) + side_tile) * (nzc ? nzc : c.nz);
+    if (!ordered && narr > 1 && blocks < 8u * static_cast<uint32_t>(ctx->cu_count)) a.narr = 1;
+  }
   a.z0   = z0;
   if (c.ny == 512 && f.split512)
   { // 2 x 256 lines: 16-column tiles, one array per block
@@ -1936,7 +1942,16 @@ template<int MODE> kw_status launch_zfused(kw_ctx* ctx, int narr, ZArgs a)
     LAUNCH((k_zfused_split<512, MODE>), dim3(f.P / NLMAX + side_tile, f.nyl, narr), dim3(Geo<256>::THREADS), a);
     return KW_OK;
   }
-  const dim3 grid(f.P / nl_yz(f.nz_global) + side_tile, f.nyl, 1);
+  // smallest grids (fewer blocks than two per CU): one array per block instead of the arrays back to back (64^3: z-fused
+  // kernels 10.6 -> 8.8 us, step +4 %; at 128^3, 640 blocks, the in-block walk with its prefetch is still the faster form)
+  uint32_t split = 1;
+  if ((MODE == Z_VGRAD || MODE == Z_ABSORB) && narr > 1 &&
+      (f.P / nl_yz(f.nz_global) + side_tile) * f.nyl < 2u * static_cast<uint32_t>(ctx->cu_count))
+  {
+    split  = static_cast<uint32_t>(narr);
+    a.narr = 1;
+  }
+  const dim3 grid(f.P / nl_yz(f.nz_global) + side_tile, f.nyl, split);
 #define M(LEN) LAUNCH((k_zfused<LEN, MODE>), grid, dim3(Geo<LEN>::THREADS), a)
   KW_LEN_SWITCH(f.nz_global, M)
 #undef M
