@@ -30,10 +30,11 @@
 using namespace kwfft;
 
 // The x-inverse + epilogue kernels are the bulk of this file's compile time and code size (one kernel per epilogue
-// variant and line length).  They are compiled in four extra passes over this file, side by side with the main pass
+// variant and line length).  They are compiled in six extra passes over this file, side by side with the main pass
 // (build.py):
-//   KW_FUSED_TU == 0  everything except those kernels;  1  the density epilogues;  2  the other epilogues;
-//                  3 / 4  the masked (TAIL) forms of 1 / 2, which only grids with a partial last x tile ever launch.
+//   KW_FUSED_TU == 0  everything except those kernels;  1  the chained density epilogues;  5  the density epilogues that
+//                  store their terms;  2  the other epilogues;  3 / 6 / 4  the masked (TAIL) forms of 1 / 5 / 2, which
+//                  only grids with a partial last x tile ever launch.
 // Every pass is a code object of its own that the runtime loads at the first launch out of it: a run pays for the
 // variants it uses.  The main pass reaches the others through the functions below (XinvArgs passed as an opaque pointer:
 // the struct lives in this file's anonymous namespace).
@@ -43,6 +44,8 @@ using namespace kwfft;
 kw_status kw_fused_xinv_density(int chain, int terms, kw_ctx* ctx, int ncomp, const void* xinv_args, uint32_t tile0, uint32_t ntiles);
 kw_status kw_fused_xinv_other(int epi, int chain, kw_ctx* ctx, int ncomp, const void* xinv_args, uint32_t tile0, uint32_t ntiles);
 kw_status kw_fused_xinv_density_tail(int chain, int terms, kw_ctx* ctx, int ncomp, const void* xinv_args, uint32_t tile0, uint32_t ntiles);
+kw_status kw_fused_xinv_density_plain(int chain, int terms, kw_ctx* ctx, int ncomp, const void* xinv_args, uint32_t tile0, uint32_t ntiles);
+kw_status kw_fused_xinv_density_tail_plain(int chain, int terms, kw_ctx* ctx, int ncomp, const void* xinv_args, uint32_t tile0, uint32_t ntiles);
 kw_status kw_fused_xinv_other_tail(int epi, int chain, kw_ctx* ctx, int ncomp, const void* xinv_args, uint32_t tile0, uint32_t ntiles);
 // whole-plane tiles (small grids, see k_xinv): tile0 / ntiles count z-planes; in passes 1 / 2
 kw_status kw_fused_xinv_density_plane(int chain, int terms, kw_ctx* ctx, int ncomp, const void* xinv_args, uint32_t tile0, uint32_t ntiles);
@@ -51,11 +54,30 @@ kw_status kw_fused_xinv_other_plane(int epi, int chain, kw_ctx* ctx, int ncomp, 
 namespace {
 
 constexpr int NLMAX = 16; // widest tile: 16 complex = 128-B segments (also the row-pitch granule)
-// x passes, rows per block = 2 * nl_x: 16 line pairs up to L = 384; 8 from L = 400 on, where the 20- to 32-point register
-// DFTs of the epilogue kernels need the VGPR budget of a small block (384^3 measured: 244 steps/s with 16, 235 with 8)
-constexpr int nl_x(int L) { return L >= 400 ? 8 : 16; }
+// x passes, rows per block = 2 * nl_x.  Chosen per line length from a measured matrix (every length from 160 up, both
+// orientations of its factor pair, 8 / 10 / 12 / 16 line pairs: profiles/r03_length_tuning.txt, tools/length_tuning_table.py).
+// What the matrix shows: a block should be a whole number of 4 waves or less — the 5- and 6-wave blocks of 18, 20 and 24
+// threads per line at 16 line pairs are rarely co-resident (one wave more on one SIMD than on the others), 240^3: x-inverse
+// kernels 1.4-1.5x faster at 12 line pairs — and the long lines want the small block's register budget.
+// (tuning builds: -DKW_TUNE_NLX=<n> overrides the table, -DKW_TUNE_SWAP the orientation table in kw_fft_device.h)
+#ifdef KW_TUNE_NLX
+constexpr int nl_x(int) { return KW_TUNE_NLX; }
+#else
+constexpr int nl_x(int L)
+{
+  switch (L)
+  {
+    case 160: case 168: case 196: case 200: case 224: case 288: case 336: case 384: case 392: return 8;
+    case 280: case 300: case 320: case 432: case 480: case 500: case 600: return 10;
+    case 180: case 216: case 240: case 324: case 360: case 400: return 12;
+    case 896: return 16;
+    default: return L >= 400 ? 8 : 16;
+  }
+}
+#endif
 // y / z passes, columns per tile: 16 (128-B row segments) at every length.  500^3 measured with 8-column tiles (64-B
-// segments) for the long lines: y passes 1.5x, z-fused 1.25x slower.
+// segments) for the long lines: y passes 1.5x, z-fused 1.25x slower; 240^3 with 12- and 8-column tiles (4- and 3-wave
+// blocks instead of 5): step 11 % and 15 % slower.
 constexpr int nl_yz(int) { return 16; }
 
 constexpr int cmax(int a, int b) { return a > b ? a : b; }
@@ -90,6 +112,25 @@ template<int L, int NLV = nl_yz(L)> struct Geo
 template<int L> using GeoX = Geo<L, nl_x(L)>; // geometry of the x passes
 
 #define ACT(R, t) ((R) == G::TPL || (t) < (R))
+// the same for the y / z kernels, whose threads are laid out t = j * NL + c: when NL * R is a whole number of waves the
+// participants of a step are whole waves, and the test is made on a wave-uniform value (a scalar branch, no exec masking)
+#define ACTW(R, j) ((R) == G::TPL || (((G::NL * (R)) % 64 == 0 && 64 % G::NL == 0) ? __builtin_amdgcn_readfirstlane(j) < (R) : (j) < (R)))
+
+// Roles of the x kernels' threads.  A step with R participants per line (R2 in step A, R1 in step B) is taken by the FIRST
+// NL * R threads of the block, R consecutive ones per line: with R < TPL (12 x 20, 12 x 18 ... factorisations) the idle
+// threads are whole trailing waves instead of masked lanes inside every wave.  Everything crosses LDS between the steps,
+// so the line a thread works on may change from step to step; with R == TPL this is the plain (c, f) = (t / TPL, t % TPL).
+template<class G, int R> struct XRole
+{
+  int  c, f;
+  bool on;
+  __device__ __forceinline__ XRole()
+  {
+    c  = static_cast<int>(threadIdx.x) / R;
+    f  = static_cast<int>(threadIdx.x) - c * R;
+    on = (R == G::TPL) || static_cast<int>(threadIdx.x) < G::NL * R;
+  }
+};
 
 // Block barrier that orders LDS traffic only.  __syncthreads() also drains every outstanding global load and store
 // (vmcnt(0)) — here all cross-thread communication goes through LDS, and global stores / prefetched loads should stay in
@@ -144,21 +185,40 @@ template<int RUN, int R1> __device__ __forceinline__ void load_op_run(float (&ds
 // v_add_u32 and a 64-bit v_lshl_add_u64: a sixth of the vector instructions of a z-pass, whose VALU is ~75 % busy).
 // (the empty asm pins the uniform part to an SGPR pair: left alone, the compiler re-associates it into a chain of 64-bit
 // vector adds)
+// PIN = false: inside a region only some lanes of a wave enter (a step whose participants are not whole waves) the
+// compiler may hold the base in vector registers, which the "s" constraint cannot take: there the base is read back
+// from the first active lane instead (two v_readfirstlane; folded away when the value already is scalar).
+template<bool PIN = true>
 __device__ __forceinline__ float2 ld_uni(const float2* __restrict__ p, uint64_t uniform_elems, uint32_t lane_bytes)
 {
   typedef float v2 __attribute__((ext_vector_type(2)));
   typedef const __attribute__((address_space(1))) char* gptr; // global address space survives the asm (else: flat loads)
   gptr b = (gptr)(p + uniform_elems);
-  asm volatile("" : "+s"(b));
+  if constexpr (PIN) asm volatile("" : "+s"(b));
+  else
+  {
+    const uint64_t bits = reinterpret_cast<uint64_t>(p + uniform_elems);
+    const uint32_t lo = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(bits));
+    const uint32_t hi = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(bits >> 32));
+    b = (gptr)((static_cast<uint64_t>(hi) << 32) | lo);
+  }
   const v2 t = *(const __attribute__((address_space(1))) v2*)(b + lane_bytes);
   return make_float2(t.x, t.y);
 }
+template<bool PIN = true>
 __device__ __forceinline__ void st_uni(float2* __restrict__ p, uint64_t uniform_elems, uint32_t lane_bytes, const float2& v)
 {
   typedef float v2 __attribute__((ext_vector_type(2)));
   typedef __attribute__((address_space(1))) char* gptr;
   gptr b = (gptr)(p + uniform_elems);
-  asm volatile("" : "+s"(b));
+  if constexpr (PIN) asm volatile("" : "+s"(b));
+  else
+  {
+    const uint64_t bits = reinterpret_cast<uint64_t>(p + uniform_elems);
+    const uint32_t lo = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(bits));
+    const uint32_t hi = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(bits >> 32));
+    b = (gptr)((static_cast<uint64_t>(hi) << 32) | lo);
+  }
   *(__attribute__((address_space(1))) v2*)(b + lane_bytes) = v2{ v.x, v.y };
 }
 
@@ -308,12 +368,12 @@ __global__ __launch_bounds__(Geo<L>::THREADS) void k_ypass(PassArgs a)
   };
 
   float2 v[R1];
-  if (ACT(R2, j)) load_lines(v, a.in[arr0]);
+  if (ACTW(R2, j)) load_lines(v, a.in[arr0]);
   lds_barrier(); // twiddle table visible (the line loads stay in flight across it)
 #pragma unroll 1
   for (uint32_t ia = 0; ia < a.narr; ia++)
   {
-    if (ACT(R2, j))
+    if (ACTW(R2, j))
     {
       const float2* __restrict__ m = a.mul[arr0 + ia];
       if (m != nullptr)
@@ -327,7 +387,7 @@ __global__ __launch_bounds__(Geo<L>::THREADS) void k_ypass(PassArgs a)
       if (ia + 1 < a.narr) load_lines(v, a.in[arr0 + ia + 1]);
     }
     lds_barrier();
-    if (ACT(R1, j))
+    if (ACTW(R1, j))
     {
       float2 w[R2];
 #pragma unroll
@@ -398,7 +458,7 @@ __device__ __forceinline__ void inverse_from_regs(float2 (&w)[Fac<L>::R2], float
   using G = Geo<L>;
   constexpr int R1 = G::R1, R2 = G::R2;
   static_assert(!COLWRITE || R1 == R2, "transposed exchange needs a square factorisation");
-  if (ACT(R1, j))
+  if (ACTW(R1, j))
   {
     Dft<R2, kInv>::run(w);
 #pragma unroll
@@ -410,7 +470,7 @@ __device__ __forceinline__ void inverse_from_regs(float2 (&w)[Fac<L>::R2], float
     }
   }
   lds_barrier();
-  if (ACT(R2, j))
+  if (ACTW(R2, j))
   {
 #pragma unroll
     for (int k1 = 0; k1 < R1; k1++)
@@ -426,6 +486,7 @@ template<int L, int MODE> __global__ __launch_bounds__(Geo<L>::THREADS, big_line
 {
   using G = Geo<L>;
   constexpr int R1 = G::R1, R2 = G::R2;
+  constexpr bool WA = (R2 == G::TPL) || ((G::NL * R2) % 64 == 0 && 64 % G::NL == 0); // step-A participants: whole waves
   __shared__ float2 lds[G::LDSB];
   __shared__ float2 twl[G::TWN];
   load_twiddles<L>(twl, a.tw);
@@ -454,17 +515,18 @@ template<int L, int MODE> __global__ __launch_bounds__(Geo<L>::THREADS, big_line
   constexpr int  NOUT   = (MODE == Z_PGRAD) ? 2 : 1;
 
   float2 v[R1];
-  if (ACT(R2, j))
+  const float2* __restrict__ in0 = a.in[arr0]; // (array pointers are picked outside the thread-dependent regions: SGPR bases)
+  if (ACTW(R2, j))
   {
-    const float2* __restrict__ in = a.in[arr0];
+    const float2* __restrict__ in = in0;
     const uint32_t lb = (basel + static_cast<uint32_t>(j) * zstr) * static_cast<uint32_t>(sizeof(float2));
 #pragma unroll
     for (int n1 = 0; n1 < R1; n1++)
-      v[n1] = ld_uni(in, static_cast<uint64_t>(n1 * R2) * zstr, lb);
+      v[n1] = ld_uni<WA>(in, static_cast<uint64_t>(n1 * R2) * zstr, lb);
   }
   // spectral operator of the elements this thread will hold after the forward transform (kz = j + R1*k2)
   float kap[R2];
-  if (MODE != Z_SHIFT && ACT(R1, j))
+  if (MODE != Z_SHIFT && ACTW(R1, j))
   {
     load_op_run<R2, R1>(kap, a.op[(MODE == Z_ABSORB) ? arr0 : 0], opbase);
   }
@@ -474,25 +536,26 @@ template<int L, int MODE> __global__ __launch_bounds__(Geo<L>::THREADS, big_line
   for (uint32_t ia = 0; ia < narr; ia++)
   {
     const uint32_t arr = arr0 + ia;
-    if (ACT(R2, j))
+    const float2* __restrict__ in_next = a.in[min(arr + 1u, arr0 + narr - 1u)];
+    if (ACTW(R2, j))
     {
       step_a<L, kFwd>(v, j, twl);
 #pragma unroll
       for (int k1 = 0; k1 < R1; k1++) lds[k1 * G::SF + j * G::NL + c] = v[k1];
     }
     // next array's lines: in flight during this array's two transforms
-    if (MULTI && ia + 1 < narr && ACT(R2, j))
+    if (MULTI && ia + 1 < narr && ACTW(R2, j))
     {
-      const float2* __restrict__ in = a.in[arr + 1];
+      const float2* __restrict__ in = in_next;
       uint32_t lb = basel + static_cast<uint32_t>(j) * zstr;
       asm volatile("" : "+v"(lb)); // per-iteration address arithmetic instead of 16 loop-invariant address registers
 #pragma unroll
       for (int n1 = 0; n1 < R1; n1++)
-        v[n1] = ld_uni(in, static_cast<uint64_t>(n1 * R2) * zstr, lb * static_cast<uint32_t>(sizeof(float2)));
+        v[n1] = ld_uni<WA>(in, static_cast<uint64_t>(n1 * R2) * zstr, lb * static_cast<uint32_t>(sizeof(float2)));
     }
     lds_barrier();
     float2 X[R2];
-    if (ACT(R1, j))
+    if (ACTW(R1, j))
     {
 #pragma unroll
       for (int n2 = 0; n2 < R2; n2++) X[n2] = lds[j * G::SF + n2 * G::NL + c];
@@ -528,7 +591,7 @@ template<int L, int MODE> __global__ __launch_bounds__(Geo<L>::THREADS, big_line
     for (int o = 0; o < NOUT; o++)
     {
       float2 w[R2];
-      if (ACT(R1, j))
+      if (ACTW(R1, j))
       {
         if (MODE == Z_PGRAD || MODE == Z_VGRAD)
         {
@@ -560,13 +623,13 @@ template<int L, int MODE> __global__ __launch_bounds__(Geo<L>::THREADS, big_line
       }
       float2 r[R1];
       inverse_from_regs<L>(w, r, lds, c, j, twl);
-      if (ACT(R2, j) && valid)
+      float2* __restrict__ out = a.out[(MODE == Z_PGRAD) ? 2 * o : arr];
+      if (ACTW(R2, j) && valid)
       {
-        float2* __restrict__ out = a.out[(MODE == Z_PGRAD) ? 2 * o : arr];
         uint32_t ob = base + static_cast<uint32_t>(j) * zstr;
         asm volatile("" : "+v"(ob)); // recomputed per output: 16 hoisted 64-bit addresses cost an occupancy step
 #pragma unroll
-        for (int q2 = 0; q2 < R1; q2++) st_uni(out, static_cast<uint64_t>(R2 * q2) * zstr, ob * static_cast<uint32_t>(sizeof(float2)), r[q2]);
+        for (int q2 = 0; q2 < R1; q2++) st_uni<WA>(out, static_cast<uint64_t>(R2 * q2) * zstr, ob * static_cast<uint32_t>(sizeof(float2)), r[q2]);
       }
       // the next output's inverse writes rows while other threads may still read their columns: barrier; the next
       // array's forward transform writes the column this thread has just read: none
@@ -839,37 +902,39 @@ struct XfwdArgs
 // partial tile: that one tile is launched on its own with TAIL = true — row loads clamp to the last row, every store is
 // predicated on the row — so the full tiles keep their unmasked kernels.
 
-// forward line FFT of this block's 16 complex lines (= 32 real rows) from the step-A registers v (valid for f < R2),
+// forward line FFT of this block's 16 complex lines (= 32 real rows) from the step-A registers v (of role XRole<G, R2>),
 // split into the two half-spectra and stored to rows tile_row0.. of `out`.  Called by every thread of the block; the
 // exchange buffer must be free on entry and is free again on exit (trailing barrier).
 // NLX: line pairs per block.  PLANE (the tile is a whole z-plane, see k_xinv): the half-spectrum rows go to the block's
 // plane buffer in LDS ([row][L / 2 + 1], `out`) instead of to the scratch array.
 template<int L, bool TAIL = false, int NLX = nl_x(L), bool PLANE = false>
-__device__ __forceinline__ void xfwd_tail(float2 (&v)[Fac<L>::R1], float2* lds, int c, int f,
+__device__ __forceinline__ void xfwd_tail(float2 (&v)[Fac<L>::R1], float2* lds,
                                           const float2* tw, float2* __restrict__ out, uint32_t P, uint32_t tile,
                                           uint32_t nrows = 0, uint32_t side_off = 0)
 {
   using G = Geo<L, NLX>;
   constexpr int R1 = G::R1, R2 = G::R2, HALF = L / 2 + 1;
-  if (ACT(R2, f))
+  const XRole<G, R2> sa; // v: the step-A registers of line sa.c, column sa.f
+  const XRole<G, R1> sb;
+  if (sa.on)
   {
-    step_a<L, kFwd>(v, f, tw);
+    step_a<L, kFwd>(v, sa.f, tw);
 #pragma unroll
-    for (int k1 = 0; k1 < R1; k1++) lds[c * G::LP + k1 * (R2 + 1) + f] = v[k1];
+    for (int k1 = 0; k1 < R1; k1++) lds[sa.c * G::LP + k1 * (R2 + 1) + sa.f] = v[k1];
   }
   lds_barrier();
   float2 w[R2];
-  if (ACT(R1, f))
+  if (sb.on)
   {
 #pragma unroll
-    for (int n2 = 0; n2 < R2; n2++) w[n2] = lds[c * G::LP + f * (R2 + 1) + n2];
+    for (int n2 = 0; n2 < R2; n2++) w[n2] = lds[sb.c * G::LP + sb.f * (R2 + 1) + n2];
     Dft<R2, kFwd>::run(w);
   }
   lds_barrier();
-  if (ACT(R1, f))
+  if (sb.on)
   {
 #pragma unroll
-    for (int k2 = 0; k2 < R2; k2++) lds[c * G::ZP + f + R1 * k2] = w[k2];
+    for (int k2 = 0; k2 < R2; k2++) lds[sb.c * G::ZP + sb.f + R1 * k2] = w[k2];
   }
   lds_barrier();
   const uint32_t tile_row0 = tile * G::NL * 2;
@@ -905,21 +970,20 @@ template<int L, bool TAIL = false> __global__ __launch_bounds__(GeoX<L>::THREADS
   __shared__ float2 lds[G::LDSX];
   __shared__ float2 twl[G::TWN];
   load_twiddles<L>(twl, a.tw);
-  const int    f   = threadIdx.x % G::TPL;
-  const int    c   = threadIdx.x / G::TPL;
+  const XRole<G, R2> sa;
   const float* __restrict__ in = a.in[blockIdx.y];
   const uint32_t tile = blockIdx.x + a.tile0;
-  const uint32_t row0 = (tile * G::NL + c) * 2;
+  const uint32_t row0 = (tile * G::NL + sa.c) * 2;
   float2 v[R1];
-  if (ACT(R2, f))
+  if (sa.on)
   {
     const float* __restrict__ ra = in + (TAIL ? min(row0, a.nrows - 1u) : row0) * L;
     const float* __restrict__ rb = TAIL ? in + min(row0 + 1u, a.nrows - 1u) * L : ra + L;
 #pragma unroll
-    for (int n1 = 0; n1 < R1; n1++) v[n1] = make_float2(ra[n1 * R2 + f], rb[n1 * R2 + f]);
+    for (int n1 = 0; n1 < R1; n1++) v[n1] = make_float2(ra[n1 * R2 + sa.f], rb[n1 * R2 + sa.f]);
   }
   lds_barrier(); // twiddle table visible
-  xfwd_tail<L, TAIL>(v, lds, c, f, twl, a.out[blockIdx.y], a.P, tile, a.nrows, a.side_off);
+  xfwd_tail<L, TAIL>(v, lds, twl, a.out[blockIdx.y], a.P, tile, a.nrows, a.side_off);
 }
 
 // =====================================================================================================================
@@ -952,10 +1016,11 @@ struct XinvArgs
   const float2* ymul[3];    // PLANE kernels: optional factor ymul[ky] applied to array i before its y-inverse (ddy of the gradient)
 };
 
-// standalone inverse of one array for this block's 32 rows; thread (c, f<R1) ends with x[f + R1*k2] of rows (2c, 2c+1)
+// standalone inverse of one array for this block's 32 rows; the thread of role sb = XRole<G, R1> ends with
+// x[sb.f + R1*k2] of rows (2 sb.c, 2 sb.c + 1)
 // PLANE: the rows come from the block's plane buffer in LDS ([row][L / 2 + 1], `src`), where the y-inverse left them
 template<int L, int NGRP = 1, bool TAIL = false, int NLX = nl_x(L), bool PLANE = false>
-__device__ __forceinline__ void xinv_lines(const float2* __restrict__ src, uint32_t P, float2* lds, int c, int f,
+__device__ __forceinline__ void xinv_lines(const float2* __restrict__ src, uint32_t P, float2* lds,
                                            const float2* tw, float2 (&w)[Fac<L>::R2], uint32_t tile,
                                            const float2* __restrict__ mulx = nullptr, uint32_t nrows = 0,
                                            uint32_t side_off = 0)
@@ -1006,24 +1071,26 @@ __device__ __forceinline__ void xinv_lines(const float2* __restrict__ src, uint3
     }
   }
   lds_barrier();
+  const XRole<G, R2> sa;
+  const XRole<G, R1> sb;
   float2 v[R1];
-  if (ACT(R2, f))
+  if (sa.on)
   {
 #pragma unroll
-    for (int n1 = 0; n1 < R1; n1++) v[n1] = lds[c * G::ZP + n1 * R2 + f];
+    for (int n1 = 0; n1 < R1; n1++) v[n1] = lds[sa.c * G::ZP + n1 * R2 + sa.f];
   }
   lds_barrier();
-  if (ACT(R2, f))
+  if (sa.on)
   {
-    step_a<L, kInv>(v, f, tw);
+    step_a<L, kInv>(v, sa.f, tw);
 #pragma unroll
-    for (int k1 = 0; k1 < R1; k1++) lds[c * G::LP + k1 * (R2 + 1) + f] = v[k1];
+    for (int k1 = 0; k1 < R1; k1++) lds[sa.c * G::LP + k1 * (R2 + 1) + sa.f] = v[k1];
   }
   lds_barrier();
-  if (ACT(R1, f))
+  if (sb.on)
   {
 #pragma unroll
-    for (int n2 = 0; n2 < R2; n2++) w[n2] = lds[c * G::LP + f * (R2 + 1) + n2];
+    for (int n2 = 0; n2 < R2; n2++) w[n2] = lds[sb.c * G::LP + sb.f * (R2 + 1) + n2];
     Dft<R2, kInv>::run(w);
   }
   lds_barrier();
@@ -1164,8 +1231,8 @@ __global__ __launch_bounds__((Geo<L, PLANE ? L / 2 : nl_x(L)>::THREADS), (EPI ==
   __shared__ float2 Yp[PLANE ? L * (L / 2 + 1) : 1]; // PLANE: the plane's half-spectrum between its y and x transforms
   load_twiddles<L>(twl, a.tw); // published by the first barrier of xinv_lines (PLANE: of the plane's y transform)
   float* ldsr = reinterpret_cast<float*>(lds);
-  const int f = threadIdx.x % G::TPL;
-  const int c = threadIdx.x / G::TPL;
+  const XRole<G, R2> sa; // (see XRole: who takes part in the R2- and in the R1-participant steps)
+  const XRole<G, R1> sb;
   const uint32_t comp = (NA == 1) ? blockIdx.y + a.comp0 : 0; // component / array index for single-array epilogues
   const uint32_t tile = blockIdx.x + a.tile0;
   float4 res[NA][NQ];
@@ -1184,18 +1251,18 @@ __global__ __launch_bounds__((Geo<L, PLANE ? L / 2 : nl_x(L)>::THREADS), (EPI ==
       plane_load<L>(Yp, a.in[ia], tile, a.P, a.side_off, a.ymul[ia], G::THREADS);
       lds_barrier();
       plane_yfft<L, kInv>(Yp, twl);
-      xinv_lines<L, 1, false, NLX, true>(Yp, a.P, lds, c, f, twl, w, tile, (NA == 1) ? a.mulx[comp] : nullptr);
+      xinv_lines<L, 1, false, NLX, true>(Yp, a.P, lds, twl, w, tile, (NA == 1) ? a.mulx[comp] : nullptr);
     }
     else
-    xinv_lines<L, (EPI == EPI_DENSITY) ? 2 : 1, TAIL, NLX>(a.in[(NA == 1) ? comp : i], a.P, lds, c, f, twl, w, tile,
+    xinv_lines<L, (EPI == EPI_DENSITY) ? 2 : 1, TAIL, NLX>(a.in[(NA == 1) ? comp : i], a.P, lds, twl, w, tile,
                                                             (NA == 1) ? a.mulx[comp] : nullptr, a.nrows, a.side_off); // ends with a barrier
-    if (ACT(R1, f))
+    if (sb.on)
     {
 #pragma unroll
       for (int k2 = 0; k2 < R2; k2++)
       {
-        ldsr[(2 * c) * RP + f + R1 * k2]     = w[k2].x;
-        ldsr[(2 * c + 1) * RP + f + R1 * k2] = w[k2].y;
+        ldsr[(2 * sb.c) * RP + sb.f + R1 * k2]     = w[k2].x;
+        ldsr[(2 * sb.c + 1) * RP + sb.f + R1 * k2] = w[k2].y;
       }
     }
     lds_barrier();
@@ -1460,22 +1527,22 @@ __global__ __launch_bounds__((Geo<L, PLANE ? L / 2 : nl_x(L)>::THREADS), (EPI ==
       }
       lds_barrier();
       float2 v[R1c];
-      if (ACT(R2c, f))
+      if (sa.on)
       {
 #pragma unroll
         for (int n1 = 0; n1 < R1c; n1++)
-          v[n1] = make_float2(ldsr[(2 * c) * RP + n1 * R2c + f], ldsr[(2 * c + 1) * RP + n1 * R2c + f]);
+          v[n1] = make_float2(ldsr[(2 * sa.c) * RP + n1 * R2c + sa.f], ldsr[(2 * sa.c + 1) * RP + n1 * R2c + sa.f]);
       }
       lds_barrier(); // the real tile aliases the exchange buffer
       if constexpr (PLANE)
       { // rows into the plane buffer, forward along y, plane -> scratch (the consumer's z-pass comes next)
-        xfwd_tail<L, false, NLX, true>(v, lds, c, f, twl, Yp, a.P, tile);
+        xfwd_tail<L, false, NLX, true>(v, lds, twl, Yp, a.P, tile);
         plane_yfft<L, kFwd>(Yp, twl);
         plane_store<L>(Yp, a.fout[(NA == 1) ? comp : jf], tile, a.P, a.side_off, G::THREADS);
         lds_barrier(); // the plane buffer is reused by the second chained array
       }
       else
-      xfwd_tail<L, TAIL, NLX>(v, lds, c, f, twl, a.fout[(NA == 1) ? comp : jf], a.P, tile, a.nrows, a.side_off);
+      xfwd_tail<L, TAIL, NLX>(v, lds, twl, a.fout[(NA == 1) ? comp : jf], a.P, tile, a.nrows, a.side_off);
     }
   }
 }
@@ -1503,69 +1570,69 @@ template<int L, bool TAIL = false> __global__ __launch_bounds__(GeoX<L>::THREADS
   __shared__ float2 twl[G::TWN];
   load_twiddles<L>(twl, a.tw);
   float* ldsr = reinterpret_cast<float*>(lds);
-  const int f = threadIdx.x % G::TPL;
-  const int c = threadIdx.x / G::TPL;
+  const XRole<G, R2> sa;
+  const XRole<G, R1> sb;
   const uint32_t tile_row0 = (blockIdx.x + a.tile0) * G::NL * 2;
   float2 v[R1];
-  if (ACT(R2, f))
+  if (sa.on)
   {
-    const uint32_t row0 = tile_row0 + 2 * c;
+    const uint32_t row0 = tile_row0 + 2 * sa.c;
     const float* __restrict__ ra = a.in + (TAIL ? min(row0, a.nrows - 1u) : row0) * L;
     const float* __restrict__ rb = TAIL ? a.in + min(row0 + 1u, a.nrows - 1u) * L : ra + L;
 #pragma unroll
-    for (int n1 = 0; n1 < R1; n1++) v[n1] = make_float2(ra[n1 * R2 + f], rb[n1 * R2 + f]);
+    for (int n1 = 0; n1 < R1; n1++) v[n1] = make_float2(ra[n1 * R2 + sa.f], rb[n1 * R2 + sa.f]);
   }
   lds_barrier(); // twiddle table visible
-  if (ACT(R2, f))
+  if (sa.on)
   {
-    step_a<L, kFwd>(v, f, twl);
+    step_a<L, kFwd>(v, sa.f, twl);
 #pragma unroll
-    for (int k1 = 0; k1 < R1; k1++) lds[c * G::LP + k1 * (R2 + 1) + f] = v[k1];
+    for (int k1 = 0; k1 < R1; k1++) lds[sa.c * G::LP + k1 * (R2 + 1) + sa.f] = v[k1];
   }
   lds_barrier();
   float2 w[R2];
-  if (ACT(R1, f))
+  if (sb.on)
   {
 #pragma unroll
-    for (int n2 = 0; n2 < R2; n2++) w[n2] = lds[c * G::LP + f * (R2 + 1) + n2];
+    for (int n2 = 0; n2 < R2; n2++) w[n2] = lds[sb.c * G::LP + sb.f * (R2 + 1) + n2];
     Dft<R2, kFwd>::run(w);
 #pragma unroll
-    for (int k2 = 0; k2 < R2; k2++) w[k2] = cmulf(w[k2], a.H[f + R1 * k2]);
+    for (int k2 = 0; k2 < R2; k2++) w[k2] = cmulf(w[k2], a.H[sb.f + R1 * k2]);
   }
   lds_barrier();
-  if (ACT(R1, f))
+  if (sb.on)
   { // natural-order spectrum of the line, the starting point of the inverse (as in xinv_lines)
 #pragma unroll
-    for (int k2 = 0; k2 < R2; k2++) lds[c * G::ZP + f + R1 * k2] = w[k2];
+    for (int k2 = 0; k2 < R2; k2++) lds[sb.c * G::ZP + sb.f + R1 * k2] = w[k2];
   }
   lds_barrier();
-  if (ACT(R2, f))
+  if (sa.on)
   {
 #pragma unroll
-    for (int n1 = 0; n1 < R1; n1++) v[n1] = lds[c * G::ZP + n1 * R2 + f];
+    for (int n1 = 0; n1 < R1; n1++) v[n1] = lds[sa.c * G::ZP + n1 * R2 + sa.f];
   }
   lds_barrier();
-  if (ACT(R2, f))
+  if (sa.on)
   {
-    step_a<L, kInv>(v, f, twl);
+    step_a<L, kInv>(v, sa.f, twl);
 #pragma unroll
-    for (int k1 = 0; k1 < R1; k1++) lds[c * G::LP + k1 * (R2 + 1) + f] = v[k1];
+    for (int k1 = 0; k1 < R1; k1++) lds[sa.c * G::LP + k1 * (R2 + 1) + sa.f] = v[k1];
   }
   lds_barrier();
-  if (ACT(R1, f))
+  if (sb.on)
   {
 #pragma unroll
-    for (int n2 = 0; n2 < R2; n2++) w[n2] = lds[c * G::LP + f * (R2 + 1) + n2];
+    for (int n2 = 0; n2 < R2; n2++) w[n2] = lds[sb.c * G::LP + sb.f * (R2 + 1) + n2];
     Dft<R2, kInv>::run(w);
   }
   lds_barrier();
-  if (ACT(R1, f))
+  if (sb.on)
   {
 #pragma unroll
     for (int k2 = 0; k2 < R2; k2++)
     {
-      ldsr[(2 * c) * RP + f + R1 * k2]     = w[k2].x;
-      ldsr[(2 * c + 1) * RP + f + R1 * k2] = w[k2].y;
+      ldsr[(2 * sb.c) * RP + sb.f + R1 * k2]     = w[k2].x;
+      ldsr[(2 * sb.c + 1) * RP + sb.f + R1 * k2] = w[k2].y;
     }
   }
   lds_barrier();
@@ -1771,14 +1838,16 @@ template<int L> __global__ __launch_bounds__(GeoX<L>::THREADS) void k_probe_xinv
 
 // ---- host side ------------------------------------------------------------------------------------------------------
 // line lengths with a two-factor register decomposition L = R1 * R2, R1, R2 in {4 ... 32} with at most one odd prime
-// power (3, 9, 27, 5, 25) each: 2^m, 3 * 2^m, 9 * 2^m, 27 * 2^m, 81 * 4, 5 * 2^m, 15 * 2^m, 25 * 2^m, 75 * 2^m, 125 * 4,
-// 45 * 2^m (180, 360), 135 * 4 (540); the x kernels need L % 4 == 0 and whole float4 counts per thread
+// power (3, 9, 27, 5, 25, 7) each: 2^m, 3 * 2^m, 9 * 2^m, 27 * 2^m, 81 * 4, 5 * 2^m, 15 * 2^m, 25 * 2^m, 75 * 2^m, 125 * 4,
+// 45 * 2^m (180, 360), 135 * 4 (540), 7 * 2^m (112 ... 896), 21 * 2^m (168, 336), 35 * 2^m (280, 560), 49 * 2^m (196,
+// 392); the x kernels need L % 4 == 0 and whole float4 counts per thread
 #ifdef KW_FUSED_ONLY /* tuning builds: one line length only (-DKW_FUSED_ONLY=256), compiles in seconds */
 #define KW_FUSED_LENGTHS(X) X(KW_FUSED_ONLY)
 #else
-#define KW_FUSED_LENGTHS(X) X(16) X(32) X(48) X(64) X(72) X(80) X(96) X(100) X(108) X(120) X(128) X(144) X(160) X(180)  \
-  X(192) X(200) X(216) X(240) X(256) X(288) X(300) X(320) X(324) X(360) X(384) X(400) X(432) X(480) X(500) X(512) X(540) \
-  X(576) X(600) X(640) X(648) X(768) X(1024)
+#define KW_FUSED_LENGTHS(X) X(16) X(32) X(48) X(64) X(72) X(80) X(96) X(100) X(108) X(112) X(120) X(128) X(144) X(160)  \
+  X(168) X(180) X(192) X(196) X(200) X(216) X(224) X(240) X(256) X(280) X(288) X(300) X(320) X(324) X(336) X(360) X(384)   \
+  X(392) X(400) X(432) X(448) X(480) X(500) X(512) X(540) X(560) X(576) X(600) X(640) X(648) X(768) X(896)   \
+  X(1024)
 #endif
 bool supported_len(uint32_t n)
 {
@@ -2563,24 +2632,37 @@ kw_status create_impl(kw_ctx* ctx, void* const s[3], void* const t[3])
 #endif // KW_FUSED_TU == 0
 } // namespace
 
-#if KW_FUSED_TU == 1 || KW_FUSED_TU == 3
+#if KW_FUSED_TU == 1 || KW_FUSED_TU == 3 || KW_FUSED_TU == 5 || KW_FUSED_TU == 6
+// passes 1 / 3: the chained density epilogues (and the entry points); passes 5 / 6: the ones that store their terms
 #if KW_FUSED_TU == 1
 kw_status kw_fused_xinv_density(int chain, int terms, kw_ctx* ctx, int ncomp, const void* xinv_args, uint32_t tile0, uint32_t ntiles)
-#else
+#elif KW_FUSED_TU == 3
 kw_status kw_fused_xinv_density_tail(int chain, int terms, kw_ctx* ctx, int ncomp, const void* xinv_args, uint32_t tile0, uint32_t ntiles)
+#elif KW_FUSED_TU == 5
+kw_status kw_fused_xinv_density_plain(int chain, int terms, kw_ctx* ctx, int ncomp, const void* xinv_args, uint32_t tile0, uint32_t ntiles)
+#else
+kw_status kw_fused_xinv_density_tail_plain(int chain, int terms, kw_ctx* ctx, int ncomp, const void* xinv_args, uint32_t tile0, uint32_t ntiles)
 #endif
 {
-  constexpr bool T = (KW_FUSED_TU == 3);
+  constexpr bool T = (KW_FUSED_TU == 3 || KW_FUSED_TU == 6);
   const XinvArgs& a = *static_cast<const XinvArgs*>(xinv_args);
+#if KW_FUSED_TU == 1
+  if (!chain) return kw_fused_xinv_density_plain(chain, terms, ctx, ncomp, xinv_args, tile0, ntiles);
+#elif KW_FUSED_TU == 3
+  if (!chain) return kw_fused_xinv_density_tail_plain(chain, terms, ctx, ncomp, xinv_args, tile0, ntiles);
+#endif
   switch (2 * terms + chain)
   {
+#if KW_FUSED_TU == 5 || KW_FUSED_TU == 6
     case 0: return launch_xinv_impl<EPI_DENSITY, false, 0, T>(ctx, ncomp, a, tile0, ntiles);
     case 2: return launch_xinv_impl<EPI_DENSITY, false, 1, T>(ctx, ncomp, a, tile0, ntiles);
-    case 3: return launch_xinv_impl<EPI_DENSITY, true, 1, T>(ctx, ncomp, a, tile0, ntiles);
     case 4: return launch_xinv_impl<EPI_DENSITY, false, 2, T>(ctx, ncomp, a, tile0, ntiles);
-    case 5: return launch_xinv_impl<EPI_DENSITY, true, 2, T>(ctx, ncomp, a, tile0, ntiles);
     case 6: return launch_xinv_impl<EPI_DENSITY, false, 3, T>(ctx, ncomp, a, tile0, ntiles);
+#else
+    case 3: return launch_xinv_impl<EPI_DENSITY, true, 1, T>(ctx, ncomp, a, tile0, ntiles);
+    case 5: return launch_xinv_impl<EPI_DENSITY, true, 2, T>(ctx, ncomp, a, tile0, ntiles);
     case 7: return launch_xinv_impl<EPI_DENSITY, true, 3, T>(ctx, ncomp, a, tile0, ntiles);
+#endif
     default: kw_set_error("fused pipeline: no density epilogue for chain = %d, terms = %d", chain, terms); return KW_ERR_INVALID;
   }
 }

@@ -153,10 +153,15 @@ def test_fused_line_length_512(orc, syn, dims):
     (180, 16, 16), (16, 180, 16), (16, 16, 180), (360, 16, 16), (16, 360, 16), (16, 16, 360), (540, 16, 16),
     (16, 540, 16), (16, 16, 540), (90 * 2, 360, 16),                                               # 45 * 2^m, 135 * 4
     (400, 100, 100), (500, 100, 108),       # Ny * Nz a multiple of 16 but not of 32: 16-row x tiles from Nx = 400 on
+    (112, 224, 16), (224, 16, 112), (16, 112, 224), (448, 16, 16), (16, 448, 16), (16, 16, 448), (896, 16, 16),
+    (16, 896, 16), (16, 16, 896),                                                                  # 7 * 2^m
+    (168, 336, 16), (336, 16, 168), (16, 168, 336),                                                # 21 * 2^m
+    (280, 16, 16), (16, 280, 16), (16, 16, 280), (560, 16, 16), (16, 560, 16), (16, 16, 560),      # 35 * 2^m
+    (196, 392, 16), (392, 16, 196), (16, 196, 392),                                                # 49 * 2^m
 ])
 def test_fused_line_lengths_mixed_radix(orc, syn, dims):
-    """Line lengths with one radix-3 or radix-5 stage (or two radix-3) inside the register DFTs: every supported
-    length along every axis."""
+    """Line lengths with one radix-3, radix-5 or radix-7 stage (or two radix-3) inside the register DFTs: every
+    supported length along every axis."""
     for kw in (dict(nonlinear=True, absorbing=True), dict(nonlinear=False, absorbing=False)):
         pr = syn.make_problem(*dims, heterogeneous=True, source="p0", pml_size=4, **kw)
         g, o = make_gpu(pr, fused_kernels=True), orc.OracleSim(pr)
@@ -174,16 +179,19 @@ def test_fused_line_lengths_mixed_radix(orc, syn, dims):
     ((100, 100, 100), dict(u_non_staggered_raw=1)),         # cube of round 1's rocFFT-path list; the x-shift kernel too
     ((108, 100, 108), dict(source="p_source", source_mode=2)),  # 10 800 rows; k-space corrected source (EPI_STORE tail)
     ((64, 100, 300), {}),                                   # power-of-two x lines over a 4 * 25 by 4 * 75 plane
+    ((240, 100, 100), {}),                                  # 24-row x tiles (12 line pairs): 416 tiles + 16 rows
+    ((300, 108, 108), {}),                                  # 20-row x tiles (10 line pairs): 583 tiles + 4 rows
+    ((160, 100, 108), dict(u_non_staggered_raw=1)),         # 16-row x tiles (8 line pairs): 675 tiles, no partial one
 ])
 def test_grids_without_whole_x_tiles_stay_on_the_fused_pipeline(orc, syn, dims, opts):
-    """The x kernels take tiles of 32 (16) rows; a row count Ny * Nz that is no whole number of tiles ends in one masked
-    tile (TAIL kernels) instead of sending the whole grid to the rocFFT path."""
+    """The x kernels take tiles of 16 to 32 rows (per line length: nl_x in kw_fused.hip); a row count Ny * Nz that is no
+    whole number of tiles ends in one masked tile (TAIL kernels) instead of sending the whole grid to the rocFFT path."""
     opts = dict(opts)
     source, mode = opts.pop("source", "p0"), opts.pop("source_mode", 0)
     ny, nz = dims[1], dims[2]
     pr = syn.make_problem(*dims, heterogeneous=True, nonlinear=True, absorbing=True, source=source, source_mode=mode,
                           pml_size=4 if min(dims) >= 20 else 2, sensor="random", nt=12)
-    assert (ny * nz) % 32 == 16  # (the fused line lengths are multiples of 4: a partial tile is always half a tile)
+    assert (ny * nz) % 16 in (0, 4)  # (the fused line lengths are multiples of 4)
     g, o = make_gpu(pr, fused_kernels=True, p_raw=1, **opts), orc.OracleSim(pr)
     g.run(10)
     assert g.scalar("fused_pipeline") == 1.0

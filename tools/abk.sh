@@ -4,8 +4,8 @@
 # holds extra bench arguments of that build (e.g. "--size 600" for a KW_VARIANT_LENGTH=600 build).
 L=k-wave-fluid-cuda_amd/lib
 cp $L/libkwave_hip.so /tmp/libkwave_hip.keep
-for rep in 1 2; do
-  for d in ab/*/; do
+for rep in $(seq 1 ${REPS:-2}); do
+  for d in ab/${ABK_GLOB:-*}/; do
     v=$(basename $d)
     cp ab/$v/libkwave_hip.so $L/
     python bench.py --no-cpu --no-512 "$@" $(cat ab/$v/args 2>/dev/null) > gpurun_out/abk_${v}_${rep}.json 2> gpurun_out/abk_${v}_${rep}.err || { echo "$v FAILED"; tail -3 gpurun_out/abk_${v}_${rep}.err; continue; }

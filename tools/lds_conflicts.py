@@ -1,0 +1,130 @@
+#!/usr/bin/env python3
+"""LDS bank-conflict factors of the x kernels' exchange patterns for one line length (model: MI355X_MICROARCH.md, LDS table).
+python tools/lds_conflicts.py L R1 R2 [NL] [ZPpad LPalign RPpad]  — prints, per access pattern, LDS cycles / conflict-free cycles."""
+import sys
+from collections import defaultdict
+
+def groups(kind):
+    if kind in ("r32", "r64", "w32"):
+        return [list(range(0, 32)), list(range(32, 64))]
+    if kind == "w64":
+        return [list(range(g * 16, g * 16 + 16)) for g in range(4)]
+    if kind == "r128":
+        return [[0, 1, 2, 3, 12, 13, 14, 15, 20, 21, 22, 23, 24, 25, 26, 27], [4, 5, 6, 7, 8, 9, 10, 11, 16, 17, 18, 19, 28, 29, 30, 31],
+                [32, 33, 34, 35, 44, 45, 46, 47, 52, 53, 54, 55, 56, 57, 58, 59], [36, 37, 38, 39, 40, 41, 42, 43, 48, 49, 50, 51, 60, 61, 62, 63]]
+    if kind == "w128":
+        return [list(range(g * 8, g * 8 + 8)) for g in range(8)]
+    raise ValueError(kind)
+
+def cost(kind, addrs):
+    """addrs: per lane dword address (None = inactive lane) of ONE wave instruction; returns (cycles, ideal)"""
+    width = {"r32": 1, "w32": 1, "r64": 2, "w64": 2, "r128": 4, "w128": 4}[kind]
+    nb = 64 if kind in ("r64", "r128") else 32
+    cyc = ideal = 0
+    for g in groups(kind):
+        per_bank = defaultdict(set)
+        act = False
+        for l in g:
+            a = addrs[l]
+            if a is None:
+                continue
+            act = True
+            for d in range(width):
+                per_bank[(a + d) % nb].add((a + d) // nb)
+        if act:
+            ideal += 1
+            # a bank serves one dword per cycle; wide accesses spanning more than the banks take width*lanes/nb cycles at best
+            lanes = sum(1 for l in g if addrs[l] is not None)
+            base = max(1, -(-lanes * width // nb))
+            cyc += max(base, max(len(v) for v in per_bank.values()))
+            ideal += base - 1
+    return cyc, ideal
+
+FMAJOR = False
+
+def run(L, R1, R2, NL=16, ZP=None, LP=None, RP=None, quiet=False, IP=None):
+    TPL = max(R1, R2)
+    T = NL * TPL
+    if IP is None: IP = R2 + 1
+    LP0 = R1 * IP
+    if LP is None: LP = LP0 + ((16 - LP0 % 32) + 32) % 32
+    if ZP is None: ZP = L + 16
+    if RP is None: RP = L + 8
+    HALF = L // 2 + 1
+    Q4 = L // 4
+    def role(R, t):
+        if FMAJOR:
+            f, c = divmod(t, NL)
+        else:
+            c, f = divmod(t, R)
+        return (c, f) if t < NL * R else None
+    pats = {}
+    def add(name, kind, fn, reps):
+        tot = idl = 0
+        for rep in reps:
+            for w0 in range(0, T, 64):
+                addrs = [fn(t, rep) if t < T else None for t in range(w0, w0 + 64)]
+                if all(a is None for a in addrs): continue
+                c, i = cost(kind, addrs)
+                tot += c; idl += i
+        pats[name] = (tot, idl)
+    NE = -(-NL * HALF // T)
+    def herm(lo):
+        def fn(t, it):
+            e = t + it * T
+            if e >= NL * HALF: return None
+            cc, k = divmod(e, HALF)
+            if not lo and (k == 0 or k == L // 2): return None
+            return 2 * (cc * ZP + (k if lo else L - k))
+        return fn
+    add("inv: spectrum rows -> line buffer (w64, k)", "w64", herm(True), range(NE))
+    add("inv: ... mirrored half (w64, L-k)", "w64", herm(False), range(NE))
+    add("inv: line buffer -> step A regs (r64)", "r64", lambda t, n1: (lambda r: None if r is None else 2 * (r[0] * ZP + n1 * R2 + r[1]))(role(R2, t)), range(R1))
+    add("step A -> exchange (w64)", "w64", lambda t, k1: (lambda r: None if r is None else 2 * (r[0] * LP + k1 * IP + r[1]))(role(R2, t)), range(R1))
+    add("exchange -> step B (r64)", "r64", lambda t, n2: (lambda r: None if r is None else 2 * (r[0] * LP + r[1] * IP + n2))(role(R1, t)), range(R2))
+    add("inv: step B -> real tile (w32 x2)", "w32", lambda t, k2: (lambda r: None if r is None else (2 * r[0]) * RP + r[1] + R1 * k2)(role(R1, t)), range(R2))
+    NQ = 2 * NL * Q4 // T
+    add("real tile -> float4 (r128)", "r128", lambda t, q: (lambda e: (e // Q4) * RP + 4 * (e % Q4))(t + q * T), range(NQ))
+    add("chain: float4 -> real tile (w128)", "w128", lambda t, q: (lambda e: (e // Q4) * RP + 4 * (e % Q4))(t + q * T), range(NQ))
+    add("chain: real tile -> step A regs (r32 x2)", "r32", lambda t, n1: (lambda r: None if r is None else (2 * r[0]) * RP + n1 * R2 + r[1])(role(R2, t)), range(R1))
+    add("fwd: step B -> line buffer (w64)", "w64", lambda t, k2: (lambda r: None if r is None else 2 * (r[0] * ZP + r[1] + R1 * k2))(role(R1, t)), range(R2))
+    def hread(lo):
+        def fn(t, it):
+            e = t + it * T
+            if e >= NL * HALF: return None
+            cc, k = divmod(e, HALF)
+            return 2 * (cc * ZP + (k if lo else (0 if k == 0 else L - k)))
+        return fn
+    add("fwd: line buffer -> half spectra (r64, k)", "r64", hread(True), range(NE))
+    add("fwd: ... (r64, L-k)", "r64", hread(False), range(NE))
+    tot = sum(v[0] for v in pats.values()); idl = sum(v[1] for v in pats.values())
+    if not quiet:
+        print(f"L={L} = {R1} x {R2}, NL={NL}, threads {T}, ZP={ZP} LP={LP} (inner {IP}) RP={RP}; LDS floats2 {NL * max(LP, ZP)}")
+        for k, (c, i) in pats.items():
+            print(f"  {k:46s} {c:6d} cycles, conflict-free {i:6d}  x{c / i:4.2f}")
+        print(f"  total {tot} vs {idl}: x{tot / idl:.2f}")
+    return tot, idl, pats
+
+if __name__ == "__main__":
+    a = [int(x) for x in sys.argv[1:]]
+    L, R1, R2 = a[:3]
+    NL = a[3] if len(a) > 3 else 16
+    kw = {}
+    if len(a) > 4: kw["ZP"] = a[4]
+    if len(a) > 5: kw["LP"] = a[5]
+    if len(a) > 6: kw["RP"] = a[6]
+    if len(a) > 7: kw["IP"] = a[7]
+    run(L, R1, R2, NL, **kw)
+
+
+def search(L, R1, R2, NL=16, span=48):
+    """best pitches per parameter (the patterns of each are independent of the others)"""
+    zkeys = ("inv: spectrum rows", "inv: ... mirrored", "inv: line buffer", "fwd: step B", "fwd: line buffer", "fwd: ... (r64")
+    lkeys = ("step A -> exchange", "exchange -> step B")
+    rkeys = ("inv: step B -> real", "real tile -> float4", "chain: float4", "chain: real tile")
+    def score(pats, keys): return sum(v[0] for k, v in pats.items() if k.startswith(keys))
+    bz = min(range(L, L + span + 1), key=lambda z: (score(run(L, R1, R2, NL, ZP=z, quiet=True)[2], zkeys), z))
+    bl = min(((ip, lp) for ip in range(R2, R2 + 4) for lp in range(R1 * ip, R1 * ip + span + 1)),
+             key=lambda t: (score(run(L, R1, R2, NL, LP=t[1], IP=t[0], quiet=True)[2], lkeys), t[1]))
+    br = min(range(L, L + span + 1, 4), key=lambda r: (score(run(L, R1, R2, NL, RP=r, quiet=True)[2], rkeys), r))
+    return bz, bl[1], bl[0], br
