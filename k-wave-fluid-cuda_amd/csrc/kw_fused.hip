@@ -55,7 +55,7 @@ namespace {
 
 constexpr int NLMAX = 16; // widest tile: 16 complex = 128-B segments (also the row-pitch granule)
 // x passes, rows per block = 2 * nl_x.  Chosen per line length from a measured matrix (every length from 160 up, both
-// orientations of its factor pair, 8 / 10 / 12 / 16 line pairs: profiles/r03_length_tuning.txt, tools/length_tuning_table.py).
+// orientations of its factor pair, 8 / 10 / 12 / 16 line pairs; 4 / 8 / 16 from 96 to 144: profiles/r03_length_tuning.txt).
 // What the matrix shows: a block should be a whole number of 4 waves or less — the 5- and 6-wave blocks of 18, 20 and 24
 // threads per line at 16 line pairs are rarely co-resident (one wave more on one SIMD than on the others), 240^3: x-inverse
 // kernels 1.4-1.5x faster at 12 line pairs — and the long lines want the small block's register budget.
@@ -67,7 +67,7 @@ constexpr int nl_x(int L)
 {
   switch (L)
   {
-    case 160: case 168: case 196: case 200: case 224: case 288: case 336: case 384: case 392: return 8;
+    case 100: case 108: case 160: case 168: case 196: case 200: case 224: case 288: case 336: case 384: case 392: return 8;
     case 280: case 300: case 320: case 432: case 480: case 500: case 600: return 10;
     case 180: case 216: case 240: case 324: case 360: case 400: return 12;
     case 896: return 16;
