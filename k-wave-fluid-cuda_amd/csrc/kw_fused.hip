@@ -79,6 +79,16 @@ constexpr int nl_x(int L)
 // segments) for the long lines: y passes 1.5x, z-fused 1.25x slower; 240^3 with 12- and 8-column tiles (4- and 3-wave
 // blocks instead of 5): step 11 % and 15 % slower.
 constexpr int nl_yz(int) { return 16; }
+// ... except the z-fused kernels of 240- and 400-point lines (20 threads per line: 5-wave blocks, of which a CU mostly
+// holds one): 32-column tiles — one 10-wave block, 256-B row segments — take 16 % / 10 % off them (the y-passes of the
+// same lengths lose with 32 columns, every other length loses in both: profiles/r03_length_tuning.txt)
+#ifdef KW_TUNE_NLZ
+constexpr int nl_z(int) { return KW_TUNE_NLZ; }
+#else
+constexpr int nl_z(int L) { return (L == 240 || L == 400) ? 32 : 16; }
+#endif
+// tiles of nl_z columns over the P (a multiple of 16) columns of a row
+constexpr uint32_t z_tiles(uint32_t P, uint32_t len) { return (P + static_cast<uint32_t>(nl_z(len)) - 1u) / static_cast<uint32_t>(nl_z(len)); }
 
 constexpr int cmax(int a, int b) { return a > b ? a : b; }
 // 20- to 32-point register DFTs next to a multi-array epilogue want more than 256 VGPRs, which leaves ONE wave per SIMD
@@ -451,11 +461,11 @@ struct ZArgs
 // forward write.
 // COLWRITE (square factorisations only, used by the 2 x 256 split kernels): the transposed cell assignment — thread k1
 // writes its column and thread q1 reads its row — for an exchange that follows one whose read was by columns.
-template<int L, bool COLWRITE = false>
+template<int L, bool COLWRITE = false, int NLV = nl_yz(L)>
 __device__ __forceinline__ void inverse_from_regs(float2 (&w)[Fac<L>::R2], float2 (&v)[Fac<L>::R1], float2* lds, int c,
                                                   int j, const float2* twl)
 {
-  using G = Geo<L>;
+  using G = Geo<L, NLV>;
   constexpr int R1 = G::R1, R2 = G::R2;
   static_assert(!COLWRITE || R1 == R2, "transposed exchange needs a square factorisation");
   if (ACTW(R1, j))
@@ -482,9 +492,9 @@ __device__ __forceinline__ void inverse_from_regs(float2 (&w)[Fac<L>::R2], float
 // One block owns the z-lines of tile (ky = blockIdx.y, kx tile = blockIdx.x) of `narr` arrays (VGRAD: the three velocity
 // spectra, ABSORB: the two pressure terms), processed back to back: the lines of array i+1 are in flight while array i
 // is transformed, and kappa is fetched once for all three velocity components.  PGRAD has one input and three outputs.
-template<int L, int MODE> __global__ __launch_bounds__(Geo<L>::THREADS, big_line_waves(L)) void k_zfused(ZArgs a)
+template<int L, int MODE> __global__ __launch_bounds__((Geo<L, nl_z(L)>::THREADS), big_line_waves(L)) void k_zfused(ZArgs a)
 {
-  using G = Geo<L>;
+  using G = Geo<L, nl_z(L)>;
   constexpr int R1 = G::R1, R2 = G::R2;
   constexpr bool WA = (R2 == G::TPL) || ((G::NL * R2) % 64 == 0 && 64 % G::NL == 0); // step-A participants: whole waves
   __shared__ float2 lds[G::LDSB];
@@ -622,7 +632,7 @@ template<int L, int MODE> __global__ __launch_bounds__(Geo<L>::THREADS, big_line
         }
       }
       float2 r[R1];
-      inverse_from_regs<L>(w, r, lds, c, j, twl);
+      inverse_from_regs<L, false, G::NL>(w, r, lds, c, j, twl);
       float2* __restrict__ out = a.out[(MODE == Z_PGRAD) ? 2 * o : arr];
       if (ACTW(R2, j) && valid)
       {
@@ -2015,13 +2025,13 @@ template<int MODE> kw_status launch_zfused(kw_ctx* ctx, int narr, ZArgs a)
   // kernels 10.6 -> 8.8 us, step +4 %; at 128^3, 640 blocks, the in-block walk with its prefetch is still the faster form)
   uint32_t split = 1;
   if ((MODE == Z_VGRAD || MODE == Z_ABSORB) && narr > 1 &&
-      (f.P / nl_yz(f.nz_global) + side_tile) * f.nyl < 2u * static_cast<uint32_t>(ctx->cu_count))
+      (z_tiles(f.P, f.nz_global) + side_tile) * f.nyl < 2u * static_cast<uint32_t>(ctx->cu_count))
   {
     split  = static_cast<uint32_t>(narr);
     a.narr = 1;
   }
-  const dim3 grid(f.P / nl_yz(f.nz_global) + side_tile, f.nyl, split);
-#define M(LEN) LAUNCH((k_zfused<LEN, MODE>), grid, dim3(Geo<LEN>::THREADS), a)
+  const dim3 grid(z_tiles(f.P, f.nz_global) + side_tile, f.nyl, split);
+#define M(LEN) LAUNCH((k_zfused<LEN, MODE>), grid, dim3((Geo<LEN, nl_z(LEN)>::THREADS)), a)
   KW_LEN_SWITCH(f.nz_global, M)
 #undef M
   return KW_OK;
@@ -3127,9 +3137,9 @@ kw_status kw_fused_shift_velocity(kw_ctx* ctx, int axis, const float* in, float*
     z.narr    = 1;
     z.lstride = nyl * z.P;
     z.bstride = z.P;
-    const uint32_t nl = nl_yz(f.nz_global);
+    const uint32_t nl = nl_z(f.nz_global);
     const dim3 grid((z.nxc + nl - 1) / nl, nyl, 1);
-#define M(LEN) LAUNCH((k_zfused<LEN, Z_SHIFT>), grid, dim3(Geo<LEN>::THREADS), z)
+#define M(LEN) LAUNCH((k_zfused<LEN, Z_SHIFT>), grid, dim3((Geo<LEN, nl_z(LEN)>::THREADS)), z)
     KW_LEN_SWITCH(f.nz_global, M)
 #undef M
     KW_TRY(xstart_bytes(ctx, KW_ZSHIFT_SLOT, rcv, snd, chunk * sizeof(float)));
@@ -3174,9 +3184,9 @@ kw_status kw_fused_shift_velocity(kw_ctx* ctx, int axis, const float* in, float*
   const uint32_t lines = (axis == 1) ? c.nz : c.ny;
   z.lstride = (axis == 1) ? z.P : c.ny * z.P;
   z.bstride = (axis == 1) ? c.ny * z.P : z.P;
-  const uint32_t nl = nl_yz(len);
+  const uint32_t nl = nl_z(len);
   const dim3 grid((z.nxc + nl - 1) / nl, lines, 1);
-#define M(LEN) LAUNCH((k_zfused<LEN, Z_SHIFT>), grid, dim3(Geo<LEN>::THREADS), z)
+#define M(LEN) LAUNCH((k_zfused<LEN, Z_SHIFT>), grid, dim3((Geo<LEN, nl_z(LEN)>::THREADS)), z)
   KW_LEN_SWITCH(len, M)
 #undef M
   return KW_OK;
