@@ -16,11 +16,13 @@ def gpu(pr, **kw):
     return HostSolver(pr, **kw)
 
 
-@pytest.mark.parametrize("seed", range(36))
+@pytest.mark.parametrize("seed", range(44))
 def test_random_configuration(orc, syn, seed):
     rng = np.random.default_rng(1000 + seed)
-    # seeds 24..35: line lengths with radix-3 / radix-5 stages
-    dims = [int(rng.choice([16, 32, 64] if seed < 24 else [16, 48, 72, 80, 96])) for _ in range(3)]
+    # seeds 24..35: line lengths with radix-3 / radix-5 stages; 36..43: radix-7 stages, large-factor-first pairs (108) and
+    # x tiles of 8 line pairs (100, 108)
+    sizes = [16, 32, 64] if seed < 24 else [16, 48, 72, 80, 96] if seed < 36 else [16, 48, 100, 108, 112]
+    dims = [int(rng.choice(sizes)) for _ in range(3)]
     if seed % 5 == 0:
         dims[int(rng.integers(3))] = 128 if seed < 24 else 120
     source = str(rng.choice(["p0", "p_source", "u_source", "transducer"]))
