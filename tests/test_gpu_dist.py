@@ -42,6 +42,9 @@ def run_ranks(world, dims, steps, source, mode, tmp_path, backend="gloo", medium
     (2, (16, 16, 512), "p0", 0),        # 512-point z lines on the transposed spectra
     (2, (48, 96, 80), "p0", 0),         # radix-3 / radix-5 lines; 48 ky rows per rank (no power of two)
     (4, (32, 120, 48), "p_source", 2),  # 30 ky rows, 12 planes per rank
+    (2, (240, 108, 112), "p0", 0),      # large-factor-first pairs (20 x 12, 18 x 6), 24-row x tiles, radix-7 z lines
+    (2, (32, 16, 240), "p_source", 1),  # 240-point z lines: 32-column z-fused tiles over 16-column exchanged rows
+    (4, (100, 240, 48), "u_source", 2), # 240-point y lines with packed per-peer addressing, 60 ky rows per rank
 ])
 def test_slab_ranks_match_oracle(orc, syn, tmp_path, world, dims, source, mode):
     steps = 20
