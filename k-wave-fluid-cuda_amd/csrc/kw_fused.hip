@@ -67,9 +67,9 @@ constexpr int nl_x(int L)
 {
   switch (L)
   {
-    case 100: case 108: case 160: case 168: case 196: case 200: case 224: case 288: case 336: case 384: case 392: return 8;
+    case 100: case 108: case 140: case 160: case 168: case 196: case 200: case 224: case 288: case 336: case 384: case 392: return 8;
     case 280: case 300: case 320: case 432: case 480: case 500: case 600: return 10;
-    case 180: case 216: case 240: case 324: case 360: case 400: return 12;
+    case 180: case 216: case 240: case 252: case 324: case 360: case 400: return 12;
     case 896: return 16;
     default: return L >= 400 ? 8 : 16;
   }
@@ -1849,15 +1849,16 @@ template<int L> __global__ __launch_bounds__(GeoX<L>::THREADS) void k_probe_xinv
 // ---- host side ------------------------------------------------------------------------------------------------------
 // line lengths with a two-factor register decomposition L = R1 * R2, R1, R2 in {4 ... 32} with at most one odd prime
 // power (3, 9, 27, 5, 25, 7) each: 2^m, 3 * 2^m, 9 * 2^m, 27 * 2^m, 81 * 4, 5 * 2^m, 15 * 2^m, 25 * 2^m, 75 * 2^m, 125 * 4,
-// 45 * 2^m (180, 360), 135 * 4 (540), 7 * 2^m (112 ... 896), 21 * 2^m (168, 336), 35 * 2^m (280, 560), 49 * 2^m (196,
-// 392); the x kernels need L % 4 == 0 and whole float4 counts per thread
+// 45 * 2^m (180, 360), 135 * 4 (540), 7 * 2^m (112 ... 896), 21 * 2^m (168, 336, 672), 35 * 2^m (140, 280, 560), 49 * 2^m
+// (196, 392, 784), 63 * 2^m (252, 504), 105 * 2^m (420, 840), 45 * 16 (720), 225 * 4 (900), 15 * 64 (960: 30 x 32, the
+// 15 * 2^m register DFTs); the x kernels need L % 4 == 0 and whole float4 counts per thread (L / (2 * max(R1, R2)) whole)
 #ifdef KW_FUSED_ONLY /* tuning builds: one line length only (-DKW_FUSED_ONLY=256), compiles in seconds */
 #define KW_FUSED_LENGTHS(X) X(KW_FUSED_ONLY)
 #else
-#define KW_FUSED_LENGTHS(X) X(16) X(32) X(48) X(64) X(72) X(80) X(96) X(100) X(108) X(112) X(120) X(128) X(144) X(160)  \
-  X(168) X(180) X(192) X(196) X(200) X(216) X(224) X(240) X(256) X(280) X(288) X(300) X(320) X(324) X(336) X(360) X(384)   \
-  X(392) X(400) X(432) X(448) X(480) X(500) X(512) X(540) X(560) X(576) X(600) X(640) X(648) X(768) X(896)   \
-  X(1024)
+#define KW_FUSED_LENGTHS(X) X(16) X(32) X(48) X(64) X(72) X(80) X(96) X(100) X(108) X(112) X(120) X(128) X(140) X(144)  \
+  X(160) X(168) X(180) X(192) X(196) X(200) X(216) X(224) X(240) X(252) X(256) X(280) X(288) X(300) X(320) X(324) X(336)   \
+  X(360) X(384) X(392) X(400) X(420) X(432) X(448) X(480) X(500) X(504) X(512) X(540) X(560) X(576) X(600) X(640) X(648)   \
+  X(672) X(720) X(768) X(784) X(840) X(896) X(900) X(960) X(1024)
 #endif
 bool supported_len(uint32_t n)
 {

@@ -158,6 +158,11 @@ def test_fused_line_length_512(orc, syn, dims):
     (168, 336, 16), (336, 16, 168), (16, 168, 336),                                                # 21 * 2^m
     (280, 16, 16), (16, 280, 16), (16, 16, 280), (560, 16, 16), (16, 560, 16), (16, 16, 560),      # 35 * 2^m
     (196, 392, 16), (392, 16, 196), (16, 196, 392),                                                # 49 * 2^m
+    (140, 252, 16), (252, 16, 140), (16, 140, 252), (504, 16, 16), (16, 504, 16), (16, 16, 504),   # 35 * 4, 63 * 2^m
+    (672, 16, 16), (16, 672, 16), (16, 16, 672), (784, 16, 16), (16, 784, 16), (16, 16, 784),      # 21 * 32, 49 * 16
+    (420, 16, 16), (16, 420, 16), (16, 16, 420), (840, 16, 16), (16, 840, 16), (16, 16, 840),      # 105 * 2^m (14 x 30, 28 x 30)
+    (720, 16, 16), (16, 720, 16), (16, 16, 720), (900, 16, 16), (16, 900, 16), (16, 16, 900),      # 24 x 30, 30 x 30
+    (960, 16, 16), (16, 960, 16), (16, 16, 960),                                                   # 30 x 32
 ])
 def test_fused_line_lengths_mixed_radix(orc, syn, dims):
     """Line lengths with one radix-3, radix-5 or radix-7 stage (or two radix-3) inside the register DFTs: every
