@@ -20,7 +20,7 @@ INCLUDE = os.path.join(ROOT, "include")
 ROCM = os.environ.get("ROCM_PATH", "/opt/rocm")
 HIPCC = os.path.join(ROCM, "bin", "hipcc")
 
-FUSED_TUS = (1, 3, 5, 6, 2, 4, 0)  # passes over kw_fused.hip, slowest first
+FUSED_TUS = (7, 8, 0, 2, 1, 5, 3, 6, 4)  # passes over kw_fused.hip, slowest first
 HIP_LIB = os.path.join(LIB_DIR, "libkwave_hip.so")
 HOST_LIB = os.path.join(LIB_DIR, "libkwave_host.so")
 

@@ -30,11 +30,12 @@
 using namespace kwfft;
 
 // The x-inverse + epilogue kernels are the bulk of this file's compile time and code size (one kernel per epilogue
-// variant and line length).  They are compiled in six extra passes over this file, side by side with the main pass
+// variant and line length).  They are compiled in eight extra passes over this file, side by side with the main pass
 // (build.py):
-//   KW_FUSED_TU == 0  everything except those kernels;  1  the chained density epilogues;  5  the density epilogues that
-//                  store their terms;  2  the other epilogues;  3 / 6 / 4  the masked (TAIL) forms of 1 / 5 / 2, which
-//                  only grids with a partial last x tile ever launch.
+//   KW_FUSED_TU == 0  everything except those kernels;  1 / 7  the chained density epilogues of the lines below / from
+//                  KW_LONG_LINES elements;  5 / 8  the density epilogues that store their terms, likewise;  2  the other
+//                  epilogues;  3 / 6 / 4  the masked (TAIL) forms of 1 + 7 / 5 + 8 / 2, which only grids with a partial
+//                  last x tile ever launch.
 // Every pass is a code object of its own that the runtime loads at the first launch out of it: a run pays for the
 // variants it uses.  The main pass reaches the others through the functions below (XinvArgs passed as an opaque pointer:
 // the struct lives in this file's anonymous namespace).
@@ -46,6 +47,9 @@ kw_status kw_fused_xinv_other(int epi, int chain, kw_ctx* ctx, int ncomp, const 
 kw_status kw_fused_xinv_density_tail(int chain, int terms, kw_ctx* ctx, int ncomp, const void* xinv_args, uint32_t tile0, uint32_t ntiles);
 kw_status kw_fused_xinv_density_plain(int chain, int terms, kw_ctx* ctx, int ncomp, const void* xinv_args, uint32_t tile0, uint32_t ntiles);
 kw_status kw_fused_xinv_density_tail_plain(int chain, int terms, kw_ctx* ctx, int ncomp, const void* xinv_args, uint32_t tile0, uint32_t ntiles);
+kw_status kw_fused_xinv_density_long(int chain, int terms, kw_ctx* ctx, int ncomp, const void* xinv_args, uint32_t tile0, uint32_t ntiles);
+kw_status kw_fused_xinv_density_plain_long(int chain, int terms, kw_ctx* ctx, int ncomp, const void* xinv_args, uint32_t tile0, uint32_t ntiles);
+#define KW_LONG_LINES 432 /* passes 7 / 8 hold the density epilogues of the x lines from this length on */
 kw_status kw_fused_xinv_other_tail(int epi, int chain, kw_ctx* ctx, int ncomp, const void* xinv_args, uint32_t tile0, uint32_t ntiles);
 // whole-plane tiles (small grids, see k_xinv): tile0 / ntiles count z-planes; in passes 1 / 2
 kw_status kw_fused_xinv_density_plane(int chain, int terms, kw_ctx* ctx, int ncomp, const void* xinv_args, uint32_t tile0, uint32_t ntiles);
@@ -75,6 +79,21 @@ constexpr int nl_x(int L)
   }
 }
 #endif
+// Every fast-path length is a multiple of 4, so the Ny * Nz rows of a 3-D grid on one GPU are a multiple of 16 and x tiles of
+// 8 line pairs (16 rows) always divide it: only 2-D grids and slabs with Ny * Nz(local) off a multiple of 16 ever need the
+// masked (TAIL) kernels of such a length.  For the long lines added in round 3 — the most expensive kernels of the file to
+// compile — those are not built; kw_fused_supported sends such a grid to the rocFFT path.
+constexpr bool has_partial_x_tiles(int L)
+{
+  switch (L)
+  {
+    case 672: case 700: case 720: case 756: case 784: case 800: case 840: case 864: case 900: case 960: return false;
+    default: return true;
+  }
+}
+#define KW_NO_TAIL(LEN)                                                                                                \
+  { kw_set_error("fused pipeline: rows of %d elements have no partial x tiles", LEN); return KW_ERR_INVALID; }
+
 // y / z passes, columns per tile: 16 (128-B row segments) at every length.  500^3 measured with 8-column tiles (64-B
 // segments) for the long lines: y passes 1.5x, z-fused 1.25x slower; 240^3 with 12- and 8-column tiles (4- and 3-wave
 // blocks instead of 5): step 11 % and 15 % slower.
@@ -1234,8 +1253,13 @@ __global__ __launch_bounds__((Geo<L, PLANE ? L / 2 : nl_x(L)>::THREADS), (EPI ==
   constexpr int NA  = (EPI == EPI_DENSITY) ? 3 : (EPI == EPI_PSUM) ? 2 : 1;
   constexpr int RP  = L + 8;                       // real-tile row pitch (floats): conflict-free 4-B scatter
   constexpr int Q4  = L / 4;                       // float4 per row
-  constexpr int NQ  = (2 * G::NL * Q4) / G::THREADS;  // float4 per thread
-  static_assert((2 * G::NL * Q4) % G::THREADS == 0, "tile must divide evenly");
+  constexpr int TOT4 = 2 * G::NL * Q4;              // float4 of the real tile
+  constexpr int NQ  = (TOT4 + G::THREADS - 1) / G::THREADS;  // float4 per thread
+  // L / 2 not a multiple of the threads per line (25 x 28, 27 x 28, 25 x 32, 27 x 32): the tile does not divide by the block;
+  // the surplus lanes of the last round read the tile's last float4 (XE) and store nothing (XE_OK)
+  constexpr bool QPART = (TOT4 % G::THREADS) != 0;
+#define XE(q) (QPART ? min(static_cast<int>(threadIdx.x) + (q) * G::THREADS, TOT4 - 1) : static_cast<int>(threadIdx.x) + (q) * G::THREADS)
+#define XE_OK(q) (!QPART || static_cast<int>(threadIdx.x) + (q) * G::THREADS < TOT4)
   __shared__ float2 lds[G::LDSX];
   __shared__ float2 twl[G::TWN];
   __shared__ float2 Yp[PLANE ? L * (L / 2 + 1) : 1]; // PLANE: the plane's half-spectrum between its y and x transforms
@@ -1279,7 +1303,7 @@ __global__ __launch_bounds__((Geo<L, PLANE ? L / 2 : nl_x(L)>::THREADS), (EPI ==
 #pragma unroll
     for (int q = 0; q < NQ; q++)
     {
-      const int e   = threadIdx.x + q * G::THREADS;
+      const int e   = XE(q);
       const int row = e / Q4;
       const int x4  = e - row * Q4;
       res[i][q]     = *reinterpret_cast<const float4*>(&ldsr[row * RP + 4 * x4]);
@@ -1312,7 +1336,7 @@ __global__ __launch_bounds__((Geo<L, PLANE ? L / 2 : nl_x(L)>::THREADS), (EPI ==
 #pragma unroll
     for (int g = 0; g < GQ; g++)
     {
-      const int      e   = threadIdx.x + (q0 + g) * G::THREADS;
+      const int      e   = XE(q0 + g);
       const uint32_t r   = TAIL ? min(tile_row0 + e / Q4, a.nrows - 1u) : tile_row0 + e / Q4; // operands of a masked row: the last row's
       const uint32_t z   = r / k.ny;
       const uint32_t y   = r - z * k.ny;
@@ -1353,11 +1377,12 @@ __global__ __launch_bounds__((Geo<L, PLANE ? L / 2 : nl_x(L)>::THREADS), (EPI ==
     for (int g = 0; g < GQ; g++)
     {
       const int      q = q0 + g;
-      const int      e = threadIdx.x + q * G::THREADS;
+      const int      e = XE(q);
       const uint32_t r = tile_row0 + e / Q4;
       const uint32_t x = XFIX ? xfix : 4u * (e % Q4);
       const uint32_t i = r * L + x;
-      const bool     row_ok = !TAIL || r < a.nrows; // every store below is predicated on it
+      const bool     e_ok   = XE_OK(q);                          // (the chained rows in LDS are predicated on it)
+      const bool     row_ok = (!TAIL || r < a.nrows) && e_ok;     // every global store below is predicated on it
       const float4   pmx = XFIX ? pmlx4 : opx[g];
       if (EPI == EPI_STORE)
       {
@@ -1464,7 +1489,7 @@ __global__ __launch_bounds__((Geo<L, PLANE ? L / 2 : nl_x(L)>::THREADS), (EPI ==
             f4put(o2, t, r0 * eDuSum);
           }
           if (row_ok) st4(a.t[1] + i, o1); // the nonlinear term is read again by the pressure sum (a stage later: cached or not, same time)
-          if constexpr (CHAIN) { *reinterpret_cast<float4*>(&ldsr[(e / Q4) * RP + x]) = o2; fw[0][q] = o0; }
+          if constexpr (CHAIN) { if (e_ok) *reinterpret_cast<float4*>(&ldsr[(e / Q4) * RP + x]) = o2; fw[0][q] = o0; }
           else { if (row_ok) st4(a.t[0] + i, o0); if (row_ok) st4(a.t[2] + i, o2); }
         }
         else if (terms == 3)
@@ -1481,7 +1506,7 @@ __global__ __launch_bounds__((Geo<L, PLANE ? L / 2 : nl_x(L)>::THREADS), (EPI ==
             else f4put(pn, t, f4get(c24, t) * rhoSum);
           }
           if (row_ok) st4(a.t[0] + i, pn);
-          if constexpr (CHAIN) *reinterpret_cast<float4*>(&ldsr[(e / Q4) * RP + x]) = pn;
+          if constexpr (CHAIN) { if (e_ok) *reinterpret_cast<float4*>(&ldsr[(e / Q4) * RP + x]) = pn; }
         }
         else if (terms == 1)
         { // :1733-1741
@@ -1494,7 +1519,7 @@ __global__ __launch_bounds__((Geo<L, PLANE ? L / 2 : nl_x(L)>::THREADS), (EPI ==
             f4put(o1, t, f4get(r04, t) * duSum);
           }
           if (row_ok) st4(a.t[0] + i, o0); // the density sum is read again by the pressure sum
-          if constexpr (CHAIN) { *reinterpret_cast<float4*>(&ldsr[(e / Q4) * RP + x]) = o1; fw[0][q] = o0; }
+          if constexpr (CHAIN) { if (e_ok) *reinterpret_cast<float4*>(&ldsr[(e / Q4) * RP + x]) = o1; fw[0][q] = o0; }
           else if (row_ok) st4(a.t[1] + i, o1);
         }
       }
@@ -1529,10 +1554,10 @@ __global__ __launch_bounds__((Geo<L, PLANE ? L / 2 : nl_x(L)>::THREADS), (EPI ==
 #pragma unroll
         for (int q = 0; q < NQ; q++)
         {
-          const int e   = threadIdx.x + q * G::THREADS;
+          const int e   = XE(q);
           const int row = e / Q4;
           const int x4  = e - row * Q4;
-          *reinterpret_cast<float4*>(&ldsr[row * RP + 4 * x4]) = fw[FW0_IN_LDS ? 0 : jf][q];
+          if (XE_OK(q)) *reinterpret_cast<float4*>(&ldsr[row * RP + 4 * x4]) = fw[FW0_IN_LDS ? 0 : jf][q];
         }
       }
       lds_barrier();
@@ -1574,8 +1599,8 @@ template<int L, bool TAIL = false> __global__ __launch_bounds__(GeoX<L>::THREADS
 {
   using G = GeoX<L>;
   constexpr int R1 = G::R1, R2 = G::R2;
-  constexpr int RP = L + 8, Q4 = L / 4, NQ = (2 * G::NL * Q4) / G::THREADS;
-  static_assert((2 * G::NL * Q4) % G::THREADS == 0, "tile must divide evenly");
+  constexpr int RP = L + 8, Q4 = L / 4, TOT4 = 2 * G::NL * Q4, NQ = (TOT4 + G::THREADS - 1) / G::THREADS;
+  constexpr bool QPART = (TOT4 % G::THREADS) != 0; // (see k_xinv)
   __shared__ float2 lds[G::LDSX];
   __shared__ float2 twl[G::TWN];
   load_twiddles<L>(twl, a.tw);
@@ -1649,10 +1674,10 @@ template<int L, bool TAIL = false> __global__ __launch_bounds__(GeoX<L>::THREADS
 #pragma unroll
   for (int q = 0; q < NQ; q++)
   {
-    const int e   = threadIdx.x + q * G::THREADS;
+    const int e   = XE(q);
     const int row = e / Q4;
     const int x4  = e - row * Q4;
-    if (!TAIL || tile_row0 + row < a.nrows)
+    if ((!TAIL || tile_row0 + row < a.nrows) && XE_OK(q))
       st4(a.out + (tile_row0 + row) * L + 4 * x4, *reinterpret_cast<const float4*>(&ldsr[row * RP + 4 * x4]));
   }
 }
@@ -1851,14 +1876,23 @@ template<int L> __global__ __launch_bounds__(GeoX<L>::THREADS) void k_probe_xinv
 // power (3, 9, 27, 5, 25, 7) each: 2^m, 3 * 2^m, 9 * 2^m, 27 * 2^m, 81 * 4, 5 * 2^m, 15 * 2^m, 25 * 2^m, 75 * 2^m, 125 * 4,
 // 45 * 2^m (180, 360), 135 * 4 (540), 7 * 2^m (112 ... 896), 21 * 2^m (168, 336, 672), 35 * 2^m (140, 280, 560), 49 * 2^m
 // (196, 392, 784), 63 * 2^m (252, 504), 105 * 2^m (420, 840), 45 * 16 (720), 225 * 4 (900), 15 * 64 (960: 30 x 32, the
-// 15 * 2^m register DFTs); the x kernels need L % 4 == 0 and whole float4 counts per thread (L / (2 * max(R1, R2)) whole)
+// 15 * 2^m register DFTs), 175 * 4 (700), 189 * 4 (756), 25 * 32 (800), 27 * 32 (864); the x kernels need L % 4 == 0 (where
+// L / 2 is no multiple of the threads per line their float4 tile ends in a partial round: QPART in k_xinv)
 #ifdef KW_FUSED_ONLY /* tuning builds: one line length only (-DKW_FUSED_ONLY=256), compiles in seconds */
 #define KW_FUSED_LENGTHS(X) X(KW_FUSED_ONLY)
 #else
-#define KW_FUSED_LENGTHS(X) X(16) X(32) X(48) X(64) X(72) X(80) X(96) X(100) X(108) X(112) X(120) X(128) X(140) X(144)  \
-  X(160) X(168) X(180) X(192) X(196) X(200) X(216) X(224) X(240) X(252) X(256) X(280) X(288) X(300) X(320) X(324) X(336)   \
-  X(360) X(384) X(392) X(400) X(420) X(432) X(448) X(480) X(500) X(504) X(512) X(540) X(560) X(576) X(600) X(640) X(648)   \
-  X(672) X(720) X(768) X(784) X(840) X(896) X(900) X(960) X(1024)
+#define KW_FUSED_LENGTHS_SHORT(X) X(16) X(32) X(48) X(64) X(72) X(80) X(96) X(100) X(108) X(112) X(120) X(128) X(140)  \
+  X(144) X(160) X(168) X(180) X(192) X(196) X(200) X(216) X(224) X(240) X(252) X(256) X(280) X(288) X(300) X(320) X(324)  \
+  X(336) X(360) X(384) X(392) X(400) X(420)
+#define KW_FUSED_LENGTHS_LONG(X) X(432) X(448) X(480) X(500) X(504) X(512) X(540) X(560) X(576) X(600) X(640) X(648)     \
+  X(672) X(700) X(720) X(756) X(768) X(784) X(800) X(840) X(864) X(896) X(900) X(960) X(1024)
+#if KW_FUSED_TU == 1 || KW_FUSED_TU == 5
+#define KW_FUSED_LENGTHS(X) KW_FUSED_LENGTHS_SHORT(X)
+#elif KW_FUSED_TU == 7 || KW_FUSED_TU == 8
+#define KW_FUSED_LENGTHS(X) KW_FUSED_LENGTHS_LONG(X)
+#else
+#define KW_FUSED_LENGTHS(X) KW_FUSED_LENGTHS_SHORT(X) KW_FUSED_LENGTHS_LONG(X)
+#endif
 #endif
 bool supported_len(uint32_t n)
 {
@@ -1916,7 +1950,7 @@ kw_status launch_xfwd(kw_ctx* ctx, int narr, const float* const* in, float2* con
   { // the partial last tile, masked
     a.tile0 = full;
     const dim3 grid(1, narr, 1);
-#define M(LEN) LAUNCH((k_xfwd<LEN, true>), grid, dim3(GeoX<LEN>::THREADS), a)
+#define M(LEN) if constexpr (!has_partial_x_tiles(LEN)) KW_NO_TAIL(LEN) else LAUNCH((k_xfwd<LEN, true>), grid, dim3(GeoX<LEN>::THREADS), a)
     KW_LEN_SWITCH(c.nx, M)
 #undef M
   }
@@ -2073,7 +2107,7 @@ kw_status launch_xinv_impl(kw_ctx* ctx, int ncomp, XinvArgs a, uint32_t tile0, u
 {
   a.tile0 = tile0;
   const dim3 grid(ntiles, ncomp, 1);
-#define M(LEN) LAUNCH((k_xinv<LEN, EPI, CHAIN, TERMS, TAIL>), grid, dim3(GeoX<LEN>::THREADS), a)
+#define M(LEN) if constexpr (TAIL && !has_partial_x_tiles(LEN)) KW_NO_TAIL(LEN) else LAUNCH((k_xinv<LEN, EPI, CHAIN, TERMS, TAIL>), grid, dim3(GeoX<LEN>::THREADS), a)
   KW_LEN_SWITCH(ctx->c.nx, M)
 #undef M
   return KW_OK;
@@ -2643,28 +2677,36 @@ kw_status create_impl(kw_ctx* ctx, void* const s[3], void* const t[3])
 #endif // KW_FUSED_TU == 0
 } // namespace
 
-#if KW_FUSED_TU == 1 || KW_FUSED_TU == 3 || KW_FUSED_TU == 5 || KW_FUSED_TU == 6
-// passes 1 / 3: the chained density epilogues (and the entry points); passes 5 / 6: the ones that store their terms
+#if KW_FUSED_TU == 1 || KW_FUSED_TU == 3 || KW_FUSED_TU == 5 || KW_FUSED_TU == 6 || KW_FUSED_TU == 7 || KW_FUSED_TU == 8
+// passes 1 / 7 / 3: the chained density epilogues (1 and 3 hold the entry points); passes 5 / 8 / 6: the ones that store
+// their terms
 #if KW_FUSED_TU == 1
 kw_status kw_fused_xinv_density(int chain, int terms, kw_ctx* ctx, int ncomp, const void* xinv_args, uint32_t tile0, uint32_t ntiles)
 #elif KW_FUSED_TU == 3
 kw_status kw_fused_xinv_density_tail(int chain, int terms, kw_ctx* ctx, int ncomp, const void* xinv_args, uint32_t tile0, uint32_t ntiles)
 #elif KW_FUSED_TU == 5
 kw_status kw_fused_xinv_density_plain(int chain, int terms, kw_ctx* ctx, int ncomp, const void* xinv_args, uint32_t tile0, uint32_t ntiles)
-#else
+#elif KW_FUSED_TU == 6
 kw_status kw_fused_xinv_density_tail_plain(int chain, int terms, kw_ctx* ctx, int ncomp, const void* xinv_args, uint32_t tile0, uint32_t ntiles)
+#elif KW_FUSED_TU == 7
+kw_status kw_fused_xinv_density_long(int chain, int terms, kw_ctx* ctx, int ncomp, const void* xinv_args, uint32_t tile0, uint32_t ntiles)
+#else
+kw_status kw_fused_xinv_density_plain_long(int chain, int terms, kw_ctx* ctx, int ncomp, const void* xinv_args, uint32_t tile0, uint32_t ntiles)
 #endif
 {
   constexpr bool T = (KW_FUSED_TU == 3 || KW_FUSED_TU == 6);
   const XinvArgs& a = *static_cast<const XinvArgs*>(xinv_args);
 #if KW_FUSED_TU == 1
+  if (ctx->c.nx >= KW_LONG_LINES)
+    return chain ? kw_fused_xinv_density_long(chain, terms, ctx, ncomp, xinv_args, tile0, ntiles)
+                 : kw_fused_xinv_density_plain_long(chain, terms, ctx, ncomp, xinv_args, tile0, ntiles);
   if (!chain) return kw_fused_xinv_density_plain(chain, terms, ctx, ncomp, xinv_args, tile0, ntiles);
 #elif KW_FUSED_TU == 3
   if (!chain) return kw_fused_xinv_density_tail_plain(chain, terms, ctx, ncomp, xinv_args, tile0, ntiles);
 #endif
   switch (2 * terms + chain)
   {
-#if KW_FUSED_TU == 5 || KW_FUSED_TU == 6
+#if KW_FUSED_TU == 5 || KW_FUSED_TU == 6 || KW_FUSED_TU == 8
     case 0: return launch_xinv_impl<EPI_DENSITY, false, 0, T>(ctx, ncomp, a, tile0, ntiles);
     case 2: return launch_xinv_impl<EPI_DENSITY, false, 1, T>(ctx, ncomp, a, tile0, ntiles);
     case 4: return launch_xinv_impl<EPI_DENSITY, false, 2, T>(ctx, ncomp, a, tile0, ntiles);
@@ -2793,6 +2835,7 @@ kw_status kw_fused_supported(kw_ctx* ctx, int* out)
   bool ok = supported_len(c.nx) && supported_len(c.ny) && supported_len(nzg);
   if (!f.slab && c.nz == 1) ok = supported_len(c.nx) && supported_len(c.ny); // 2-D: x-pass, fused y-pass, x-pass
   if (f.slab) ok = ok && (nzg == c.nz * f.nranks) && (c.ny % f.nranks == 0);
+  if (ok && !has_partial_x_tiles(static_cast<int>(c.nx))) ok = (c.ny * c.nz) % (2u * static_cast<uint32_t>(nl_x(c.nx))) == 0;
   const uint64_t P64 = (c.nx_complex + NLMAX - 1) / NLMAX * NLMAX;
   ok = ok && (P64 * c.ny * c.nz < (1ull << 32)) && (static_cast<uint64_t>(c.nx) * c.ny * c.nz < (1ull << 32));
   *out = ok ? 1 : 0;
@@ -3164,7 +3207,7 @@ kw_status kw_fused_shift_velocity(kw_ctx* ctx, int axis, const float* in, float*
     if (a.nrows % rows_per_tile != 0)
     {
       a.tile0 = full;
-#define M(LEN) LAUNCH((k_xshift<LEN, true>), dim3(1, 1, 1), dim3(GeoX<LEN>::THREADS), a)
+#define M(LEN) if constexpr (!has_partial_x_tiles(LEN)) KW_NO_TAIL(LEN) else LAUNCH((k_xshift<LEN, true>), dim3(1, 1, 1), dim3(GeoX<LEN>::THREADS), a)
       KW_LEN_SWITCH(c.nx, M)
 #undef M
     }

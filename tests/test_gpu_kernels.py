@@ -78,7 +78,7 @@ def hermitian_filter(half, n):
 
 @pytest.mark.parametrize("dims", [(32, 48, 16), (64, 16, 96), (256, 32, 16), (16, 256, 32), (32, 16, 512), (80, 72, 120), (108, 300, 216), (500, 16, 648),
                                   (224, 112, 168), (392, 16, 280),
-                                  (420, 16, 252), (16, 720, 140)])
+                                  (420, 16, 252), (16, 720, 140), (800, 16, 48), (756, 48, 16)])
 @pytest.mark.parametrize("axis", [0, 1, 2])
 def test_fused_shift_velocity_matches_oracle(orc, syn, dims, axis):
     """One kernel per axis (two real x-neighbours or rows packed into one complex line) against the oracle's

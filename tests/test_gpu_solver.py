@@ -163,6 +163,9 @@ def test_fused_line_length_512(orc, syn, dims):
     (420, 16, 16), (16, 420, 16), (16, 16, 420), (840, 16, 16), (16, 840, 16), (16, 16, 840),      # 105 * 2^m (14 x 30, 28 x 30)
     (720, 16, 16), (16, 720, 16), (16, 16, 720), (900, 16, 16), (16, 900, 16), (16, 16, 900),      # 24 x 30, 30 x 30
     (960, 16, 16), (16, 960, 16), (16, 16, 960),                                                   # 30 x 32
+    (700, 16, 16), (16, 700, 16), (16, 16, 700), (756, 16, 16), (16, 756, 16), (16, 16, 756),      # L / 2 no multiple of the
+    (800, 16, 16), (16, 800, 16), (16, 16, 800), (864, 16, 16), (16, 864, 16), (16, 16, 864),      # threads per line: x tiles
+    (800, 48, 100), (864, 16, 48),                                                                # end in a partial round
 ])
 def test_fused_line_lengths_mixed_radix(orc, syn, dims):
     """Line lengths with one radix-3, radix-5 or radix-7 stage (or two radix-3) inside the register DFTs: every

@@ -24,8 +24,8 @@ def compile_tu(args):
 def main():
     length = int(sys.argv[1]) if len(sys.argv) > 1 else 256
     extra = sys.argv[2:]
-    with tempfile.TemporaryDirectory() as tmp, concurrent.futures.ThreadPoolExecutor(7) as pool:
-        texts = list(pool.map(compile_tu, [(length, tu, tmp, extra) for tu in (0, 1, 2, 3, 4, 5, 6)]))
+    with tempfile.TemporaryDirectory() as tmp, concurrent.futures.ThreadPoolExecutor(8) as pool:
+        texts = list(pool.map(compile_tu, [(length, tu, tmp, extra) for tu in (0, 1, 2, 3, 4, 5, 6, 7, 8)]))
     pat = re.compile(r"Function Name: (\S+).*?VGPRs: (\d+).*?AGPRs: (\d+).*?ScratchSize \[bytes/lane\]: (\d+).*?"
                      r"Occupancy \[waves/SIMD\]: (\d+).*?LDS Size \[bytes/block\]: (\d+)", re.S)
     for txt in texts:
