@@ -179,3 +179,23 @@ def test_gpu_2d_fused_pass_on_other_line_lengths(orc, syn, dims):
     assert not g.field("uz").any() and not g.field("rhoz").any()
     g.close()
     o.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dims,fused", [((720, 48), True), ((720, 100), False), ((800, 64), True), ((448, 100), True)])
+def test_gpu_2d_long_lines_without_masked_kernels(orc, syn, dims, fused):
+    """the ten longest lengths of round 3 carry no masked (TAIL) x kernels: a 2-D grid whose Ny rows are no whole number of
+    16-row x tiles runs on the rocFFT path there (720 x 100), any other one on the fused pipeline; older lengths keep their
+    masked kernels (448 x 100: 6 tiles + 4 rows)"""
+    from kwave_amd.solver import HostSolver
+    pr = problem2d(syn, dims[0], dims[1], heterogeneous=True, nonlinear=True, absorbing=True, source="p0", nt=14)
+    g = HostSolver(pr, p_raw=1)
+    o = orc.OracleSim(pr)
+    o.step(12)
+    g.run(12)
+    assert (g.scalar("fused_pipeline") == 1.0) == fused, dims
+    for f in ("p", "ux", "uy", "rhoy"):
+        assert rel_l2(g.field(f), o.field(f)) < TOL, (f, dims)
+    g.close()
+    o.close()
+
